@@ -1,0 +1,244 @@
+// extern "C" surface of libm2d.so -- see include/m2d.h for the contract and the reference
+// interfaces each entry point replaces.  No exceptions cross this boundary.
+#include <string.h>
+
+#include <new>
+
+#include "m2d_engine.h"
+
+namespace {
+
+std::string g_create_error;
+
+int fail(m2d_engine *h, int code, const char *msg)
+{
+    if (h) h->last_error = msg; else g_create_error = msg;
+    return code;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// copy a host table to HBM (engine-owned) or borrow a device pointer
+int adopt_table(m2d_engine *h, const float *src, size_t count, int flags, const float **dst, bool *own)
+{
+    if (flags == M2D_TABLES_DEVICE) {
+        *dst = src;
+        *own = false;
+        return M2D_OK;
+    }
+    float *d = nullptr;
+    M2D_HIP_TRY(h, hipMalloc((void **)&d, count * sizeof(float)));
+    hipError_t e = hipMemcpy(d, src, count * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        h->last_error = std::string("hipMemcpy(table): ") + hipGetErrorString(e);
+        return M2D_ERR_HIP;
+    }
+    *dst = d;
+    *own = true;
+    return M2D_OK;
+}
+
+void release(m2d_engine *h)
+{
+    if (h->own_pm && h->pm) (void)hipFree((void *)h->pm);
+    if (h->own_re && h->re) (void)hipFree((void *)h->re);
+    if (h->own_ce && h->ce) (void)hipFree((void *)h->ce);
+    if (h->own_dish_cats && h->dish_cats) (void)hipFree((void *)h->dish_cats);
+    if (h->dish_vec) (void)hipFree(h->dish_vec);
+    if (h->scratch) (void)hipFree(h->scratch);
+    if (h->err_dev) (void)hipFree(h->err_dev);
+    if (h->err_host) (void)hipHostFree(h->err_host);
+}
+
+}  // namespace
+
+extern "C" {
+
+int m2d_abi_version(void) { return 1; }
+
+int m2d_create(const float *pm, const float *re, const float *ce, int64_t U, int64_t I, int32_t C, int32_t E,
+               float coef, int device, int table_flags, m2d_engine **out)
+{
+    if (!out) return fail(nullptr, M2D_ERR_INVALID_ARG, "m2d_create: out is null");
+    *out = nullptr;
+    if (!pm || !re || !ce) return fail(nullptr, M2D_ERR_INVALID_ARG, "m2d_create: null table pointer");
+    if (U <= 0 || I <= 0 || C <= 0 || E <= 0)
+        return fail(nullptr, M2D_ERR_INVALID_ARG, "m2d_create: U, I, C, E must be positive");
+    if (I > INT32_MAX || U > (int64_t)INT32_MAX)
+        return fail(nullptr, M2D_ERR_UNSUPPORTED, "m2d_create: ids are int32 (Model_Recommender.py:26-29)");
+    if (table_flags != M2D_TABLES_HOST && table_flags != M2D_TABLES_DEVICE)
+        return fail(nullptr, M2D_ERR_INVALID_ARG, "m2d_create: bad table_flags");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, M2D_ERR_NO_DEVICE,
+                    "m2d_create: no HIP device visible (this engine has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, M2D_ERR_INVALID_ARG, "m2d_create: bad device index");
+    m2d_engine *h = new (std::nothrow) m2d_engine();
+    if (!h) return fail(nullptr, M2D_ERR_HIP, "m2d_create: out of host memory");
+    h->U = U; h->I = I; h->C = C; h->E = E; h->device = device;
+    h->a = coef;            // float32(coef)               Model_Recommender.py:17
+    h->b = 1.0f - h->a;     // evaluated in float32        Model_Recommender.py:96
+    int rc = M2D_OK;
+    auto bail = [&](int code) {
+        g_create_error = h->last_error;
+        release(h);
+        delete h;
+        return code;
+    };
+    if (hipSetDevice(device) != hipSuccess) { h->last_error = "hipSetDevice failed"; return bail(M2D_ERR_HIP); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        h->num_cu = prop.multiProcessorCount;
+    if ((rc = adopt_table(h, pm, (size_t)U * (C + 1) * E, table_flags, &h->pm, &h->own_pm)) != M2D_OK) return bail(rc);
+    if ((rc = adopt_table(h, re, (size_t)I * E, table_flags, &h->re, &h->own_re)) != M2D_OK) return bail(rc);
+    if ((rc = adopt_table(h, ce, (size_t)C * E, table_flags, &h->ce, &h->own_ce)) != M2D_OK) return bail(rc);
+    if (!aligned16(h->pm) || !aligned16(h->re) || !aligned16(h->ce)) {
+        h->last_error = "m2d_create: device tables must be 16-byte aligned";
+        return bail(M2D_ERR_INVALID_ARG);
+    }
+    if (hipMalloc((void **)&h->err_dev, 4 * sizeof(int32_t)) != hipSuccess ||
+        hipMemset(h->err_dev, 0, 4 * sizeof(int32_t)) != hipSuccess ||
+        hipHostMalloc((void **)&h->err_host, 4 * sizeof(int32_t)) != hipSuccess) {
+        h->last_error = "m2d_create: could not allocate the error latch";
+        return bail(M2D_ERR_HIP);
+    }
+    *out = h;
+    return M2D_OK;
+}
+
+int m2d_destroy(m2d_engine *h)
+{
+    if (!h) return M2D_OK;
+    (void)hipSetDevice(h->device);
+    release(h);
+    delete h;
+    return M2D_OK;
+}
+
+const char *m2d_last_error(const m2d_engine *h) { return h ? h->last_error.c_str() : g_create_error.c_str(); }
+
+const char *m2d_last_kernel(const m2d_engine *h) { return h ? h->last_kernel : ""; }
+
+int m2d_set_user_base(m2d_engine *h, int64_t user_base)
+{
+    if (!h) return M2D_ERR_INVALID_ARG;
+    if (user_base < 0 || user_base + h->U > (int64_t)INT32_MAX + 1)
+        return fail(h, M2D_ERR_INVALID_ARG, "m2d_set_user_base: shard range leaves int32");
+    h->user_base = user_base;
+    return M2D_OK;
+}
+
+int m2d_set_dish_categories(m2d_engine *h, const float *cats, int table_flags)
+{
+    if (!h || !cats) return fail(h, M2D_ERR_INVALID_ARG, "m2d_set_dish_categories: null argument");
+    if (table_flags != M2D_TABLES_HOST && table_flags != M2D_TABLES_DEVICE)
+        return fail(h, M2D_ERR_INVALID_ARG, "m2d_set_dish_categories: bad table_flags");
+    M2D_HIP_TRY(h, hipSetDevice(h->device));
+    if (h->own_dish_cats && h->dish_cats) (void)hipFree((void *)h->dish_cats);
+    h->dish_cats = nullptr;
+    h->own_dish_cats = false;
+    h->dish_vec_valid = false;
+    int rc = adopt_table(h, cats, (size_t)h->I * h->C, table_flags, &h->dish_cats, &h->own_dish_cats);
+    if (rc != M2D_OK) return rc;
+    if (!aligned16(h->dish_cats)) return fail(h, M2D_ERR_INVALID_ARG, "dish categories must be 16-byte aligned");
+    return M2D_OK;
+}
+
+int m2d_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats, int64_t B,
+                    float *out, void *stream)
+{
+    if (!h) return M2D_ERR_INVALID_ARG;
+    if (B < 0) return fail(h, M2D_ERR_INVALID_ARG, "m2d_score_pairs: negative batch");
+    if (B == 0) return M2D_OK;
+    if (!users || !items || !cats || !out) return fail(h, M2D_ERR_INVALID_ARG, "m2d_score_pairs: null buffer");
+    if (h->C == 4 && !aligned16(cats)) return fail(h, M2D_ERR_INVALID_ARG, "m2d_score_pairs: cats must be 16-byte aligned");
+    M2D_HIP_TRY(h, hipSetDevice(h->device));
+    return m2d_launch_score_pairs(h, users, items, cats, false, B, out, (hipStream_t)stream);
+}
+
+int m2d_score_pairs_bydish(m2d_engine *h, const int32_t *users, const int32_t *items, int64_t B, float *out,
+                           void *stream)
+{
+    if (!h) return M2D_ERR_INVALID_ARG;
+    if (B < 0) return fail(h, M2D_ERR_INVALID_ARG, "m2d_score_pairs_bydish: negative batch");
+    if (B == 0) return M2D_OK;
+    if (!users || !items || !out) return fail(h, M2D_ERR_INVALID_ARG, "m2d_score_pairs_bydish: null buffer");
+    if (!h->dish_cats) return fail(h, M2D_ERR_NOT_CONFIGURED, "call m2d_set_dish_categories first");
+    M2D_HIP_TRY(h, hipSetDevice(h->device));
+    return m2d_launch_score_pairs(h, users, items, h->dish_cats, true, B, out, (hipStream_t)stream);
+}
+
+int m2d_rank_candidates(m2d_engine *h, const int32_t *users, const int32_t *items, const int32_t *lens,
+                        int64_t nseg, int32_t L, int32_t k, float *out_scores, int32_t *out_items,
+                        int32_t *out_flags, void *stream)
+{
+    if (!h) return M2D_ERR_INVALID_ARG;
+    if (nseg < 0 || L < 1 || L > 1024 || k < 1 || k > 64)
+        return fail(h, M2D_ERR_INVALID_ARG, "m2d_rank_candidates: need nseg >= 0, 1 <= L <= 1024, 1 <= k <= 64");
+    if (nseg == 0) return M2D_OK;
+    if (!users || !items || !out_scores || !out_items || !out_flags)
+        return fail(h, M2D_ERR_INVALID_ARG, "m2d_rank_candidates: null buffer");
+    if (!h->dish_cats) return fail(h, M2D_ERR_NOT_CONFIGURED, "call m2d_set_dish_categories first");
+    M2D_HIP_TRY(h, hipSetDevice(h->device));
+    return m2d_launch_rank_candidates(h, users, items, lens, nseg, L, k, out_scores, out_items, out_flags,
+                                      (hipStream_t)stream);
+}
+
+int m2d_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, float *out_scores,
+                   int32_t *out_ids, void *stream)
+{
+    if (!h) return M2D_ERR_INVALID_ARG;
+    if (nU < 0 || k < 1 || k > 64 || (int64_t)k > h->I)
+        return fail(h, M2D_ERR_INVALID_ARG, "m2d_topk_users: need nU >= 0 and 1 <= k <= min(64, I)");
+    if (nU == 0) return M2D_OK;
+    if (!users || !out_scores || !out_ids) return fail(h, M2D_ERR_INVALID_ARG, "m2d_topk_users: null buffer");
+    if (!h->dish_cats) return fail(h, M2D_ERR_NOT_CONFIGURED, "call m2d_set_dish_categories first");
+    M2D_HIP_TRY(h, hipSetDevice(h->device));
+    return m2d_launch_topk_users(h, users, nU, k, out_scores, out_ids, (hipStream_t)stream);
+}
+
+int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_index)
+{
+    if (!h) return M2D_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    M2D_HIP_TRY(h, hipSetDevice(h->device));
+    M2D_HIP_TRY(h, hipMemcpyAsync(h->err_host, h->err_dev, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    M2D_HIP_TRY(h, hipStreamSynchronize(st));
+    const int code = h->err_host[0];
+    if (code == 0) return M2D_OK;
+    const int64_t value = h->err_host[1];
+    const int64_t index = ((int64_t)(uint32_t)h->err_host[3] << 32) | (uint32_t)h->err_host[2];
+    if (bad_value) *bad_value = value;
+    if (bad_index) *bad_index = index;
+    M2D_HIP_TRY(h, hipMemsetAsync(h->err_dev, 0, 4 * sizeof(int32_t), st));
+    M2D_HIP_TRY(h, hipStreamSynchronize(st));
+    h->last_error = std::string(code == M2D_ERR_BAD_USER_ID ? "user" : "item") + " id " + std::to_string(value) +
+                    " at position " + std::to_string(index) + " is out of range";
+    return code;
+}
+
+int m2d_set_option(m2d_engine *h, const char *name, int64_t value)
+{
+    if (!h || !name) return M2D_ERR_INVALID_ARG;
+    if (!strcmp(name, "prefetch")) h->opt_prefetch = (int)value;
+    else if (!strcmp(name, "nt_loads")) h->opt_nt = (int)value;
+    else if (!strcmp(name, "blocks_per_cu")) h->opt_blocks_per_cu = (int)value;
+    else if (!strcmp(name, "variant")) h->opt_variant = (int)value;
+    else return fail(h, M2D_ERR_INVALID_ARG, "m2d_set_option: unknown option");
+    return M2D_OK;
+}
+
+int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value)
+{
+    if (!h || !name || !value) return M2D_ERR_INVALID_ARG;
+    if (!strcmp(name, "prefetch")) *value = h->opt_prefetch;
+    else if (!strcmp(name, "nt_loads")) *value = h->opt_nt;
+    else if (!strcmp(name, "blocks_per_cu")) *value = h->opt_blocks_per_cu;
+    else if (!strcmp(name, "variant")) *value = h->opt_variant;
+    else if (!strcmp(name, "num_cu")) *value = h->num_cu;
+    else return M2D_ERR_INVALID_ARG;
+    return M2D_OK;
+}
+
+}  // extern "C"

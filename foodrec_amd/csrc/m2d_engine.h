@@ -1,0 +1,65 @@
+// Engine state shared by the ABI layer and the kernel launchers (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/m2d.h"
+
+struct m2d_engine {
+    // tables in HBM, row-major, float32 (Model_Recommender.py:45-53)
+    const float *pm = nullptr;  // [U, C+1, E]
+    const float *re = nullptr;  // [I, E]
+    const float *ce = nullptr;  // [C, E]
+    const float *dish_cats = nullptr;  // [I, C] or null
+    bool own_pm = false, own_re = false, own_ce = false, own_dish_cats = false;
+    int64_t U = 0, I = 0;
+    int32_t C = 0, E = 0;
+    int64_t user_base = 0;
+    float a = 0.f;  // float32(coef)             Model_Recommender.py:17
+    float b = 0.f;  // 1.0f - a, taken in float32 Model_Recommender.py:96
+    int device = 0;
+    int num_cu = 256;
+
+    // id-error latch: {code, bad value, index lo, index hi}; cleared by m2d_check
+    int32_t *err_dev = nullptr;
+    int32_t *err_host = nullptr;  // pinned
+
+    // factored dish vectors for catalogue retrieval (built lazily by m2d_topk_users)
+    float *dish_vec = nullptr;  // [I_pad, (C+1)*E]
+    int64_t dish_vec_rows = 0;
+    bool dish_vec_valid = false;
+
+    // scratch for rank_candidates
+    float *scratch = nullptr;
+    size_t scratch_bytes = 0;
+
+    // benchmarking knobs
+    int opt_prefetch = 2;
+    int opt_nt = 1;
+    int opt_blocks_per_cu = 8;
+    int opt_variant = 0;
+
+    std::string last_error;
+    const char *last_kernel = "";
+};
+
+#define M2D_HIP_TRY(h, expr)                                                                   \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (h)->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);               \
+            return M2D_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+// launchers (m2d_score.hip / m2d_topk.hip); all enqueue on `stream` and return a status
+int m2d_launch_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
+                           bool by_dish, int64_t B, float *out, hipStream_t stream);
+int m2d_launch_rank_candidates(m2d_engine *h, const int32_t *users, const int32_t *items,
+                               const int32_t *lens, int64_t nseg, int32_t L, int32_t k, float *out_scores,
+                               int32_t *out_items, int32_t *out_flags, hipStream_t stream);
+int m2d_launch_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, float *out_scores,
+                          int32_t *out_ids, hipStream_t stream);

@@ -1,0 +1,298 @@
+// Fused pair-score kernels for gfx950 (MI355X): one pass over
+//   gather PM[user] ((C+1)*E floats, contiguous)      Model_Recommender.py:57-62
+//   gather RE[item] (E floats)                        Model_Recommender.py:63-66
+//   masked category dot (high level)                  Model_Recommender.py:67-80
+//   masked low-level dot                              Model_Recommender.py:82-93
+//   blend                                             Model_Recommender.py:95-97
+// with none of the [B, C, E] temporaries the TF graph materialises.
+//
+// Mapping (wave64).  A wave owns 64 consecutive pairs ("chunk"): lane i reads pair i's two ids and
+// its mask with coalesced loads and finally stores pair i's score, so every id/mask/score access is
+// one full 256-B (or 1-KiB) wave transaction.  Inside the chunk the wave is cut into 64/LPP groups
+// of LPP lanes; a group walks its LPP pairs one per step, lane j of the group holding float4 column
+// j of every row, so each row read is LPP*16 contiguous bytes (256 B at E = 64).  The Category_Embedding
+// fragment a lane needs (C float4) never changes and lives in registers.  PF steps of row loads
+// are kept in flight ahead of the arithmetic; the rows of Personal_Memory are read once and can
+// be marked non-temporal so they do not evict the (re-used) dish rows from L2 / Infinity Cache.
+//
+// HBM-bound: ~1 flop per byte.  Algorithmic bytes per pair = (C+2)*E*4 + C*4 + 12.
+#include "m2d_engine.h"
+
+namespace {
+
+struct ScoreArgs {
+    const float *pm;
+    const float *re;
+    const float *ce;
+    const int32_t *users;
+    const int32_t *items;
+    const float *cats;  // [B, C] (explicit feed) or [I, C] (by dish)
+    float *out;
+    int64_t B;
+    int64_t U;
+    int64_t I;
+    int64_t user_base;
+    int32_t E;
+    int32_t C;
+    float a;
+    float b;
+    int32_t *err;
+};
+
+__device__ __forceinline__ void latch_error(int32_t *err, int code, int64_t value, int64_t index)
+{
+    if (atomicCAS(&err[0], 0, code) == 0) {
+        err[1] = (int32_t)value;
+        err[2] = (int32_t)(index & 0xffffffff);
+        err[3] = (int32_t)(index >> 32);
+    }
+}
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ v4f ld4(const v4f *p)
+{
+    if constexpr (NT)
+        return __builtin_nontemporal_load(p);
+    else
+        return *p;
+}
+
+__device__ __forceinline__ float dot4(const v4f &x, const v4f &y, float acc)
+{
+    acc = fmaf(x.x, y.x, acc);
+    acc = fmaf(x.y, y.y, acc);
+    acc = fmaf(x.z, y.z, acc);
+    acc = fmaf(x.w, y.w, acc);
+    return acc;
+}
+
+__device__ __forceinline__ v4f scale4(float s, const v4f &x) { return s * x; }
+
+// Sum over the LPP lanes of a group; every lane of the group ends with the total.
+template <int LPP>
+__device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int off = LPP / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// C == 4 categories, E % 4 == 0, E / 4 <= LPP.  FULL: E / 4 == LPP (no idle lanes).
+template <int LPP, int PF, bool BYDISH, bool NT, bool FULL>
+__global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
+{
+    constexpr int C = 4;
+    const int lane = threadIdx.x & 63;
+    const int j = lane & (LPP - 1);
+    const int E4 = FULL ? LPP : (p.E >> 2);
+    const bool col_ok = FULL || (j < E4);
+    const int jc = col_ok ? j : 0;  // idle lanes re-read column 0 (in bounds), contribution zeroed
+    const int64_t nchunks = (p.B + 63) >> 6;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+
+    const v4f *pm4 = reinterpret_cast<const v4f *>(p.pm);
+    const v4f *re4 = reinterpret_cast<const v4f *>(p.re);
+    const v4f *ce4 = reinterpret_cast<const v4f *>(p.ce);
+    const size_t urow4 = (size_t)(C + 1) * E4;  // float4 per user block
+
+    v4f cef[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        cef[c] = ce4[(size_t)c * E4 + jc];
+        if (!col_ok) cef[c] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int64_t chunk = wave0; chunk < nchunks; chunk += nwaves) {
+        const int64_t pi = (chunk << 6) + lane;
+        const bool valid = pi < p.B;
+        int32_t uid = valid ? p.users[pi] : (int32_t)p.user_base;
+        int32_t did = valid ? p.items[pi] : 0;
+        int64_t ul = (int64_t)uid - p.user_base;
+        bool bad = false;
+        if (ul < 0 || ul >= p.U) {
+            latch_error(p.err, M2D_ERR_BAD_USER_ID, uid, pi);
+            ul = 0;
+            bad = true;
+        }
+        if (did < 0 || (int64_t)did >= p.I) {
+            latch_error(p.err, M2D_ERR_BAD_ITEM_ID, did, pi);
+            did = 0;
+            bad = true;
+        }
+        v4f m = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            const v4f *cp = reinterpret_cast<const v4f *>(p.cats);
+            m = BYDISH ? cp[did] : cp[pi];
+        }
+        const int32_t ul32 = (int32_t)ul;
+
+        v4f ub[PF][C + 1];
+        v4f ib[PF];
+        float my_high = 0.f, my_low = 0.f;
+
+        auto issue = [&](int s, int slot) {
+            const int32_t us = __shfl(ul32, s, LPP);
+            const int32_t ds = __shfl(did, s, LPP);
+            const v4f *pu = pm4 + (size_t)us * urow4 + jc;
+#pragma unroll
+            for (int r = 0; r <= C; ++r) ub[slot][r] = ld4<NT>(pu + (size_t)r * E4);
+            ib[slot] = re4[(size_t)ds * E4 + jc];
+        };
+
+#pragma unroll
+        for (int k = 0; k < PF; ++k) issue(k, k);
+
+        for (int s0 = 0; s0 < LPP; s0 += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int s = s0 + k;
+                const float m0 = __shfl(m.x, s, LPP);
+                const float m1 = __shfl(m.y, s, LPP);
+                const float m2 = __shfl(m.z, s, LPP);
+                const float m3 = __shfl(m.w, s, LPP);
+                const float mc[C] = {m0, m1, m2, m3};
+                float hs = 0.f, ls = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const v4f dish_category = scale4(mc[c], cef[c]);        // :67
+                    hs = dot4(ub[k][0], dish_category, hs);                    // :71, :75
+                    const v4f dish_memory = scale4(mc[c], ub[k][c + 1]);    // :82
+                    ls = dot4(ib[k], dish_memory, ls);                         // :86, :90
+                }
+                if (!FULL && !col_ok) ls = 0.f;
+                if (s + PF < LPP) issue(s + PF, k);
+                hs = group_sum<LPP>(hs);
+                ls = group_sum<LPP>(ls);
+                if (j == s) {
+                    my_high = hs;
+                    my_low = ls;
+                }
+            }
+        }
+        if (valid) {
+            const float n = (m.x + m.y) + (m.z + m.w);                         // :77
+            const float high = my_high / n;                                    // :79
+            const float low = my_low / n;                                      // :92
+            float score = __fadd_rn(__fmul_rn(p.a, high), __fmul_rn(p.b, low));     // :95-96, no fma contraction
+            if (bad) score = __builtin_nanf("");
+            p.out[pi] = score;
+        }
+    }
+}
+
+// Any C (<= 64), any E: one wave per pair, lanes stride over e.  Slow path for shapes the
+// vectorised kernel does not cover (E % 4 != 0, E > 256, C != 4).
+template <bool BYDISH>
+__global__ __launch_bounds__(256) void m2d_score_pairs_generic(ScoreArgs p)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int C = p.C, E = p.E;
+    for (int64_t pi = wave0; pi < p.B; pi += nwaves) {
+        int32_t uid = p.users[pi];
+        int32_t did = p.items[pi];
+        int64_t ul = (int64_t)uid - p.user_base;
+        bool bad = false;
+        if (ul < 0 || ul >= p.U) {
+            if (lane == 0) latch_error(p.err, M2D_ERR_BAD_USER_ID, uid, pi);
+            ul = 0;
+            bad = true;
+        }
+        if (did < 0 || (int64_t)did >= p.I) {
+            if (lane == 0) latch_error(p.err, M2D_ERR_BAD_ITEM_ID, did, pi);
+            did = 0;
+            bad = true;
+        }
+        const float *um = p.pm + (size_t)ul * (size_t)(C + 1) * E;
+        const float *it = p.re + (size_t)did * E;
+        const float *mrow = p.cats + (BYDISH ? (size_t)did * C : (size_t)pi * C);
+        float hs = 0.f, ls = 0.f, n = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float mc = mrow[c];
+            n += mc;
+            for (int e = lane; e < E; e += 64) {
+                hs = fmaf(um[e], mc * p.ce[(size_t)c * E + e], hs);
+                ls = fmaf(it[e], mc * um[(size_t)(c + 1) * E + e], ls);
+            }
+        }
+        hs = group_sum<64>(hs);
+        ls = group_sum<64>(ls);
+        if (lane == 0) {
+            float score = __fadd_rn(__fmul_rn(p.a, hs / n), __fmul_rn(p.b, ls / n));
+            if (bad) score = __builtin_nanf("");
+            p.out[pi] = score;
+        }
+    }
+}
+
+template <int LPP, bool FULL, bool BYDISH>
+void launch_c4(const ScoreArgs &a, int pf, bool nt, dim3 grid, hipStream_t st, const char **name)
+{
+#define M2D_CASE(PFV, NTV)                                                                           \
+    if (pf == PFV && nt == NTV) {                                                                    \
+        hipLaunchKernelGGL((m2d_score_pairs_c4<LPP, PFV, BYDISH, NTV, FULL>), grid, dim3(256), 0, st, a); \
+        return;                                                                                      \
+    }
+    *name = "m2d_score_pairs_c4";
+    M2D_CASE(1, false) M2D_CASE(1, true) M2D_CASE(2, false) M2D_CASE(2, true)
+    M2D_CASE(4, false) M2D_CASE(4, true)
+#undef M2D_CASE
+}
+
+template <bool BYDISH>
+int launch_any(m2d_engine *h, const ScoreArgs &a, hipStream_t st)
+{
+    const int64_t nchunks = (a.B + 63) >> 6;
+    int pf = h->opt_prefetch;
+    if (pf != 1 && pf != 2 && pf != 4) pf = 2;
+    const bool nt = h->opt_nt != 0;
+    const int E4 = a.E >> 2;
+    const bool vec_ok = (a.C == 4) && (a.E % 4 == 0) && E4 <= 64 && h->opt_variant != 9;
+    int64_t blocks;
+    const int64_t cap = (int64_t)h->num_cu * (h->opt_blocks_per_cu > 0 ? h->opt_blocks_per_cu : 8);
+    if (vec_ok) {
+        blocks = (nchunks + 3) / 4;
+        if (blocks > cap) blocks = cap;
+        if (blocks < 1) blocks = 1;
+        dim3 grid((unsigned)blocks);
+        const char **nm = &h->last_kernel;
+        if (E4 == 8) launch_c4<8, true, BYDISH>(a, pf, nt, grid, st, nm);
+        else if (E4 == 16) launch_c4<16, true, BYDISH>(a, pf, nt, grid, st, nm);
+        else if (E4 == 32) launch_c4<32, true, BYDISH>(a, pf, nt, grid, st, nm);
+        else if (E4 == 64) launch_c4<64, true, BYDISH>(a, pf, nt, grid, st, nm);
+        else if (E4 < 8) launch_c4<8, false, BYDISH>(a, pf, nt, grid, st, nm);
+        else if (E4 < 16) launch_c4<16, false, BYDISH>(a, pf, nt, grid, st, nm);
+        else if (E4 < 32) launch_c4<32, false, BYDISH>(a, pf, nt, grid, st, nm);
+        else launch_c4<64, false, BYDISH>(a, pf, nt, grid, st, nm);
+    } else {
+        if (a.C > 64) {
+            h->last_error = "num_categories > 64 is not supported";
+            return M2D_ERR_UNSUPPORTED;
+        }
+        blocks = (a.B + 3) / 4;
+        if (blocks > cap) blocks = cap;
+        dim3 grid((unsigned)blocks);
+        h->last_kernel = "m2d_score_pairs_generic";
+        hipLaunchKernelGGL((m2d_score_pairs_generic<BYDISH>), grid, dim3(256), 0, st, a);
+    }
+    M2D_HIP_TRY(h, hipGetLastError());
+    return M2D_OK;
+}
+
+}  // namespace
+
+int m2d_launch_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
+                           bool by_dish, int64_t B, float *out, hipStream_t stream)
+{
+    if (B == 0) return M2D_OK;
+    ScoreArgs a;
+    a.pm = h->pm; a.re = h->re; a.ce = h->ce;
+    a.users = users; a.items = items; a.cats = cats; a.out = out;
+    a.B = B; a.U = h->U; a.I = h->I; a.user_base = h->user_base;
+    a.E = h->E; a.C = h->C; a.a = h->a; a.b = h->b; a.err = h->err_dev;
+    return by_dish ? launch_any<true>(h, a, stream) : launch_any<false>(h, a, stream);
+}

@@ -1,0 +1,220 @@
+"""PyTorch-ROCm custom ops over the C ABI (``include/m2d.h``).
+
+torch is plumbing here -- device memory, streams, ``torch.distributed`` -- the arithmetic is in
+``libm2d.so``.  Ops are registered for the ``cuda`` (= HIP on ROCm) device only: handing them CPU
+tensors raises ``NotImplementedError``; there is no eager/CPU fallback to fall through to.
+"""
+from __future__ import annotations
+
+import ctypes
+import weakref
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _native
+
+_ENGINES: "weakref.WeakValueDictionary[int, ScoringEngine]" = weakref.WeakValueDictionary()
+
+
+def _stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev_f32(x, device) -> torch.Tensor:
+    t = torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x)
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class ScoringEngine:
+    """Owns one ``m2d_engine`` and the HBM tables it borrows.
+
+    Stands in for the variable set the reference builds in ``instantiate_weights``
+    (Model_Recommender.py:43-54); ``user_base`` makes it one user-range shard.
+    """
+
+    def __init__(self, Personal_Memory, Recipe_Embedding, Category_Embedding, coef: float = 0.99,
+                 device: Optional[torch.device] = None, user_base: int = 0):
+        lib = _native.lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("foodrec_amd needs an MI355X (no HIP device visible); there is no CPU fallback")
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.pm = _dev_f32(Personal_Memory, self.device)
+        self.re = _dev_f32(Recipe_Embedding, self.device)
+        self.ce = _dev_f32(Category_Embedding, self.device)
+        if self.pm.dim() != 3 or self.re.dim() != 2 or self.ce.dim() != 2:
+            raise ValueError("Personal_Memory [U, C+1, E], Recipe_Embedding [I, E], Category_Embedding [C, E] expected")
+        self.U, c1, self.E = self.pm.shape
+        self.I = self.re.shape[0]
+        self.C = self.ce.shape[0]
+        if c1 != self.C + 1 or self.re.shape[1] != self.E or self.ce.shape[1] != self.E:
+            raise ValueError("table shapes disagree: PM %s, RE %s, CE %s" % (tuple(self.pm.shape), tuple(self.re.shape), tuple(self.ce.shape)))
+        self.coef = float(np.float32(coef))
+        self.dish_cats: Optional[torch.Tensor] = None
+        handle = ctypes.c_void_p()
+        rc = lib.m2d_create(self.pm.data_ptr(), self.re.data_ptr(), self.ce.data_ptr(), self.U, self.I, self.C,
+                            self.E, self.coef, self.device.index or 0, _native.M2D_TABLES_DEVICE,
+                            ctypes.byref(handle))
+        _native.raise_for(rc, None)
+        self._h = handle
+        self.user_base = 0
+        if user_base:
+            self.set_user_base(user_base)
+        self.id = id(self)
+        _ENGINES[self.id] = self
+
+    # -- configuration ---------------------------------------------------------------------------
+    def set_user_base(self, user_base: int):
+        _native.raise_for(_native.lib().m2d_set_user_base(self._h, int(user_base)), self._h)
+        self.user_base = int(user_base)
+
+    def set_dish_categories(self, cats):
+        """cats: [I, C] (or [I, C, 1]) float mask per dish -- dish_to_category.json as a table."""
+        t = _dev_f32(cats, self.device).reshape(self.I, self.C)
+        _native.raise_for(_native.lib().m2d_set_dish_categories(self._h, t.data_ptr(), _native.M2D_TABLES_DEVICE), self._h)
+        self.dish_cats = t
+
+    def set_option(self, name: str, value: int):
+        _native.raise_for(_native.lib().m2d_set_option(self._h, name.encode(), int(value)), self._h)
+
+    def get_option(self, name: str) -> int:
+        v = ctypes.c_int64()
+        _native.raise_for(_native.lib().m2d_get_option(self._h, name.encode(), ctypes.byref(v)), self._h)
+        return int(v.value)
+
+    def last_kernel(self) -> str:
+        return (_native.lib().m2d_last_kernel(self._h) or b"").decode()
+
+    # -- raw launches (device tensors in, device tensors out, no sync) -----------------------------
+    def _check_ids(self, users: torch.Tensor, items: torch.Tensor):
+        if users.dtype != torch.int32 or items.dtype != torch.int32:
+            raise TypeError("ids must be int32 tensors (Model_Recommender.py:26-29)")
+        if users.device != self.device or items.device != self.device:
+            raise NotImplementedError("m2d ops run on %s only; got %s" % (self.device, users.device))
+
+    def score_pairs(self, users: torch.Tensor, items: torch.Tensor, cats: torch.Tensor,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._check_ids(users, items)
+        B = users.numel()
+        if items.numel() != B or cats.numel() != B * self.C:
+            raise ValueError("score_pairs: users[%d], items[%d], cats[%d] disagree (C=%d)" % (B, items.numel(), cats.numel(), self.C))
+        users, items = users.contiguous(), items.contiguous()
+        cats = cats.to(torch.float32).contiguous()
+        if cats.data_ptr() % 16:
+            cats = cats.clone()
+        if out is None:
+            out = torch.empty(B, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = _native.lib().m2d_score_pairs(self._h, users.data_ptr(), items.data_ptr(), cats.data_ptr(), B,
+                                               out.data_ptr(), _stream_ptr())
+        _native.raise_for(rc, self._h)
+        return out
+
+    def score_pairs_bydish(self, users: torch.Tensor, items: torch.Tensor,
+                           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._check_ids(users, items)
+        B = users.numel()
+        if items.numel() != B:
+            raise ValueError("score_pairs_bydish: users and items differ in length")
+        users, items = users.contiguous(), items.contiguous()
+        if out is None:
+            out = torch.empty(B, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = _native.lib().m2d_score_pairs_bydish(self._h, users.data_ptr(), items.data_ptr(), B, out.data_ptr(),
+                                                      _stream_ptr())
+        _native.raise_for(rc, self._h)
+        return out
+
+    def rank_candidates(self, users: torch.Tensor, items: torch.Tensor, k: int,
+                        lens: Optional[torch.Tensor] = None):
+        """users i32[nseg], items i32[nseg, L] -> (scores f32[nseg, k], items i32[nseg, k], flags i32[nseg])."""
+        if items.dim() != 2 or users.numel() != items.shape[0]:
+            raise ValueError("rank_candidates: items must be [nseg, L] with one user per row")
+        self._check_ids(users, items)
+        nseg, L = items.shape
+        users, items = users.contiguous(), items.contiguous()
+        if lens is not None:
+            lens = lens.to(device=self.device, dtype=torch.int32).contiguous()
+        out_s = torch.empty((nseg, k), dtype=torch.float32, device=self.device)
+        out_i = torch.empty((nseg, k), dtype=torch.int32, device=self.device)
+        out_f = torch.empty((nseg,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = _native.lib().m2d_rank_candidates(self._h, users.data_ptr(), items.data_ptr(),
+                                                   lens.data_ptr() if lens is not None else None, nseg, L, k,
+                                                   out_s.data_ptr(), out_i.data_ptr(), out_f.data_ptr(), _stream_ptr())
+        _native.raise_for(rc, self._h)
+        return out_s, out_i, out_f
+
+    def topk_users(self, users: torch.Tensor, k: int):
+        """users i32[nU] -> (scores f32[nU, k], dish ids i32[nU, k]) over the whole catalogue."""
+        if users.dtype != torch.int32 or users.device != self.device:
+            raise TypeError("topk_users: users must be an int32 tensor on %s" % self.device)
+        users = users.contiguous()
+        nU = users.numel()
+        out_s = torch.empty((nU, k), dtype=torch.float32, device=self.device)
+        out_i = torch.empty((nU, k), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = _native.lib().m2d_topk_users(self._h, users.data_ptr(), nU, k, out_s.data_ptr(), out_i.data_ptr(),
+                                              _stream_ptr())
+        _native.raise_for(rc, self._h)
+        return out_s, out_i
+
+    def check(self):
+        """Synchronise the current stream; raise IndexError for an out-of-range id seen by a kernel."""
+        bv, bi = ctypes.c_int64(), ctypes.c_int64()
+        with torch.cuda.device(self.device):
+            rc = _native.lib().m2d_check(self._h, _stream_ptr(), ctypes.byref(bv), ctypes.byref(bi))
+        _native.raise_for(rc, self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _native.lib().m2d_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- torch.library registration -----------------------------------------------------------------
+# The engine travels through the dispatcher as an integer key into _ENGINES.
+
+def _engine(eid: int) -> ScoringEngine:
+    try:
+        return _ENGINES[eid]
+    except KeyError:
+        raise RuntimeError("m2d: engine %d is gone" % eid) from None
+
+
+@torch.library.custom_op("m2d::score_pairs", mutates_args=(), device_types="cuda")
+def score_pairs_op(engine: int, users: torch.Tensor, items: torch.Tensor, cats: torch.Tensor) -> torch.Tensor:
+    return _engine(engine).score_pairs(users, items, cats)
+
+
+@score_pairs_op.register_fake
+def _(engine, users, items, cats):
+    return users.new_empty(users.shape, dtype=torch.float32)
+
+
+@torch.library.custom_op("m2d::score_pairs_bydish", mutates_args=(), device_types="cuda")
+def score_pairs_bydish_op(engine: int, users: torch.Tensor, items: torch.Tensor) -> torch.Tensor:
+    return _engine(engine).score_pairs_bydish(users, items)
+
+
+@score_pairs_bydish_op.register_fake
+def _(engine, users, items):
+    return users.new_empty(users.shape, dtype=torch.float32)
+
+
+@torch.library.custom_op("m2d::topk_users", mutates_args=(), device_types="cuda")
+def topk_users_op(engine: int, users: torch.Tensor, k: int) -> tuple[torch.Tensor, torch.Tensor]:
+    return _engine(engine).topk_users(users, k)
+
+
+@topk_users_op.register_fake
+def _(engine, users, k):
+    return (users.new_empty((users.numel(), k), dtype=torch.float32),
+            users.new_empty((users.numel(), k), dtype=torch.int32))

@@ -1,0 +1,112 @@
+/* m2d.h -- C ABI of the MI355X (gfx950) Market2Dish scoring engine (libm2d.so).
+ *
+ * The reference (WenjieWWJ/FoodRec) has no FFI: its boundary is a Python class plus TF1 session
+ * fetches.  Each entry point below names the reference interface it stands in for (paths relative
+ * to the reference root, Code/Recommender/...).  The Python layer (foodrec_amd/) is the only
+ * caller; it registers these as torch.library custom ops (foodrec_amd/ops.py).
+ *
+ * Conventions
+ *   - every function returns an int status: M2D_OK (0) or a negative M2D_ERR_* code; nothing throws;
+ *   - data pointers are DEVICE pointers (HBM) unless a parameter says "host"; the caller owns every
+ *     buffer; the engine owns only what it allocates itself (tables passed with M2D_TABLES_HOST);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); kernels are enqueued and
+ *     the call returns without synchronising.  Id errors found by a kernel are latched on the
+ *     device and reported by m2d_check(), which does synchronise;
+ *   - an engine is not thread-safe; distinct engines / streams are independent;
+ *   - all arithmetic is float32; ids are int32 (Model_Recommender.py:26-32).
+ */
+#ifndef M2D_H_
+#define M2D_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct m2d_engine m2d_engine;
+
+#define M2D_OK 0
+#define M2D_ERR_INVALID_ARG (-1)    /* null pointer, non-positive size, k out of range ...          */
+#define M2D_ERR_HIP (-2)            /* a HIP runtime call failed; text in m2d_last_error()           */
+#define M2D_ERR_BAD_USER_ID (-3)    /* a user id outside [user_base, user_base + U)                  */
+#define M2D_ERR_BAD_ITEM_ID (-4)    /* a dish id outside [0, I)                                      */
+#define M2D_ERR_NOT_CONFIGURED (-5) /* call needs m2d_set_dish_categories / m2d_set_* first          */
+#define M2D_ERR_UNSUPPORTED (-6)    /* shape outside what the kernels cover (message says which)     */
+#define M2D_ERR_NO_DEVICE (-7)      /* no HIP device visible: there is no CPU fallback, by design    */
+
+#define M2D_TABLES_HOST 0   /* table pointers are host memory: copied to HBM once, engine-owned      */
+#define M2D_TABLES_DEVICE 1 /* table pointers are device memory: borrowed, caller keeps them alive   */
+
+/* ABI version: bumped on any signature change. */
+int m2d_abi_version(void);
+
+/* Model build.  Replaces Model.__init__ + instantiate_weights (Model_Recommender.py:5-37, :43-54):
+ *   pm [U, C+1, E]  Personal_Memory  (row 0 high-level, rows 1..C low-level per category)
+ *   re [I, E]       Recipe_Embedding
+ *   ce [C, E]       Category_Embedding
+ *   coef            high_level_score_coefficient, held as float32; (1 - coef) is taken in float32
+ *                   (Model_Recommender.py:17, :96)
+ * General_Memory is not an argument: the forward never reads it (Model_Recommender.py:56-97). */
+int m2d_create(const float *pm, const float *re, const float *ce, int64_t U, int64_t I, int32_t C,
+               int32_t E, float coef, int device, int table_flags, m2d_engine **out);
+int m2d_destroy(m2d_engine *h);
+
+/* Text of the last failure on this engine (or of the last failed m2d_create when h == NULL). */
+const char *m2d_last_error(const m2d_engine *h);
+
+/* User-axis sharding (no reference counterpart): this engine holds users
+ * [user_base, user_base + U); ids in every call stay GLOBAL. */
+int m2d_set_user_base(m2d_engine *h, int64_t user_base);
+
+/* Resident per-dish category masks [I, C] -- the device-side form of dish_to_category.json
+ * (Train_recommender.py:132, evaluate.py:43,50).  Needed by the *_bydish / rank / topk calls. */
+int m2d_set_dish_categories(m2d_engine *h, const float *cats, int table_flags);
+
+/* Predict.  Replaces sess.run([model.logits], feed_dict) (evaluate.py:55-59) = Model.inference
+ * (Model_Recommender.py:56-97) for B pairs:
+ *   users i32[B], items i32[B], cats f32[B, C] (the [B, C, 1] placeholder flattened; any float
+ *   weight is accepted, a row summing to 0 yields NaN as 0/0 does at :79/:92), out f32[B]. */
+int m2d_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
+                    int64_t B, float *out, void *stream);
+
+/* Same, with cats looked up from the resident dish table: cats[b] = dish_categories[items[b]]. */
+int m2d_score_pairs_bydish(m2d_engine *h, const int32_t *users, const int32_t *items, int64_t B,
+                           float *out, void *stream);
+
+/* Evaluator inner step.  Replaces eval_one_rating's scoring + ranking (evaluate.py:35-63) for
+ * nseg users in ONE launch: segment s scores users[s] against items[s*L .. s*L + lens[s]) and
+ * returns the first k of heapq.nlargest order -- a repeated item keeps its first position and its
+ * last score (dict collapse, :60-61), ties go to the earlier position (:63).
+ *   lens may be NULL (every segment has L candidates); 1 <= L <= 1024; 1 <= k <= 64
+ *   out_items i32[nseg, k] (-1 past the number of distinct candidates), out_scores f32[nseg, k],
+ *   out_flags i32[nseg]: bit 0 set when a candidate score is NaN -- the caller must then rank that
+ *   segment on the host, where the reference's NaN behaviour can be reproduced exactly. */
+int m2d_rank_candidates(m2d_engine *h, const int32_t *users, const int32_t *items, const int32_t *lens,
+                        int64_t nseg, int32_t L, int32_t k, float *out_scores, int32_t *out_items,
+                        int32_t *out_flags, void *stream);
+
+/* Full-catalogue retrieval (build-defined generalisation of evaluate.py:39-63 to every dish; BASELINE
+ * config 5): for each of nU users the k best dishes over all I, descending score, ties to the lower
+ * dish id, NaN scores last.  out_scores f32[nU, k], out_ids i32[nU, k].  1 <= k <= 64. */
+int m2d_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, float *out_scores,
+                   int32_t *out_ids, void *stream);
+
+/* Synchronise `stream` and report (then clear) the first id error latched by kernels since the
+ * previous check: M2D_OK, M2D_ERR_BAD_USER_ID or M2D_ERR_BAD_ITEM_ID.  TF-CPU GatherV2 raises
+ * InvalidArgument for such ids; the kernels never read out of bounds and write NaN for the pair.
+ * bad_value / bad_index (host pointers, may be NULL) receive the offending id and its position. */
+int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_index);
+
+/* Kernel-selection knobs for benchmarking ("prefetch", "nt_loads", "blocks_per_cu", "variant").
+ * Unknown names return M2D_ERR_INVALID_ARG.  Results never depend on them. */
+int m2d_set_option(m2d_engine *h, const char *name, int64_t value);
+int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value);
+
+/* Name of the kernel the last m2d_score_pairs* call launched (for matching rocprofv3 traces). */
+const char *m2d_last_kernel(const m2d_engine *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M2D_H_ */

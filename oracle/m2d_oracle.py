@@ -1,0 +1,227 @@
+"""CPU oracle for the Market2Dish Recommender scoring path.  TEST INFRASTRUCTURE ONLY.
+
+This file is the checker, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+``foodrec_amd`` never imports anything under ``oracle/``.
+
+PARITY STATUS -- read before trusting a number that came out of here:
+
+* Rows A3-A7 (the arithmetic of ``Model.inference``,
+  ``Code/Recommender/Model_Recommender.py:56-97``) execute inside TensorFlow 1.x,
+  which is not in this image and cannot be installed (no network).  The reference
+  ships no tests, no golden vectors and no fixtures for this path.  The functions
+  below are therefore a *restatement* of those lines, op for op, checked against a
+  hand-computed known answer (score = 3.4625) and against
+  each other (float64 / float32-naive / factored / C).  **PARITY UNPINNED** for
+  A3-A7: nothing produced by TensorFlow itself anchors these values.
+* Rows A8-A9 (``Code/Recommender/evaluate.py:13-81``: candidate batch, dict
+  collapse, ``heapq.nlargest``, HR/NDCG) are pure Python in the reference.  The
+  restatement here is pinned against the reference's own module, imported from
+  ``/root/reference`` in the build container by
+  ``tests/golden/make_reference_eval_golden.py`` (fixtures:
+  ``tests/golden/ref_eval_*.json``).
+
+Every function cites the reference lines it follows (paths relative to
+``/root/reference``).
+"""
+from __future__ import annotations
+
+import heapq
+import math
+from typing import Dict, Iterable, List, Sequence, Tuple
+
+import numpy as np
+
+# Model_Recommender.py:17 -- tf.constant(args.high_level_score_coefficient) is a
+# float32 constant; `1 - coef` (:96) is evaluated in float32 as well.
+DEFAULT_COEF = 0.99
+
+
+def blend_coefficients(coef: float = DEFAULT_COEF) -> Tuple[np.float32, np.float32]:
+    """(a, 1-a) exactly as the graph holds them: both float32 (Model_Recommender.py:17, :95-96)."""
+    a = np.float32(coef)
+    return a, np.float32(np.float32(1.0) - a)
+
+
+def _as_mask(categories, num_categories: int | None = None) -> np.ndarray:
+    """Accept the placeholder layout [B, C, 1] (Model_Recommender.py:32) or [B, C]; return [B, C, 1]."""
+    m = np.asarray(categories)
+    if m.ndim == 2:
+        m = m[:, :, None]
+    if m.ndim != 3 or m.shape[2] != 1:
+        raise ValueError("categories must be [B, C, 1] or [B, C], got %r" % (m.shape,))
+    if num_categories is not None and m.shape[1] != num_categories:
+        raise ValueError("categories has %d columns, model has %d" % (m.shape[1], num_categories))
+    return m
+
+
+def _as_ids(ids, bound: int, what: str) -> np.ndarray:
+    """int32 feed conversion (Model_Recommender.py:26-29); TF-CPU GatherV2 rejects out-of-range ids."""
+    a = np.asarray([int(x) for x in ids] if not isinstance(ids, np.ndarray) else ids)
+    a = a.astype(np.int64).reshape(-1)
+    if a.size and (a.min() < 0 or a.max() >= bound):
+        bad = a[(a < 0) | (a >= bound)][0]
+        raise IndexError("%s id %d out of range [0, %d)" % (what, int(bad), bound))
+    return a
+
+
+def inference(Personal_Memory, Recipe_Embedding, Category_Embedding, user_input, item_input,
+              categories, coef: float = DEFAULT_COEF, dtype=np.float64) -> np.ndarray:
+    """Op-for-op restatement of ``Model.inference`` (Model_Recommender.py:56-97).
+
+    ``dtype=np.float32`` keeps every intermediate in float32 with the same
+    materialised ``[B, C, E]`` temporaries the TF graph builds; ``np.float64``
+    evaluates the same expression tree in double, with the two blend constants
+    still rounded through float32 as the graph does (:17, :96).
+    """
+    PM = np.asarray(Personal_Memory)
+    RE = np.asarray(Recipe_Embedding)
+    CE = np.asarray(Category_Embedding)
+    C = CE.shape[0]
+    if PM.ndim != 3 or PM.shape[1] != C + 1:
+        raise ValueError("Personal_Memory must be [U, C+1, E]")
+    users = _as_ids(user_input, PM.shape[0], "user")
+    items = _as_ids(item_input, RE.shape[0], "item")
+    if users.shape != items.shape:
+        raise ValueError("user_input and item_input differ in length")
+    cat = _as_mask(categories, C).astype(dtype)                      # [B, C, 1]   :32
+    if cat.shape[0] != users.shape[0]:
+        raise ValueError("categories batch differs from ids")
+    PM = PM.astype(dtype, copy=False)
+    RE = RE.astype(dtype, copy=False)
+    CE = CE.astype(dtype, copy=False)
+    a32, b32 = blend_coefficients(coef)
+    a, b = dtype(a32), dtype(b32)
+
+    with np.errstate(divide="ignore", invalid="ignore"):
+        User_Memory = PM[users]                                      # [B, C+1, E] :57
+        U_high = User_Memory[:, :1, :]                               # [B, 1, E]   :59 split [1, C]
+        U_low = User_Memory[:, 1:, :]                                # [B, C, E]
+        Item = RE[items][:, None, :]                                 # [B, 1, E]   :63-65
+        Dish_Category = cat * CE                                     # [B, C, E]   :67
+        category_score = U_high * Dish_Category                      # [B, C, E]   :71
+        sum_cat = category_score.sum(axis=(1, 2), dtype=dtype)       # [B]         :75
+        category_num = cat.sum(axis=(1, 2), dtype=dtype)             # [B]         :77
+        high_score = sum_cat / category_num                          # [B]         :79
+        Dish_Memory = cat * U_low                                    # [B, C, E]   :82
+        dish_score = Item * Dish_Memory                              # [B, C, E]   :86
+        sum_dish = dish_score.sum(axis=(1, 2), dtype=dtype)          # [B]         :90
+        low_score = sum_dish / category_num                          # [B]         :92
+        score = a * high_score + b * low_score                       # [B]         :95-96
+    return score.astype(dtype, copy=False)
+
+
+def inference_f32(PM, RE, CE, users, items, categories, coef: float = DEFAULT_COEF) -> np.ndarray:
+    return inference(PM, RE, CE, users, items, categories, coef, np.float32)
+
+
+def inference_f64(PM, RE, CE, users, items, categories, coef: float = DEFAULT_COEF) -> np.ndarray:
+    return inference(PM, RE, CE, users, items, categories, coef, np.float64)
+
+
+def dish_vectors(Recipe_Embedding, Category_Embedding, dish_categories, coef: float = DEFAULT_COEF,
+                 dtype=np.float64) -> np.ndarray:
+    """Factored form of Model_Recommender.py:67-96: per dish d the vector
+
+        Dt[d] = concat( a*(sum_c m_c CE_c)/n , (1-a)*m_0/n*RE[d], ..., (1-a)*m_{C-1}/n*RE[d] )
+
+    so that score(u, d) = <flatten(PM[u]), Dt[d]>.  ``dish_categories`` is [I, C] (or [I, C, 1]).
+    An independent second route to the same number, used to cross-check `inference`.
+    """
+    RE = np.asarray(Recipe_Embedding, dtype=dtype)
+    CE = np.asarray(Category_Embedding, dtype=dtype)
+    m = _as_mask(dish_categories, CE.shape[0])[:, :, 0].astype(dtype)    # [I, C]
+    a32, b32 = blend_coefficients(coef)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        n = m.sum(axis=1, dtype=dtype)                                   # [I]
+        high = dtype(a32) * (m @ CE) / n[:, None]                        # [I, E]
+        low = dtype(b32) * (m / n[:, None])[:, :, None] * RE[:, None, :]  # [I, C, E]
+    return np.concatenate([high[:, None, :], low], axis=1).reshape(RE.shape[0], -1)
+
+
+def inference_factored(PM, RE, CE, users, items, dish_categories, coef: float = DEFAULT_COEF,
+                       dtype=np.float64) -> np.ndarray:
+    """score = <flatten(PM[u]), Dt[d]> with Dt from `dish_vectors` (dish_categories indexed by dish id)."""
+    PMf = np.asarray(PM, dtype=dtype)
+    Dt = dish_vectors(RE, CE, dish_categories, coef, dtype)
+    users = _as_ids(users, PMf.shape[0], "user")
+    items = _as_ids(items, Dt.shape[0], "item")
+    with np.errstate(invalid="ignore"):
+        return np.einsum("bk,bk->b", PMf[users].reshape(len(users), -1), Dt[items])
+
+
+# ----------------------------------------------------------------------------------------------
+# Evaluator (evaluate.py)
+# ----------------------------------------------------------------------------------------------
+
+def getHitRatio(ranklist: Sequence, gtItem) -> int:
+    """evaluate.py:69-73."""
+    for item in ranklist:
+        if item == gtItem:
+            return 1
+    return 0
+
+
+def getNDCG(ranklist: Sequence, gtItem) -> float:
+    """evaluate.py:76-81 -- ln2 / ln(rank + 2), 0 when absent."""
+    for i in range(len(ranklist)):
+        if ranklist[i] == gtItem:
+            return math.log(2) / math.log(i + 2)
+    return 0
+
+
+def candidate_batch(user, testRatings: Dict[str, List[int]], testNegatives: Dict[str, List[int]]):
+    """evaluate.py:39-51 -- [positive] + negatives[50:100]; the user key is ``str(user)``."""
+    positive = testRatings[str(user)][0]
+    return [positive] + list(testNegatives[str(user)][50:100])
+
+
+def rank_candidates(items: Sequence, scores: Sequence, K: int) -> List:
+    """evaluate.py:53, :60-63 -- dict collapse (a repeated item keeps its FIRST position and its
+    LAST score) followed by ``heapq.nlargest(K, dict, key=dict.get)``."""
+    table = {}
+    for it, sc in zip(items, scores):
+        table[it] = sc
+    return heapq.nlargest(K, table, key=table.get)
+
+
+def eval_one_rating(score_fn, user, testRatings, testNegatives, K, dish_to_category):
+    """evaluate.py:35-66 with ``score_fn(users, items, categories) -> scores`` in place of
+    ``sess.run([model.logits], feed_dict)[0]`` (:55-59)."""
+    if str(user) not in testRatings or len(testRatings[str(user)]) == 0:
+        return None                                                    # :37-38
+    items = candidate_batch(user, testRatings, testNegatives)
+    users = [user] * len(items)
+    cats = [dish_to_category[str(i)] for i in items]                   # :43, :50
+    scores = score_fn(users, items, cats)
+    ranklist = rank_candidates(items, scores, K)
+    return getHitRatio(ranklist, items[0]), getNDCG(ranklist, items[0])
+
+
+def evaluate_model(score_fn, testRatings, testNegatives, K, dish_to_category):
+    """evaluate.py:13-32 -- iterate the users in dict order, one scoring call per user."""
+    hits, ndcgs = [], []
+    for idx in testRatings:
+        hr, ndcg = eval_one_rating(score_fn, idx, testRatings, testNegatives, K, dish_to_category)
+        hits.append(hr)
+        ndcgs.append(ndcg)
+    return hits, ndcgs
+
+
+def topk_catalogue(PM, RE, CE, dish_categories, users: Iterable[int], k: int,
+                   coef: float = DEFAULT_COEF, dtype=np.float64):
+    """Full-catalogue retrieval (build-defined generalisation of evaluate.py:39-63 to every dish):
+    score every dish with `inference`, rank with the reference's ``heapq.nlargest`` rule --
+    descending score, ties to the earlier (lower) dish id.  NaN scores (0/0, :79/:92) rank last."""
+    PM = np.asarray(PM)
+    I = np.asarray(RE).shape[0]
+    m = _as_mask(dish_categories, np.asarray(CE).shape[0])
+    all_items = np.arange(I)
+    out_s, out_i = [], []
+    for u in users:
+        s = inference(PM, RE, CE, np.full(I, int(u)), all_items, m, coef, dtype)
+        key = np.where(np.isnan(s), -np.inf, s)
+        order = np.lexsort((all_items, -key))[:k]
+        out_i.append(order.astype(np.int64))
+        out_s.append(s[order])
+    return np.asarray(out_s), np.asarray(out_i)

@@ -1,0 +1,48 @@
+"""Shared test helpers.  The oracle is the checker here and nowhere else."""
+import glob
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# north_star tolerance: scores match "within 1e-4 fp32"; stated as absolute-or-relative because
+# |score| grows with E and table magnitude ("Reduction order").
+TOL = 1e-4
+
+
+def assert_scores_close(got, ref, tol=TOL, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    nan_g, nan_r = np.isnan(got), np.isnan(ref)
+    assert np.array_equal(nan_g, nan_r), "%s: NaN positions differ (%d vs %d)" % (what, nan_g.sum(), nan_r.sum())
+    ok = ~nan_r
+    err = np.abs(got[ok] - ref[ok])
+    bound = tol * np.maximum(1.0, np.abs(ref[ok]))
+    assert np.all(err <= bound), "%s: max err %.3e (bound %.1e)" % (what, err.max(), tol)
+    return float(err.max()) if err.size else 0.0
+
+
+def score_cases():
+    return sorted(glob.glob(os.path.join(GOLDEN, "score_*.npz")))
+
+
+def load_json(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def random_case(U, I, C, E, B, seed, zero_rows=True):
+    rng = np.random.default_rng(seed)
+    s = 1.0 / np.sqrt(E)
+    PM = (rng.standard_normal((U, C + 1, E)) * s).astype(np.float32)
+    RE = (rng.standard_normal((I, E)) * s).astype(np.float32)
+    CE = (rng.standard_normal((C, E)) * s).astype(np.float32)
+    users = rng.integers(0, U, B).astype(np.int32)
+    items = rng.integers(0, I, B).astype(np.int32)
+    cats = rng.integers(0, 2, (B, C)).astype(np.float32)
+    if not zero_rows:
+        cats[cats.sum(1) == 0, 0] = 1.0
+    return PM, RE, CE, users, items, cats

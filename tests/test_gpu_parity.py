@@ -1,0 +1,216 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle.
+
+Tolerance (north_star: "within 1e-4 fp32"): |got - ref| <= 1e-4 * max(1, |ref|) against the float64
+restatement; NaN (0/0 on an empty mask, Model_Recommender.py:79/:92) must appear at the same pairs.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from helpers import assert_scores_close, random_case, score_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return torch
+
+
+def _engine(PM, RE, CE, **kw):
+    from foodrec_amd import ScoringEngine
+    return ScoringEngine(PM, RE, CE, **kw)
+
+
+def _run(eng, torch, users, items, cats):
+    dev = eng.device
+    out = eng.score_pairs(torch.as_tensor(users, dtype=torch.int32, device=dev),
+                          torch.as_tensor(items, dtype=torch.int32, device=dev),
+                          torch.as_tensor(cats, dtype=torch.float32, device=dev))
+    eng.check()
+    return out.cpu().numpy()
+
+
+def test_native_library_is_what_runs(torch_cuda):
+    import foodrec_amd
+    maps = open("/proc/self/maps").read()
+    assert "libm2d.so" in maps
+    assert "libm2d_oracle" not in maps or True     # the oracle may be loaded by the TEST, never by the package
+
+
+@pytest.mark.parametrize("path", score_cases(), ids=lambda p: p.split("score_")[-1][:-4])
+def test_golden_vectors(torch_cuda, path):
+    from oracle import m2d_oracle as oracle
+    z = np.load(path)
+    eng = _engine(z["PM"], z["RE"], z["CE"], coef=float(z["coef"]))
+    got = _run(eng, torch_cuda, z["users"], z["items"], z["cats"])
+    assert_scores_close(got, z["score_f64"], what="HIP vs frozen f64")
+    assert_scores_close(got, oracle.inference_f64(z["PM"], z["RE"], z["CE"], z["users"], z["items"], z["cats"]),
+                        what="HIP vs live oracle")
+    if "hand" in z.files:
+        assert abs(float(got[0]) - 3.4625) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(11, 13, 4, 6), (257, 129, 4, 32), (1000, 500, 4, 64), (1000, 500, 4, 128),
+                                   (300, 100, 4, 200), (64, 64, 4, 256), (50, 40, 4, 260), (30, 20, 4, 7),
+                                   (40, 30, 3, 16), (40, 30, 9, 64), (25, 12, 1, 4)])
+@pytest.mark.parametrize("B", [1, 63, 64, 65, 4097])
+def test_seeded_shapes(torch_cuda, shape, B):
+    from oracle import m2d_oracle as oracle
+    U, I, C, E = shape
+    PM, RE, CE, users, items, cats = random_case(U, I, C, E, B, seed=U + E + B)
+    if B > 3:
+        cats[1] = 1.0
+        cats[2] = 0.0
+        cats[3] = np.linspace(0.25, 1.75, C)
+    eng = _engine(PM, RE, CE)
+    got = _run(eng, torch_cuda, users, items, cats)
+    assert_scores_close(got, oracle.inference_f64(PM, RE, CE, users, items, cats), what=str(shape))
+
+
+def test_kernel_variants_agree(torch_cuda):
+    from oracle import m2d_oracle as oracle
+    for E in (32, 64, 128, 200):
+        PM, RE, CE, users, items, cats = random_case(500, 300, 4, E, 5000, seed=E)
+        ref = oracle.inference_f64(PM, RE, CE, users, items, cats)
+        eng = _engine(PM, RE, CE)
+        outs = []
+        for pf in (1, 2, 4):
+            for nt in (0, 1):
+                for bpc in (1, 8):
+                    eng.set_option("prefetch", pf); eng.set_option("nt_loads", nt); eng.set_option("blocks_per_cu", bpc)
+                    got = _run(eng, torch_cuda, users, items, cats)
+                    assert_scores_close(got, ref, what="E%d pf%d nt%d" % (E, pf, nt))
+                    outs.append(got)
+        for o in outs[1:]:
+            assert np.array_equal(o, outs[0], equal_nan=True), "variants must be bit-identical"
+        eng.set_option("variant", 9)                       # force the generic kernel
+        assert_scores_close(_run(eng, torch_cuda, users, items, cats), ref, what="generic E%d" % E)
+        assert eng.last_kernel() == "m2d_score_pairs_generic"
+
+
+def test_bydish_equals_explicit_feed(torch_cuda):
+    torch = torch_cuda
+    PM, RE, CE, users, items, _ = random_case(300, 200, 4, 64, 3000, seed=77)
+    dish_cats = np.random.default_rng(3).integers(0, 2, (200, 4)).astype(np.float32)
+    eng = _engine(PM, RE, CE)
+    with pytest.raises(ValueError):
+        eng.score_pairs_bydish(torch.as_tensor(users, device=eng.device), torch.as_tensor(items, device=eng.device))
+    eng.set_dish_categories(dish_cats)
+    a = eng.score_pairs_bydish(torch.as_tensor(users, device=eng.device), torch.as_tensor(items, device=eng.device))
+    b = _run(eng, torch, users, items, dish_cats[items])
+    eng.check()
+    assert np.array_equal(a.cpu().numpy(), b, equal_nan=True)
+
+
+def test_out_of_range_ids_raise_and_engine_recovers(torch_cuda):
+    from oracle import m2d_oracle as oracle
+    PM, RE, CE, users, items, cats = random_case(20, 10, 4, 64, 200, seed=5, zero_rows=False)
+    eng = _engine(PM, RE, CE)
+    bad_u = users.copy(); bad_u[17] = 20
+    with pytest.raises(IndexError, match="user id 20 at position 17"):
+        _run(eng, torch_cuda, bad_u, items, cats)
+    bad_i = items.copy(); bad_i[150] = -1
+    with pytest.raises(IndexError, match="item id -1 at position 150"):
+        _run(eng, torch_cuda, users, bad_i, cats)
+    assert_scores_close(_run(eng, torch_cuda, users, items, cats), oracle.inference_f64(PM, RE, CE, users, items, cats))
+
+
+def test_empty_batch_and_user_shard_offset(torch_cuda):
+    from oracle import m2d_oracle as oracle
+    PM, RE, CE, users, items, cats = random_case(64, 32, 4, 64, 500, seed=8, zero_rows=False)
+    eng = _engine(PM, RE, CE)
+    assert _run(eng, torch_cuda, users[:0], items[:0], cats[:0]).shape == (0,)
+    # a shard holding global users [1000, 1064): global ids in, same scores out
+    shard = _engine(PM, RE, CE, user_base=1000)
+    got = _run(shard, torch_cuda, users + 1000, items, cats)
+    assert_scores_close(got, oracle.inference_f64(PM, RE, CE, users, items, cats))
+    with pytest.raises(IndexError):
+        _run(shard, torch_cuda, users, items, cats)          # local ids are out of this shard's range
+
+
+def test_raw_c_abi_with_host_tables(torch_cuda):
+    """Straight through ctypes: host tables copied by the engine (M2D_TABLES_HOST), device id buffers."""
+    torch = torch_cuda
+    from foodrec_amd import _native
+    from oracle import m2d_oracle as oracle
+    lib = _native.lib()
+    PM, RE, CE, users, items, cats = random_case(100, 50, 4, 64, 1000, seed=12)
+    h = ctypes.c_void_p()
+    rc = lib.m2d_create(PM.ctypes.data, RE.ctypes.data, CE.ctypes.data, 100, 50, 4, 64, 0.99, 0,
+                        _native.M2D_TABLES_HOST, ctypes.byref(h))
+    assert rc == 0, _native.error_text(None)
+    u = torch.as_tensor(users, device="cuda"); d = torch.as_tensor(items, device="cuda")
+    c = torch.as_tensor(cats, device="cuda"); out = torch.empty(1000, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.m2d_score_pairs(h, u.data_ptr(), d.data_ptr(), c.data_ptr(), 1000, out.data_ptr(), st) == 0
+    assert lib.m2d_check(h, st, None, None) == 0
+    assert_scores_close(out.cpu().numpy(), oracle.inference_f64(PM, RE, CE, users, items, cats))
+    assert lib.m2d_score_pairs(h, None, d.data_ptr(), c.data_ptr(), 10, out.data_ptr(), st) == _native.M2D_ERR_INVALID_ARG
+    assert lib.m2d_score_pairs_bydish(h, u.data_ptr(), d.data_ptr(), 10, out.data_ptr(), st) == _native.M2D_ERR_NOT_CONFIGURED
+    assert lib.m2d_destroy(h) == 0
+
+
+def test_model_predict_surface(torch_cuda):
+    """Model(args, ...) + Session.run([model.logits], feed_dict) exactly as evaluate.py:55-59 feeds it."""
+    import types
+    from foodrec_amd import Model, Session
+    from oracle import m2d_oracle as oracle
+    PM, RE, CE, users, items, cats = random_case(64, 48, 4, 200, 51, seed=21, zero_rows=False)
+    args = types.SimpleNamespace(learner="adam", num_categories=4, num_users=64, num_labels=95, embed_size=200,
+                                 lr=0.001, decay_steps=1000, decay_rate=1.0, high_level_score_coefficient=0.99,
+                                 beta_1=0.01, beta_2=0.01, alpha=0.01)
+    model = Model(args, PM, RE, CE, np.zeros((95, 5, 200), np.float32))
+    sess = Session(model)
+    feed = {model.user_input: [str(u) for u in users], model.item_input: [int(i) for i in items],
+            model.labels: [0] * 51, model.categories: cats[:, :, None].tolist(), model.dropout_keep_prob: 1.0,
+            model.is_training_flag: False}
+    pred = sess.run([model.logits], feed)[0]
+    assert pred.dtype == np.float32 and pred.shape == (51,)
+    assert_scores_close(pred, oracle.inference_f64(PM, RE, CE, users, items, cats))
+    with pytest.raises(IndexError):
+        model.predict([64], [0], cats[:1])
+    with pytest.raises(NotImplementedError):
+        sess.run([model.labels], feed)
+    with pytest.raises(NotImplementedError):      # CPU tensors never fall back to an eager path
+        torch_cuda.ops.m2d.score_pairs(model.engine.id, torch_cuda.zeros(1, dtype=torch_cuda.int32),
+                                       torch_cuda.zeros(1, dtype=torch_cuda.int32), torch_cuda.ones(1, 4))
+
+
+def test_full_size_properties(torch_cuda):
+    """BASELINE config 2 sizes (1M users x 100k dishes, E = 64): the oracle cannot score 4M pairs in
+    seconds, so check (i) a random sample of pairs against the oracle on the gathered rows,
+    (ii) permutation invariance, (iii) linearity in Personal_Memory -- all size-independent."""
+    torch = torch_cuda
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    U, I, C, E, B = 1_000_000, 100_000, 4, 64, 1 << 22
+    g = torch.Generator(device="cuda"); g.manual_seed(20260102)
+    s = 1.0 / np.sqrt(E)
+    PM = torch.randn((U, C + 1, E), generator=g, device="cuda") * s
+    RE = torch.randn((I, E), generator=g, device="cuda") * s
+    CE = torch.randn((C, E), generator=g, device="cuda") * s
+    users = torch.randint(0, U, (B,), generator=g, device="cuda", dtype=torch.int32)
+    items = torch.randint(0, I, (B,), generator=g, device="cuda", dtype=torch.int32)
+    pat = torch.randint(1, 16, (B,), generator=g, device="cuda", dtype=torch.int32)
+    cats = ((pat[:, None] >> torch.arange(4, device="cuda", dtype=torch.int32)[None, :]) & 1).float()
+    eng = ScoringEngine(PM, RE, CE)
+    out = eng.score_pairs(users, items, cats); eng.check()
+    assert torch.isfinite(out).all()
+    # (i) sample
+    idx = torch.randint(0, B, (4096,), generator=g, device="cuda")
+    su, si = users[idx].long(), items[idx].long()
+    ref = oracle.inference_f64(PM[su].cpu().numpy(), RE[si].cpu().numpy(), CE.cpu().numpy(), np.arange(4096),
+                               np.arange(4096), cats[idx].cpu().numpy())
+    assert_scores_close(out[idx].cpu().numpy(), ref, what="full-size sample")
+    # (ii) permutation
+    perm = torch.randperm(B, generator=g, device="cuda")
+    out_p = eng.score_pairs(users[perm].contiguous(), items[perm].contiguous(), cats[perm].contiguous()); eng.check()
+    assert torch.equal(out_p, out[perm])
+    # (iii) linearity: score(2*PM) = 2*score(PM) exactly (power-of-two scaling commutes with rounding)
+    eng2 = ScoringEngine(PM * 2, RE, CE)
+    out2 = eng2.score_pairs(users, items, cats); eng2.check()
+    assert torch.equal(out2, out * 2)
