@@ -44,6 +44,7 @@ SIGNATURES = {
     "m2d_rank_candidates": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "m2d_topk_users": (_c.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "m2d_check": (_c.c_int, [_vp, _vp, _c.POINTER(_i64), _c.POINTER(_i64)]),
+    "m2d_stream_read_probe": (_c.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "m2d_set_option": (_c.c_int, [_vp, _c.c_char_p, _i64]),
     "m2d_get_option": (_c.c_int, [_vp, _c.c_char_p, _c.POINTER(_i64)]),
 }
@@ -75,7 +76,16 @@ def lib():
         raise NativeLibraryMissing(
             "%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(foodrec_amd has no CPU fallback)" % LIB_PATH)
+    # libm2d.so must share ONE HIP runtime with PyTorch (streams and events cross the boundary).
+    # torch bundles its own libamdhip64.so.7; importing torch first makes the loader resolve
+    # libm2d.so's NEEDED entry to that already-loaded copy instead of mapping /opt/rocm's as a second
+    # runtime (which would see torch's stream handles as garbage).
+    import torch  # noqa: F401
     l = ctypes.CDLL(LIB_PATH)
+    with open("/proc/self/maps") as f:
+        runtimes = {line.split()[-1] for line in f if "libamdhip64.so" in line}
+    if len(runtimes) > 1:
+        raise RuntimeError("two HIP runtimes are mapped in this process: %s" % sorted(runtimes))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(l, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype = res

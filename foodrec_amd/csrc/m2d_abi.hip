@@ -8,6 +8,26 @@
 
 namespace {
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// plain streaming read, 4 x 16 B in flight per lane per iteration
+__global__ __launch_bounds__(256) void m2d_stream_read(const v4f *p, int64_t n4, float *sink)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const v4f a = __builtin_nontemporal_load(p + i);
+        const v4f b = __builtin_nontemporal_load(p + i + stride);
+        const v4f c = __builtin_nontemporal_load(p + i + 2 * stride);
+        const v4f d = __builtin_nontemporal_load(p + i + 3 * stride);
+        acc += (a + b) + (c + d);
+    }
+    for (; i < n4; i += stride) acc += __builtin_nontemporal_load(p + i);
+    const float s = (acc.x + acc.y) + (acc.z + acc.w);
+    if (s == 123456.789f) sink[0] = s;   // keeps the loads live; practically never true
+}
+
 std::string g_create_error;
 
 int fail(m2d_engine *h, int code, const char *msg)
@@ -216,6 +236,17 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
     h->last_error = std::string(code == M2D_ERR_BAD_USER_ID ? "user" : "item") + " id " + std::to_string(value) +
                     " at position " + std::to_string(index) + " is out of range";
     return code;
+}
+
+int m2d_stream_read_probe(m2d_engine *h, const void *buf, int64_t bytes, float *sink, void *stream)
+{
+    if (!h || !buf || !sink || bytes <= 0 || (bytes & 15) || !aligned16(buf))
+        return fail(h, M2D_ERR_INVALID_ARG, "m2d_stream_read_probe: need a 16-byte aligned buffer and size");
+    M2D_HIP_TRY(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(m2d_stream_read, dim3(h->num_cu * 8), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const v4f *>(buf), bytes / 16, sink);
+    M2D_HIP_TRY(h, hipGetLastError());
+    return M2D_OK;
 }
 
 int m2d_set_option(m2d_engine *h, const char *name, int64_t value)

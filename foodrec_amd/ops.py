@@ -160,6 +160,14 @@ class ScoringEngine:
         _native.raise_for(rc, self._h)
         return out_s, out_i
 
+    def stream_read_probe(self, buf: torch.Tensor, sink: torch.Tensor):
+        """Calibration only: plain streaming read of `buf` (achievable HBM read rate of this box)."""
+        nbytes = buf.numel() * buf.element_size()
+        with torch.cuda.device(self.device):
+            rc = _native.lib().m2d_stream_read_probe(self._h, buf.data_ptr(), nbytes - nbytes % 16, sink.data_ptr(),
+                                                     _stream_ptr())
+        _native.raise_for(rc, self._h)
+
     def check(self):
         """Synchronise the current stream; raise IndexError for an out-of-range id seen by a kernel."""
         bv, bi = ctypes.c_int64(), ctypes.c_int64()

@@ -103,6 +103,11 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
 int m2d_set_option(m2d_engine *h, const char *name, int64_t value);
 int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value);
 
+/* Calibration probe, not part of the scoring path: a plain 16-B-per-lane streaming read of `bytes`
+ * bytes (multiple of 16) that folds everything into sink[0]; bench.py times it to report the
+ * achievable HBM read rate of the box beside the 8 TB/s spec peak. */
+int m2d_stream_read_probe(m2d_engine *h, const void *buf, int64_t bytes, float *sink, void *stream);
+
 /* Name of the kernel the last m2d_score_pairs* call launched (for matching rocprofv3 traces). */
 const char *m2d_last_kernel(const m2d_engine *h);
 
