@@ -46,6 +46,7 @@ def parse():
     p.add_argument("--pairs", type=int, default=1 << 22, help="pairs per step per GPU")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
+    p.add_argument("--topk-users", type=int, default=65536, help="users in the catalogue top-k side leg (0 = skip)")
     p.add_argument("--no-side", action="store_true", help="skip the no-reuse / stream-probe side measurements")
     p.add_argument("--unique-users", action="store_true",
                    help="profiling aid: every user at most once per step (pairs <= users), no table reuse")
@@ -122,6 +123,32 @@ def cpu_baseline(torch, PM, RE, CE, users, items, cats, budget_s):
             "value_51_pair_calls": rates[51],
             "fused_c_port": {"value": c_rate, "unit": "pairs/s", "cores": c_oracle.max_threads(),
                              "what": "oracle/m2d_oracle.c, fused scalar loop, OpenMP"}}, ref, Bc
+
+
+def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10):
+    """Outside the timed region: full-catalogue top-k (m2d_topk_users, fp32 MFMA) for n_users users."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    pat = torch.randint(1, 2 ** C, (I,), generator=g, device=dev, dtype=torch.int32)
+    dish_cats = ((pat[:, None] >> torch.arange(C, device=dev, dtype=torch.int32)[None, :]) & 1).to(torch.float32)
+    eng.set_dish_categories(dish_cats)
+    users = (torch.randperm(U, generator=g, device=dev)[:n_users].to(torch.int32) + int(user_base)).contiguous()
+    eng.topk_users(users[:1024], k)                       # builds the dish vectors, warms up
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for i in range(3):
+        evs[i].record()
+        eng.topk_users(users, k)
+    evs[3].record()
+    torch.cuda.synchronize()
+    eng.check()
+    ms = median([evs[i].elapsed_time(evs[i + 1]) for i in range(3)])
+    flops = 2.0 * (C + 1) * E * n_users * I
+    return {"users": n_users, "dishes": I, "k": k, "median_ms": ms, "users_per_s": n_users / ms * 1e3,
+            "pairs_per_s": n_users * I / ms * 1e3, "tflops": flops / ms / 1e9,
+            "roofline": {"bound": "mfma", "achieved": flops / ms / 1e9, "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": flops / ms / 1e9 / 157.3, "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact)"},
+            "kernel": eng.last_kernel()}
 
 
 def median(xs):
@@ -256,6 +283,8 @@ def main():
             line["roofline"]["no_reuse"] = nr
             line["roofline"]["stream_read_probe"] = probe
             line["roofline"]["frac_of_stream_probe"] = achieved / probe["GBps"]
+        if a.topk_users > 0 and not a.no_side:
+            line["catalogue_topk"] = catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U))
         if a.unique_users:
             line["config"]["workload"] += " [--unique-users: every user at most once per step]"
         if world == 1 and not a.no_cpu_baseline:

@@ -135,9 +135,3 @@ int m2d_launch_rank_candidates(m2d_engine *h, const int32_t *users, const int32_
     M2D_HIP_TRY(h, hipGetLastError());
     return M2D_OK;
 }
-
-int m2d_launch_topk_users(m2d_engine *h, const int32_t *, int64_t, int32_t, float *, int32_t *, hipStream_t)
-{
-    h->last_error = "m2d_topk_users: not built yet";
-    return M2D_ERR_UNSUPPORTED;
-}

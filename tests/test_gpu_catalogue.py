@@ -1,0 +1,120 @@
+"""GPU parity of full-catalogue retrieval (m2d_topk_users, fp32-MFMA kernel + generic kernel) with the
+oracle: scores within 1e-4*max(1,|ref|) of the float64 restatement at the returned ids, descending
+order with NaN last, optimality of the returned set, and lower-id-first on exact ties."""
+import numpy as np
+import pytest
+
+from helpers import TOL, assert_scores_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables(U, I, C, E, seed, n_nan=0, dup=0):
+    rng = np.random.default_rng(seed)
+    s = 1.0 / np.sqrt(E)
+    PM = (rng.standard_normal((U, C + 1, E)) * s).astype(np.float32)
+    RE = (rng.standard_normal((I, E)) * s).astype(np.float32)
+    CE = (rng.standard_normal((C, E)) * s).astype(np.float32)
+    pat = rng.integers(1, 2 ** C, I)
+    cats = ((pat[:, None] >> np.arange(C)[None, :]) & 1).astype(np.float32)
+    if n_nan:
+        cats[rng.choice(I, n_nan, replace=False)] = 0
+    if dup:                                     # dishes I-dup.. are copies of dishes 0..dup-1 -> exact ties
+        RE[I - dup:] = RE[:dup]
+        cats[I - dup:] = cats[:dup]
+    return PM, RE, CE, cats
+
+
+def _check(eng, PM, RE, CE, cats, users, k, user_base=0):
+    import torch
+    from oracle import m2d_oracle as oracle
+    s, ids = eng.topk_users(torch.as_tensor(users + user_base, dtype=torch.int32, device="cuda"), k)
+    eng.check()
+    s, ids = s.cpu().numpy(), ids.cpu().numpy()
+    I = RE.shape[0]
+    all_items = np.arange(I)
+    for r, u in enumerate(users):
+        ref = oracle.inference_f64(PM, RE, CE, np.full(I, u), all_items, cats)
+        got_ids = ids[r]
+        n_valid = min(k, I)
+        assert np.all(got_ids[:n_valid] >= 0) and np.all(got_ids[:n_valid] < I), (r, got_ids)
+        assert len(set(got_ids[:n_valid].tolist())) == n_valid, "duplicate dish in top-k"
+        assert_scores_close(s[r, :n_valid], ref[got_ids[:n_valid]], what="user %d" % u)
+        key = np.where(np.isnan(s[r, :n_valid]), -np.inf, s[r, :n_valid])
+        assert np.all(key[:-1] >= key[1:]), "not descending / NaN not last"
+        # optimality: nothing left out beats the k-th returned score by more than the tolerance
+        rest = np.delete(np.where(np.isnan(ref), -np.inf, ref), got_ids[:n_valid])
+        if rest.size:
+            kth = key[n_valid - 1]
+            assert rest.max() <= kth + TOL * max(1.0, abs(kth)), (u, rest.max(), kth)
+        # exact ties (bit-equal scores) go to the lower dish id
+        for a in range(n_valid - 1):
+            if s[r, a] == s[r, a + 1]:
+                assert got_ids[a] < got_ids[a + 1], (u, got_ids[a], got_ids[a + 1])
+
+
+@pytest.mark.parametrize("E,C", [(32, 4), (64, 4), (128, 4), (200, 4), (16, 3), (20, 4)])
+@pytest.mark.parametrize("k", [1, 10, 16, 17, 64])
+def test_topk_users_shapes(E, C, k):
+    from foodrec_amd import ScoringEngine
+    U, I = 150, 333
+    PM, RE, CE, cats = _tables(U, I, C, E, seed=E + k, n_nan=3, dup=20)
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    users = np.random.default_rng(1).integers(0, U, 45)
+    _check(eng, PM, RE, CE, cats, users, k)
+    want = "m2d_topk_mfma" if (C, E) in ((4, 32), (4, 64), (4, 128)) else "m2d_topk_generic"
+    assert eng.last_kernel() == want
+
+
+def test_topk_dish_splits_and_tail_tiles():
+    from foodrec_amd import ScoringEngine
+    U, I, E = 300, 2500, 64
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=5, n_nan=4, dup=64)
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    users = np.arange(0, 290, 3)
+    for forced in (101, 103, 108):                     # 1, 3, 8 dish-range splits
+        eng.set_option("variant", forced)
+        _check(eng, PM, RE, CE, cats, users, 10)
+    eng.set_option("variant", 0)
+    _check(eng, PM, RE, CE, cats, users, 10)           # automatic split choice
+    eng.set_option("variant", 9)                       # generic kernel on the same data
+    _check(eng, PM, RE, CE, cats, users[:8], 10)
+
+
+def test_topk_fewer_dishes_than_k_and_all_nan():
+    import torch
+    from foodrec_amd import ScoringEngine
+    PM, RE, CE, cats = _tables(40, 12, 4, 64, seed=9)
+    cats[3] = 0
+    eng = ScoringEngine(PM, RE, CE); eng.set_dish_categories(cats)
+    with pytest.raises(ValueError):
+        eng.topk_users(torch.zeros(2, dtype=torch.int32, device="cuda"), 13)      # k > I
+    s, ids = eng.topk_users(torch.arange(5, dtype=torch.int32, device="cuda"), 12)
+    eng.check()
+    ids = ids.cpu().numpy(); s = s.cpu().numpy()
+    assert np.all(np.sort(ids, axis=1) == np.arange(12)[None, :])
+    assert np.all(ids[:, -1] == 3) and np.all(np.isnan(s[:, -1]))                 # NaN dish ranks last
+
+
+def test_topk_user_shard_and_bad_ids():
+    import torch
+    from foodrec_amd import ScoringEngine
+    PM, RE, CE, cats = _tables(100, 200, 4, 64, seed=10)
+    eng = ScoringEngine(PM, RE, CE, user_base=5000); eng.set_dish_categories(cats)
+    _check(eng, PM, RE, CE, cats, np.arange(0, 100, 7), 10, user_base=5000)
+    with pytest.raises(IndexError):
+        eng.topk_users(torch.tensor([5000, 42], dtype=torch.int32, device="cuda"), 5); eng.check()
+
+
+def test_topk_matches_pair_kernel_scores():
+    """The two device paths (factored MFMA vs fused pair kernel) agree on the same (user, dish)."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    PM, RE, CE, cats = _tables(500, 4000, 4, 128, seed=11)
+    eng = ScoringEngine(PM, RE, CE); eng.set_dish_categories(cats)
+    users = torch.arange(0, 500, dtype=torch.int32, device="cuda")
+    s, ids = eng.topk_users(users, 10); eng.check()
+    pair = eng.score_pairs_bydish(users.repeat_interleave(10), ids.reshape(-1).contiguous()); eng.check()
+    assert_scores_close(s.reshape(-1).cpu().numpy(), pair.cpu().numpy())
