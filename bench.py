@@ -151,6 +151,42 @@ def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10):
             "kernel": eng.last_kernel()}
 
 
+def sharded_topk_leg(torch, dist, eng, U, I, C, E, dev, user_base, n_users, world, k=10):
+    """Every rank: top-k over the replicated catalogue for n_users of ITS users, then one all-gather of
+    [n_users, k] x (f32 score, i32 id) per rank.  All ranks take part."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)                                     # same dish masks on every rank (replicated)
+    pat = torch.randint(1, 2 ** C, (I,), generator=g, device=dev, dtype=torch.int32)
+    dish_cats = ((pat[:, None] >> torch.arange(C, device=dev, dtype=torch.int32)[None, :]) & 1).to(torch.float32)
+    eng.set_dish_categories(dish_cats)
+    users = (torch.randperm(U, generator=g, device=dev)[:n_users].to(torch.int32) + int(user_base)).contiguous()
+    eng.topk_users(users[:1024], k)
+    gs = torch.empty((world * n_users, k), dtype=torch.float32, device=dev)
+    gi = torch.empty((world * n_users, k), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    t0 = time.perf_counter()
+    e0.record()
+    s, ids = eng.topk_users(users, k)
+    e1.record()
+    dist.all_gather_into_tensor(gs, s)
+    dist.all_gather_into_tensor(gi, ids)
+    e2.record()
+    torch.cuda.synchronize()
+    dist.barrier()
+    wall = time.perf_counter() - t0
+    eng.check()
+    ok = bool(torch.equal(gi[dist.get_rank() * n_users:(dist.get_rank() + 1) * n_users], ids))
+    t = torch.tensor([wall, e0.elapsed_time(e1), e1.elapsed_time(e2)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall, topk_ms, ag_ms = (float(x) for x in t.tolist())
+    return {"users_per_gpu": n_users, "dishes": I, "k": k, "topk_ms_max": topk_ms, "allgather_ms_max": ag_ms,
+            "wall_ms_max": wall * 1e3, "allgather_bytes_per_rank": n_users * k * 8,
+            "users_per_s_whole_job": world * n_users / wall, "pairs_per_s_whole_job": world * n_users * I / wall,
+            "own_slice_roundtrip_ok": ok}
+
+
 def median(xs):
     xs = sorted(xs)
     return xs[len(xs) // 2]
@@ -195,7 +231,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -219,7 +256,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -231,9 +268,17 @@ def main():
     barrier()
     eng.check()
     t = torch.tensor([wall], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
+
+    # user-sharded retrieval: per-shard top-k + RCCL all-gather of the results (outside the timed region)
+    topk_ag = None
+    if use_dist and a.topk_users > 0 and not a.no_side:
+        try:
+            topk_ag = sharded_topk_leg(torch, dist, eng, U, I, C, E, dev, user_base, min(a.topk_users, U), world)
+        except Exception as e:                                         # noqa: BLE001 -- never lose the headline line
+            topk_ag = {"error": "%s: %s" % (type(e).__name__, e)}
 
     opts_used = {k: eng.get_option(k) for k in ("prefetch", "nt_loads", "blocks_per_cu")}
     kernel_used = eng.last_kernel()
@@ -285,6 +330,8 @@ def main():
             line["roofline"]["frac_of_stream_probe"] = achieved / probe["GBps"]
         if a.topk_users > 0 and not a.no_side:
             line["catalogue_topk"] = catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U))
+        if topk_ag is not None:
+            line["sharded_topk_allgather"] = topk_ag
         if a.unique_users:
             line["config"]["workload"] += " [--unique-users: every user at most once per step]"
         if world == 1 and not a.no_cpu_baseline:
@@ -296,7 +343,7 @@ def main():
             line["cpu_baseline"] = cb
         print(json.dumps(line))
         sys.stdout.flush()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
