@@ -21,6 +21,7 @@ M2D_ERR_BAD_ITEM_ID = -4
 M2D_ERR_NOT_CONFIGURED = -5
 M2D_ERR_UNSUPPORTED = -6
 M2D_ERR_NO_DEVICE = -7
+M2D_ERR_BAD_INGREDIENT = -8
 M2D_TABLES_HOST = 0
 M2D_TABLES_DEVICE = 1
 
@@ -43,6 +44,9 @@ SIGNATURES = {
     "m2d_score_pairs_bydish": (_c.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "m2d_rank_candidates": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "m2d_topk_users": (_c.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "m2d_set_ingredients": (_c.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _i64, _c.c_int]),
+    "m2d_clear_ingredients": (_c.c_int, [_vp]),
+    "m2d_score_pairs_ingredients": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "m2d_check": (_c.c_int, [_vp, _vp, _c.POINTER(_i64), _c.POINTER(_i64)]),
     "m2d_stream_read_probe": (_c.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "m2d_set_option": (_c.c_int, [_vp, _c.c_char_p, _i64]),
@@ -104,7 +108,7 @@ def raise_for(rc: int, handle=None):
     if rc == M2D_OK:
         return
     msg = error_text(handle) or ("m2d error %d" % rc)
-    if rc in (M2D_ERR_BAD_USER_ID, M2D_ERR_BAD_ITEM_ID):
+    if rc in (M2D_ERR_BAD_USER_ID, M2D_ERR_BAD_ITEM_ID, M2D_ERR_BAD_INGREDIENT):
         raise IndexError(msg)          # TF-CPU GatherV2: InvalidArgumentError (indices out of range)
     if rc in (M2D_ERR_INVALID_ARG, M2D_ERR_UNSUPPORTED, M2D_ERR_NOT_CONFIGURED):
         raise ValueError(msg)

@@ -66,6 +66,13 @@ void release(m2d_engine *h)
     if (h->own_ce && h->ce) (void)hipFree((void *)h->ce);
     if (h->own_dish_cats && h->dish_cats) (void)hipFree((void *)h->dish_cats);
     if (h->dish_vec) (void)hipFree(h->dish_vec);
+    if (h->dish_high) (void)hipFree(h->dish_high);
+    if (h->own_ing) {
+        if (h->ing) (void)hipFree((void *)h->ing);
+        if (h->ing_off) (void)hipFree((void *)h->ing_off);
+        if (h->ing_ids) (void)hipFree((void *)h->ing_ids);
+        if (h->ing_w) (void)hipFree((void *)h->ing_w);
+    }
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->err_dev) (void)hipFree(h->err_dev);
     if (h->err_host) (void)hipHostFree(h->err_host);
@@ -218,6 +225,89 @@ int m2d_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     return m2d_launch_topk_users(h, users, nU, k, out_scores, out_ids, (hipStream_t)stream);
 }
 
+int m2d_clear_ingredients(m2d_engine *h)
+{
+    if (!h) return M2D_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    if (h->own_ing) {
+        if (h->ing) (void)hipFree((void *)h->ing);
+        if (h->ing_off) (void)hipFree((void *)h->ing_off);
+        if (h->ing_ids) (void)hipFree((void *)h->ing_ids);
+        if (h->ing_w) (void)hipFree((void *)h->ing_w);
+    }
+    if (h->dish_high) (void)hipFree(h->dish_high);
+    h->ing = nullptr; h->ing_off = nullptr; h->ing_ids = nullptr; h->ing_w = nullptr; h->dish_high = nullptr;
+    h->own_ing = false; h->ing_rows = 0; h->ing_nnz = 0;
+    h->dish_vec_valid = false;
+    return M2D_OK;
+}
+
+int m2d_set_ingredients(m2d_engine *h, const float *ing, int64_t R, const int32_t *off, const int32_t *ids,
+                        const float *w, int64_t nnz, int table_flags)
+{
+    if (!h || !ing || !off || (!ids && nnz > 0) || R <= 0 || nnz < 0 || nnz > INT32_MAX)
+        return fail(h, M2D_ERR_INVALID_ARG, "m2d_set_ingredients: bad argument");
+    if (table_flags != M2D_TABLES_HOST && table_flags != M2D_TABLES_DEVICE)
+        return fail(h, M2D_ERR_INVALID_ARG, "m2d_set_ingredients: bad table_flags");
+    int rc = m2d_clear_ingredients(h);
+    if (rc != M2D_OK) return rc;
+    M2D_HIP_TRY(h, hipSetDevice(h->device));
+    if (table_flags == M2D_TABLES_DEVICE) {
+        h->ing = ing; h->ing_off = off; h->ing_ids = ids; h->ing_w = w; h->own_ing = false;
+    } else {
+        bool own = false;
+        const float *t = nullptr;
+        if ((rc = adopt_table(h, ing, (size_t)R * h->E, table_flags, &h->ing, &own)) != M2D_OK) return rc;
+        h->own_ing = true;
+        if ((rc = adopt_table(h, reinterpret_cast<const float *>(off), (size_t)h->I + 1, table_flags, &t, &own)) != M2D_OK) return rc;
+        h->ing_off = reinterpret_cast<const int32_t *>(t);
+        if (nnz > 0) {
+            if ((rc = adopt_table(h, reinterpret_cast<const float *>(ids), (size_t)nnz, table_flags, &t, &own)) != M2D_OK) return rc;
+            h->ing_ids = reinterpret_cast<const int32_t *>(t);
+            if (w) {
+                if ((rc = adopt_table(h, w, (size_t)nnz, table_flags, &h->ing_w, &own)) != M2D_OK) return rc;
+            }
+        }
+    }
+    h->ing_rows = R;
+    h->ing_nnz = nnz;
+    M2D_HIP_TRY(h, hipMalloc((void **)&h->dish_high, (size_t)h->I * h->E * sizeof(float)));
+    if (!aligned16(h->dish_high)) return fail(h, M2D_ERR_HIP, "dish_high not aligned");
+    if ((rc = m2d_launch_check_csr(h, nullptr)) != M2D_OK) return rc;
+    rc = m2d_check(h, nullptr, nullptr, nullptr);
+    if (rc != M2D_OK) {
+        (void)m2d_clear_ingredients(h);
+        h->last_error = "m2d_set_ingredients: offsets are not a CSR row pointer (off[0] = 0, non-decreasing, off[I] = nnz)";
+        return M2D_ERR_BAD_INGREDIENT;
+    }
+    if ((rc = m2d_launch_build_dish_high(h, nullptr)) != M2D_OK) return rc;
+    rc = m2d_check(h, nullptr, nullptr, nullptr);
+    if (rc != M2D_OK) {
+        std::string msg = h->last_error;
+        (void)m2d_clear_ingredients(h);
+        h->last_error = "m2d_set_ingredients: " + msg;
+        return M2D_ERR_BAD_INGREDIENT;
+    }
+    h->dish_vec_valid = false;
+    return M2D_OK;
+}
+
+int m2d_score_pairs_ingredients(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
+                                int64_t B, float *out, void *stream)
+{
+    if (!h) return M2D_ERR_INVALID_ARG;
+    if (B < 0) return fail(h, M2D_ERR_INVALID_ARG, "m2d_score_pairs_ingredients: negative batch");
+    if (B == 0) return M2D_OK;
+    if (!users || !items || !out) return fail(h, M2D_ERR_INVALID_ARG, "m2d_score_pairs_ingredients: null buffer");
+    if (!h->dish_high) return fail(h, M2D_ERR_NOT_CONFIGURED, "call m2d_set_ingredients first");
+    if (!cats && !h->dish_cats) return fail(h, M2D_ERR_NOT_CONFIGURED, "cats == NULL needs m2d_set_dish_categories");
+    if (cats && h->C == 4 && !aligned16(cats)) return fail(h, M2D_ERR_INVALID_ARG, "cats must be 16-byte aligned");
+    M2D_HIP_TRY(h, hipSetDevice(h->device));
+    return m2d_launch_score_pairs(h, users, items, cats ? cats : h->dish_cats, cats == nullptr, B, out,
+                                  (hipStream_t)stream, /*use_ingredients=*/true);
+}
+
 int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_index)
 {
     if (!h) return M2D_ERR_INVALID_ARG;
@@ -233,8 +323,9 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
     if (bad_index) *bad_index = index;
     M2D_HIP_TRY(h, hipMemsetAsync(h->err_dev, 0, 4 * sizeof(int32_t), st));
     M2D_HIP_TRY(h, hipStreamSynchronize(st));
-    h->last_error = std::string(code == M2D_ERR_BAD_USER_ID ? "user" : "item") + " id " + std::to_string(value) +
-                    " at position " + std::to_string(index) + " is out of range";
+    const char *what = code == M2D_ERR_BAD_USER_ID ? "user" : code == M2D_ERR_BAD_ITEM_ID ? "item" : "ingredient";
+    h->last_error = std::string(what) + " id " + std::to_string(value) + " at position " +
+                    std::to_string(code == M2D_ERR_BAD_INGREDIENT ? (int64_t)h->err_host[2] : index) + " is out of range";
     return code;
 }
 

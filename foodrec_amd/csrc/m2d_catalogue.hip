@@ -29,8 +29,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 // One wave per dish; Dt rows are padded to a multiple of 32 dishes (pad rows are zero and are never
 // ranked: their id is >= I).
 __global__ __launch_bounds__(256) void m2d_build_dish_vectors(const float *re, const float *ce,
-                                                              const float *dish_cats, int64_t I, int C, int E,
-                                                              float a, float b, float *dt, int64_t rows)
+                                                              const float *dish_cats, const float *hv, int64_t I,
+                                                              int C, int E, float a, float b, float *dt,
+                                                              int64_t rows)
 {
     const int lane = threadIdx.x & 63;
     const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void m2d_build_dish_vectors(const float *re, c
     for (int e = lane; e < E; e += 64) {
         float s = 0.f;
         for (int c = 0; c < C; ++c) s = fmaf(dish_cats[d * C + c], ce[(size_t)c * E + e], s);   // :67 summed over c
-        o[e] = a * (s / n);                                                // :79, :95
+        o[e] = hv ? a * hv[d * E + e] : a * (s / n);                       // :79, :95 (hv: ingredient extension)
         const float r = re[d * E + e];
         for (int c = 0; c < C; ++c) o[(size_t)(c + 1) * E + e] = b * ((dish_cats[d * C + c] / n) * r);   // :82-96
     }
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
     extern __shared__ __align__(16) float smem[];
     float *stage0 = smem;
     float *lists = smem + 2 * STAGE_FLOATS;      // per wave: k x 64 scores then k x 64 ids
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int k = p.k;
     float *ls = lists + (size_t)wave * 2 * k * 64;
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
 __global__ __launch_bounds__(256) void m2d_topk_generic(TopkArgs p, int K)
 {
     extern __shared__ __align__(16) float smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int k = p.k;
     float *ls = smem + (size_t)wave * 2 * k;
     int32_t *li = reinterpret_cast<int32_t *>(ls + k);
@@ -344,7 +345,7 @@ int ensure_dish_vectors(m2d_engine *h, hipStream_t st)
         h->dish_vec_rows = rows;
     }
     hipLaunchKernelGGL(m2d_build_dish_vectors, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, h->re, h->ce,
-                       h->dish_cats, h->I, h->C, h->E, h->a, h->b, h->dish_vec, rows);
+                       h->dish_cats, h->dish_high, h->I, h->C, h->E, h->a, h->b, h->dish_vec, rows);
     M2D_HIP_TRY(h, hipGetLastError());
     h->dish_vec_valid = true;
     return M2D_OK;

@@ -27,6 +27,15 @@ struct m2d_engine {
     int32_t *err_dev = nullptr;
     int32_t *err_host = nullptr;  // pinned
 
+    // build-defined extension: multi-hot ingredient table
+    const float *ing = nullptr;        // [R, E]
+    const int32_t *ing_off = nullptr;  // [I+1] CSR offsets per dish
+    const int32_t *ing_ids = nullptr;  // [nnz]
+    const float *ing_w = nullptr;      // [nnz] or null (all ones)
+    bool own_ing = false;
+    int64_t ing_rows = 0, ing_nnz = 0;
+    float *dish_high = nullptr;        // [I, E]  H[d] = sum_j w_j ING[id_j] / sum_j w_j
+
     // factored dish vectors for catalogue retrieval (built lazily by m2d_topk_users)
     float *dish_vec = nullptr;  // [I_pad, (C+1)*E]
     int64_t dish_vec_rows = 0;
@@ -57,7 +66,10 @@ struct m2d_engine {
 
 // launchers (m2d_score.hip / m2d_topk.hip); all enqueue on `stream` and return a status
 int m2d_launch_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
-                           bool by_dish, int64_t B, float *out, hipStream_t stream);
+                           bool by_dish, int64_t B, float *out, hipStream_t stream,
+                           bool use_ingredients = false);
+int m2d_launch_build_dish_high(m2d_engine *h, hipStream_t stream);
+int m2d_launch_check_csr(m2d_engine *h, hipStream_t stream);
 int m2d_launch_rank_candidates(m2d_engine *h, const int32_t *users, const int32_t *items,
                                const int32_t *lens, int64_t nseg, int32_t L, int32_t k, float *out_scores,
                                int32_t *out_items, int32_t *out_flags, hipStream_t stream);

@@ -27,6 +27,7 @@ struct ScoreArgs {
     const int32_t *users;
     const int32_t *items;
     const float *cats;  // [B, C] (explicit feed) or [I, C] (by dish)
+    const float *hv;    // extension: per-dish high-level vectors [I, E] (ingredient table), or null
     float *out;
     int64_t B;
     int64_t U;
@@ -80,7 +81,10 @@ __device__ __forceinline__ float group_sum(float v)
 }
 
 // C == 4 categories, E % 4 == 0, E / 4 <= LPP.  FULL: E / 4 == LPP (no idle lanes).
-template <int LPP, int PF, bool BYDISH, bool NT, bool FULL>
+// HV (build-defined extension): the high-level operand sum_c m_c CE_c / n of
+// Model_Recommender.py:67-79 is replaced by a resident per-dish vector H[d] (the normalised multi-hot
+// ingredient sum), i.e. high = <U_high, H[d]>; the low-level path is unchanged.
+template <int LPP, int PF, bool BYDISH, bool NT, bool FULL, bool HV>
 __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
 {
     constexpr int C = 4;
@@ -90,12 +94,14 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
     const bool col_ok = FULL || (j < E4);
     const int jc = col_ok ? j : 0;  // idle lanes re-read column 0 (in bounds), contribution zeroed
     const int64_t nchunks = (p.B + 63) >> 6;
-    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // wave-uniform loop control lives in SGPRs: no shuffle below ever runs under a partial EXEC mask
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
 
     const v4f *pm4 = reinterpret_cast<const v4f *>(p.pm);
     const v4f *re4 = reinterpret_cast<const v4f *>(p.re);
     const v4f *ce4 = reinterpret_cast<const v4f *>(p.ce);
+    const v4f *hv4 = reinterpret_cast<const v4f *>(p.hv);
     const size_t urow4 = (size_t)(C + 1) * E4;  // float4 per user block
 
     v4f cef[C];
@@ -131,6 +137,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
 
         v4f ub[PF][C + 1];
         v4f ib[PF];
+        v4f hb[PF];
         float my_high = 0.f, my_low = 0.f;
 
         auto issue = [&](int s, int slot) {
@@ -140,6 +147,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
 #pragma unroll
             for (int r = 0; r <= C; ++r) ub[slot][r] = ld4<NT>(pu + (size_t)r * E4);
             ib[slot] = re4[(size_t)ds * E4 + jc];
+            if constexpr (HV) hb[slot] = hv4[(size_t)ds * E4 + jc];
         };
 
 #pragma unroll
@@ -157,12 +165,18 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
                 float hs = 0.f, ls = 0.f;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    const v4f dish_category = scale4(mc[c], cef[c]);        // :67
-                    hs = dot4(ub[k][0], dish_category, hs);                    // :71, :75
+                    if constexpr (!HV) {
+                        const v4f dish_category = scale4(mc[c], cef[c]);    // :67
+                        hs = dot4(ub[k][0], dish_category, hs);                // :71, :75
+                    }
                     const v4f dish_memory = scale4(mc[c], ub[k][c + 1]);    // :82
                     ls = dot4(ib[k], dish_memory, ls);                         // :86, :90
                 }
-                if (!FULL && !col_ok) ls = 0.f;
+                if constexpr (HV) hs = dot4(ub[k][0], hb[k], hs);
+                if (!FULL && !col_ok) {
+                    ls = 0.f;
+                    if (HV) hs = 0.f;
+                }
                 if (s + PF < LPP) issue(s + PF, k);
                 hs = group_sum<LPP>(hs);
                 ls = group_sum<LPP>(ls);
@@ -174,7 +188,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
         }
         if (valid) {
             const float n = (m.x + m.y) + (m.z + m.w);                         // :77
-            const float high = my_high / n;                                    // :79
+            const float high = HV ? my_high : my_high / n;                     // :79 (H[d] is already normalised)
             const float low = my_low / n;                                      // :92
             float score = __fadd_rn(__fmul_rn(p.a, high), __fmul_rn(p.b, low));     // :95-96, no fma contraction
             if (bad) score = __builtin_nanf("");
@@ -189,7 +203,7 @@ template <bool BYDISH>
 __global__ __launch_bounds__(256) void m2d_score_pairs_generic(ScoreArgs p)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int C = p.C, E = p.E;
     for (int64_t pi = wave0; pi < p.B; pi += nwaves) {
@@ -215,14 +229,16 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_generic(ScoreArgs p)
             const float mc = mrow[c];
             n += mc;
             for (int e = lane; e < E; e += 64) {
-                hs = fmaf(um[e], mc * p.ce[(size_t)c * E + e], hs);
+                if (!p.hv) hs = fmaf(um[e], mc * p.ce[(size_t)c * E + e], hs);
                 ls = fmaf(it[e], mc * um[(size_t)(c + 1) * E + e], ls);
             }
         }
+        if (p.hv)
+            for (int e = lane; e < E; e += 64) hs = fmaf(um[e], p.hv[(size_t)did * E + e], hs);
         hs = group_sum<64>(hs);
         ls = group_sum<64>(ls);
         if (lane == 0) {
-            float score = __fadd_rn(__fmul_rn(p.a, hs / n), __fmul_rn(p.b, ls / n));
+            float score = __fadd_rn(__fmul_rn(p.a, p.hv ? hs : hs / n), __fmul_rn(p.b, ls / n));
             if (bad) score = __builtin_nanf("");
             p.out[pi] = score;
         }
@@ -234,8 +250,13 @@ void launch_c4(const ScoreArgs &a, int pf, bool nt, dim3 grid, hipStream_t st, c
 {
 #define M2D_CASE(PFV, NTV)                                                                           \
     if (pf == PFV && nt == NTV) {                                                                    \
-        hipLaunchKernelGGL((m2d_score_pairs_c4<LPP, PFV, BYDISH, NTV, FULL>), grid, dim3(256), 0, st, a); \
+        hipLaunchKernelGGL((m2d_score_pairs_c4<LPP, PFV, BYDISH, NTV, FULL, false>), grid, dim3(256), 0, st, a); \
         return;                                                                                      \
+    }
+    if (a.hv) {   // extension kernel: one configuration (PF 2, non-temporal user rows)
+        *name = "m2d_score_pairs_c4_hv";
+        hipLaunchKernelGGL((m2d_score_pairs_c4<LPP, 2, BYDISH, true, FULL, true>), grid, dim3(256), 0, st, a);
+        return;
     }
     *name = "m2d_score_pairs_c4";
     M2D_CASE(1, false) M2D_CASE(1, true) M2D_CASE(2, false) M2D_CASE(2, true)
@@ -286,10 +307,11 @@ int launch_any(m2d_engine *h, const ScoreArgs &a, hipStream_t st)
 }  // namespace
 
 int m2d_launch_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
-                           bool by_dish, int64_t B, float *out, hipStream_t stream)
+                           bool by_dish, int64_t B, float *out, hipStream_t stream, bool use_ingredients)
 {
     if (B == 0) return M2D_OK;
     ScoreArgs a;
+    a.hv = use_ingredients ? h->dish_high : nullptr;
     a.pm = h->pm; a.re = h->re; a.ce = h->ce;
     a.users = users; a.items = items; a.cats = cats; a.out = out;
     a.B = B; a.U = h->U; a.I = h->I; a.user_base = h->user_base;

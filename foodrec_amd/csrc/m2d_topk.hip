@@ -46,7 +46,7 @@ __global__ __launch_bounds__(RANK_WAVES * 64) void m2d_rank_segments(
     float *out_scores, int32_t *out_items, int32_t *out_flags)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int32_t *s_item = reinterpret_cast<int32_t *>(smem) + (size_t)wave * 3 * L;  // as fed
     int32_t *s_key = s_item + L;                                 // item if first occurrence, else -1
     float *s_val = reinterpret_cast<float *>(s_key + L);         // collapsed value of that key

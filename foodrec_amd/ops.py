@@ -75,6 +75,53 @@ class ScoringEngine:
         _native.raise_for(_native.lib().m2d_set_dish_categories(self._h, t.data_ptr(), _native.M2D_TABLES_DEVICE), self._h)
         self.dish_cats = t
 
+    def set_ingredients(self, ing_table, offsets, ids, weights=None):
+        """Build-defined extension: multi-hot ingredient lists per dish in CSR form.
+        ing_table [R, E]; offsets i32[I+1]; ids i32[nnz]; weights f32[nnz] or None (all ones)."""
+        t = _dev_f32(ing_table, self.device)
+        if t.dim() != 2 or t.shape[1] != self.E:
+            raise ValueError("ingredient table must be [R, E=%d]" % self.E)
+        as_i32 = lambda x: torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x).to(
+            device=self.device, dtype=torch.int32).contiguous()
+        off, idt = as_i32(offsets), as_i32(ids)
+        if off.numel() != self.I + 1:
+            raise ValueError("offsets must have I + 1 = %d entries" % (self.I + 1))
+        wt = _dev_f32(weights, self.device) if weights is not None else None
+        if wt is not None and wt.numel() != idt.numel():
+            raise ValueError("weights and ids differ in length")
+        with torch.cuda.device(self.device):
+            rc = _native.lib().m2d_set_ingredients(self._h, t.data_ptr(), t.shape[0], off.data_ptr(),
+                                                   idt.data_ptr() if idt.numel() else None,
+                                                   wt.data_ptr() if wt is not None else None, idt.numel(),
+                                                   _native.M2D_TABLES_DEVICE)
+        _native.raise_for(rc, self._h)
+        self._ingredients = (t, off, idt, wt)          # keep the borrowed device buffers alive
+
+    def clear_ingredients(self):
+        _native.raise_for(_native.lib().m2d_clear_ingredients(self._h), self._h)
+        self._ingredients = None
+
+    def score_pairs_ingredients(self, users: torch.Tensor, items: torch.Tensor, cats: Optional[torch.Tensor] = None,
+                                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Extension: high-level path from the ingredient table; cats=None -> resident dish masks."""
+        self._check_ids(users, items)
+        B = users.numel()
+        users, items = users.contiguous(), items.contiguous()
+        if cats is not None:
+            if cats.numel() != B * self.C:
+                raise ValueError("cats must be [B, C]")
+            cats = cats.to(torch.float32).contiguous()
+            if cats.data_ptr() % 16:
+                cats = cats.clone()
+        if out is None:
+            out = torch.empty(B, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = _native.lib().m2d_score_pairs_ingredients(self._h, users.data_ptr(), items.data_ptr(),
+                                                           cats.data_ptr() if cats is not None else None, B,
+                                                           out.data_ptr(), _stream_ptr())
+        _native.raise_for(rc, self._h)
+        return out
+
     def set_option(self, name: str, value: int):
         _native.raise_for(_native.lib().m2d_set_option(self._h, name.encode(), int(value)), self._h)
 

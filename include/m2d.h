@@ -34,6 +34,7 @@ typedef struct m2d_engine m2d_engine;
 #define M2D_ERR_NOT_CONFIGURED (-5) /* call needs m2d_set_dish_categories / m2d_set_* first          */
 #define M2D_ERR_UNSUPPORTED (-6)    /* shape outside what the kernels cover (message says which)     */
 #define M2D_ERR_NO_DEVICE (-7)      /* no HIP device visible: there is no CPU fallback, by design    */
+#define M2D_ERR_BAD_INGREDIENT (-8) /* extension: ingredient id outside [0, R) or a malformed CSR     */
 
 #define M2D_TABLES_HOST 0   /* table pointers are host memory: copied to HBM once, engine-owned      */
 #define M2D_TABLES_DEVICE 1 /* table pointers are device memory: borrowed, caller keeps them alive   */
@@ -91,6 +92,25 @@ int m2d_rank_candidates(m2d_engine *h, const int32_t *users, const int32_t *item
  * dish id, NaN scores last.  out_scores f32[nU, k], out_ids i32[nU, k].  1 <= k <= 64. */
 int m2d_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, float *out_scores,
                    int32_t *out_ids, void *stream);
+
+/* ---- build-defined extension, NO reference counterpart (BASELINE.json configs 2-5) ----
+ * Multi-hot ingredient table for the high-level path:
+ *     H[d]  = sum_j w_j ING[id_j] / sum_j w_j     over dish d's list ids[off[d] .. off[d+1])
+ *     high  = <U_high[u], H[d]>                    in place of Model_Recommender.py:67-79
+ *     score = a*high + (1-a)*low                   low-level path and blend unchanged (:82-96)
+ * With ING = Category_Embedding, ids = 0..C-1 and w = the dish's category mask this is the reference's
+ * formula.  ing f32[R, E]; off i32[I+1] (CSR, off[0] = 0); ids i32[nnz]; w f32[nnz] or NULL (all 1).
+ * The call gathers and segment-sums the rows into H once (it synchronises and reports a malformed CSR /
+ * bad id as M2D_ERR_BAD_INGREDIENT); all four arrays use `table_flags`.  A dish with an empty list
+ * scores NaN, like an empty category mask. */
+int m2d_set_ingredients(m2d_engine *h, const float *ing, int64_t R, const int32_t *off, const int32_t *ids,
+                        const float *w, int64_t nnz, int table_flags);
+int m2d_clear_ingredients(m2d_engine *h);
+
+/* m2d_score_pairs with the ingredient high-level path.  cats f32[B, C] feeds the low-level path;
+ * cats == NULL uses the resident dish masks (m2d_set_dish_categories). */
+int m2d_score_pairs_ingredients(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
+                                int64_t B, float *out, void *stream);
 
 /* Synchronise `stream` and report (then clear) the first id error latched by kernels since the
  * previous check: M2D_OK, M2D_ERR_BAD_USER_ID or M2D_ERR_BAD_ITEM_ID.  TF-CPU GatherV2 raises

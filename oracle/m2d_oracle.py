@@ -151,6 +151,50 @@ def inference_factored(PM, RE, CE, users, items, dish_categories, coef: float = 
 
 
 # ----------------------------------------------------------------------------------------------
+# Build-defined extensions (NO reference counterpart; BASELINE.json configs 2-5).  These restate the
+# build's own definitions; nothing in the reference pins them.
+# ----------------------------------------------------------------------------------------------
+
+def dish_high_vectors(ING, offsets, ids, weights=None, dtype=np.float64) -> np.ndarray:
+    """H[d] = sum_j w_j ING[id_j] / sum_j w_j over the CSR list of dish d (empty list -> NaN row)."""
+    ING = np.asarray(ING, dtype=dtype)
+    offsets = np.asarray(offsets, dtype=np.int64)
+    ids = np.asarray(ids, dtype=np.int64)
+    w = np.ones(len(ids), dtype=dtype) if weights is None else np.asarray(weights, dtype=dtype)
+    I = len(offsets) - 1
+    H = np.empty((I, ING.shape[1]), dtype=dtype)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for d in range(I):
+            sl = slice(offsets[d], offsets[d + 1])
+            acc = np.zeros(ING.shape[1], dtype=dtype)
+            tot = dtype(0)
+            for j, wj in zip(ids[sl], w[sl]):                 # sequential, like the kernel
+                acc = acc + wj * ING[j]
+                tot = tot + wj
+            H[d] = acc / tot
+    return H
+
+
+def inference_ingredients(PM, RE, ING, offsets, ids, weights, users, items, categories,
+                          coef: float = DEFAULT_COEF, dtype=np.float64) -> np.ndarray:
+    """score = a * <U_high, H[d]> + (1-a) * low, with `low` exactly as Model_Recommender.py:82-92."""
+    PM = np.asarray(PM)
+    C = PM.shape[1] - 1
+    users = _as_ids(users, PM.shape[0], "user")
+    items = _as_ids(items, np.asarray(RE).shape[0], "item")
+    cat = _as_mask(categories, C).astype(dtype)
+    PMd, REd = PM.astype(dtype), np.asarray(RE).astype(dtype)
+    H = dish_high_vectors(ING, offsets, ids, weights, dtype)
+    a32, b32 = blend_coefficients(coef)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        UM = PMd[users]
+        high = (UM[:, 0, :] * H[items]).sum(axis=1, dtype=dtype)
+        n = cat.sum(axis=(1, 2), dtype=dtype)
+        low = (REd[items][:, None, :] * (cat * UM[:, 1:, :])).sum(axis=(1, 2), dtype=dtype) / n
+        return dtype(a32) * high + dtype(b32) * low
+
+
+# ----------------------------------------------------------------------------------------------
 # Evaluator (evaluate.py)
 # ----------------------------------------------------------------------------------------------
 

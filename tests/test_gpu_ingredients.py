@@ -1,0 +1,111 @@
+"""GPU parity of the build-defined ingredient extension (m2d_set_ingredients /
+m2d_score_pairs_ingredients) against the build's own CPU restatement -- the reference has no
+ingredient table, so this pins only the documented superset and its reduction
+to the reference formula."""
+import numpy as np
+import pytest
+
+from helpers import assert_scores_close, random_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _csr(I, R, rng, lo=1, hi=20, empty=()):
+    lens = rng.integers(lo, hi + 1, I)
+    for d in empty:
+        lens[d] = 0
+    off = np.zeros(I + 1, np.int32)
+    off[1:] = np.cumsum(lens)
+    ids = rng.integers(0, R, off[-1]).astype(np.int32)
+    return off, ids
+
+
+@pytest.mark.parametrize("E", [6, 32, 64, 128, 200, 320])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_ingredient_scores_match_restatement(E, weighted):
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    U, I, R, B = 200, 150, 300, 3000
+    PM, RE, CE, users, items, cats = random_case(U, I, 4, E, B, seed=E, zero_rows=False)
+    rng = np.random.default_rng(E + 1)
+    ING = (rng.standard_normal((R, E)) / np.sqrt(E)).astype(np.float32)
+    off, ids = _csr(I, R, rng, empty=(7, 149))
+    w = rng.uniform(0.5, 2.0, len(ids)).astype(np.float32) if weighted else None
+    eng = ScoringEngine(PM, RE, CE)
+    with pytest.raises(ValueError):
+        eng.score_pairs_ingredients(torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda"),
+                                    torch.as_tensor(cats, device="cuda"))
+    eng.set_ingredients(ING, off, ids, w)
+    got = eng.score_pairs_ingredients(torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda"),
+                                      torch.as_tensor(cats, device="cuda"))
+    eng.check()
+    ref = oracle.inference_ingredients(PM, RE, ING, off, ids, w, users, items, cats)
+    assert np.isnan(ref[(items == 7) | (items == 149)]).all()
+    assert_scores_close(got.cpu().numpy(), ref, what="E%d" % E)
+    # resident dish masks instead of per-pair masks
+    dish_cats = np.random.default_rng(3).integers(0, 2, (I, 4)).astype(np.float32)
+    eng.set_dish_categories(dish_cats)
+    got2 = eng.score_pairs_ingredients(torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda"))
+    eng.check()
+    assert_scores_close(got2.cpu().numpy(), oracle.inference_ingredients(PM, RE, ING, off, ids, w, users, items, dish_cats[items]))
+    # the plain reference path is untouched by the extension
+    base = eng.score_pairs(torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda"),
+                           torch.as_tensor(cats, device="cuda")); eng.check()
+    assert_scores_close(base.cpu().numpy(), oracle.inference_f64(PM, RE, CE, users, items, cats))
+    eng.clear_ingredients()
+    with pytest.raises(ValueError):
+        eng.score_pairs_ingredients(torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda"))
+
+
+@pytest.mark.parametrize("E", [64, 128, 24])
+def test_reduces_to_reference_formula(E):
+    """ING = Category_Embedding, ids = 0..3, weights = the dish mask  ==>  the reference score."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    U, I, B = 120, 90, 2000
+    PM, RE, CE, users, items, _ = random_case(U, I, 4, E, B, seed=E + 5)
+    dish_cats = np.random.default_rng(2).integers(0, 2, (I, 4)).astype(np.float32)
+    dish_cats[5] = 0                                                  # empty mask -> NaN on both paths
+    off = (np.arange(I + 1) * 4).astype(np.int32)
+    ids = np.tile(np.arange(4, dtype=np.int32), I)
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(dish_cats)
+    eng.set_ingredients(CE, off, ids, dish_cats.reshape(-1))
+    ut, it = torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda")
+    ext = eng.score_pairs_ingredients(ut, it).cpu().numpy()
+    ref_dev = eng.score_pairs_bydish(ut, it).cpu().numpy()
+    eng.check()
+    assert_scores_close(ext, ref_dev, 2e-6, "extension vs reference kernel")
+    assert_scores_close(ext, oracle.inference_f64(PM, RE, CE, users, items, dish_cats[items]))
+
+
+def test_ingredient_errors_and_topk():
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    U, I, R, E = 64, 100, 50, 64
+    PM, RE, CE, users, items, cats = random_case(U, I, 4, E, 100, seed=1, zero_rows=False)
+    rng = np.random.default_rng(4)
+    ING = rng.standard_normal((R, E)).astype(np.float32) / 8
+    off, ids = _csr(I, R, rng)
+    eng = ScoringEngine(PM, RE, CE)
+    bad = ids.copy(); bad[17] = R
+    with pytest.raises(IndexError, match="ingredient id %d at position 17" % R):
+        eng.set_ingredients(ING, off, bad)
+    boff = off.copy(); boff[10] = boff[11] + 1
+    with pytest.raises(IndexError, match="CSR"):
+        eng.set_ingredients(ING, boff, ids)
+    with pytest.raises(ValueError):
+        eng.set_ingredients(ING, off[:-1], ids)
+    eng.set_ingredients(ING, off, ids)
+    # catalogue retrieval picks the ingredient vectors up as well
+    dish_cats = np.ones((I, 4), np.float32)
+    eng.set_dish_categories(dish_cats)
+    s, idx = eng.topk_users(torch.arange(0, 40, dtype=torch.int32, device="cuda"), 10); eng.check()
+    s, idx = s.cpu().numpy(), idx.cpu().numpy()
+    for u in range(40):
+        ref = oracle.inference_ingredients(PM, RE, ING, off, ids, None, np.full(I, u), np.arange(I), dish_cats)
+        assert_scores_close(s[u], ref[idx[u]])
+        assert np.sort(ref)[-10] <= s[u].min() + 1e-4

@@ -102,3 +102,14 @@ def test_torch_graph_restatement_agrees():
     got = torch_graph.inference(torch.from_numpy(PM), torch.from_numpy(RE), torch.from_numpy(CE),
                                 torch.from_numpy(users), torch.from_numpy(items), torch.from_numpy(cats)).numpy()
     assert_scores_close(got, oracle.inference_f64(PM, RE, CE, users, items, cats), 1e-5)
+
+
+def test_ingredient_extension_reduces_to_reference_in_the_oracle():
+    """Build-defined superset: with ING = CE, ids = 0..C-1 and w = the mask it IS the
+    reference formula."""
+    PM, RE, CE, users, items, _ = random_case(40, 30, 4, 16, 200, seed=77)
+    dish_cats = np.random.default_rng(1).integers(0, 2, (30, 4)).astype(np.float32)
+    off = np.arange(31) * 4
+    ids = np.tile(np.arange(4), 30)
+    ext = oracle.inference_ingredients(PM, RE, CE, off, ids, dish_cats.reshape(-1), users, items, dish_cats[items])
+    assert_scores_close(ext, oracle.inference_f64(PM, RE, CE, users, items, dish_cats[items]), 1e-12)
