@@ -66,6 +66,10 @@ void release(m2d_engine *h)
     if (h->own_ce && h->ce) (void)hipFree((void *)h->ce);
     if (h->own_dish_cats && h->dish_cats) (void)hipFree((void *)h->dish_cats);
     if (h->dish_vec) (void)hipFree(h->dish_vec);
+    if (h->own_mlp) {
+        for (const float *q : {h->mlp_w1, h->mlp_b1, h->mlp_w2, h->mlp_b2, h->mlp_w3})
+            if (q) (void)hipFree((void *)q);
+    }
     if (h->dish_high) (void)hipFree(h->dish_high);
     if (h->own_ing) {
         if (h->ing) (void)hipFree((void *)h->ing);
@@ -306,6 +310,59 @@ int m2d_score_pairs_ingredients(m2d_engine *h, const int32_t *users, const int32
     M2D_HIP_TRY(h, hipSetDevice(h->device));
     return m2d_launch_score_pairs(h, users, items, cats ? cats : h->dish_cats, cats == nullptr, B, out,
                                   (hipStream_t)stream, /*use_ingredients=*/true);
+}
+
+int m2d_clear_mlp_head(m2d_engine *h)
+{
+    if (!h) return M2D_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    if (h->own_mlp) {
+        for (const float *q : {h->mlp_w1, h->mlp_b1, h->mlp_w2, h->mlp_b2, h->mlp_w3})
+            if (q) (void)hipFree((void *)q);
+    }
+    h->mlp_w1 = h->mlp_b1 = h->mlp_w2 = h->mlp_b2 = h->mlp_w3 = nullptr;
+    h->own_mlp = false;
+    h->mlp_h1 = h->mlp_h2 = 0;
+    return M2D_OK;
+}
+
+int m2d_set_mlp_head(m2d_engine *h, const float *W1, const float *b1, const float *W2, const float *b2,
+                     const float *w3, float b3, int32_t H1, int32_t H2, int table_flags)
+{
+    if (!h || !W1 || !b1 || !W2 || !b2 || !w3 || H1 <= 0 || H2 <= 0)
+        return fail(h, M2D_ERR_INVALID_ARG, "m2d_set_mlp_head: bad argument");
+    if (table_flags != M2D_TABLES_HOST && table_flags != M2D_TABLES_DEVICE)
+        return fail(h, M2D_ERR_INVALID_ARG, "m2d_set_mlp_head: bad table_flags");
+    int rc = m2d_clear_mlp_head(h);
+    if (rc != M2D_OK) return rc;
+    M2D_HIP_TRY(h, hipSetDevice(h->device));
+    const size_t K = (size_t)(h->C + 1) * h->E;
+    bool own = false;
+    if ((rc = adopt_table(h, W1, K * H1, table_flags, &h->mlp_w1, &own)) != M2D_OK) return rc;
+    h->own_mlp = own;
+    if ((rc = adopt_table(h, b1, (size_t)H1, table_flags, &h->mlp_b1, &own)) != M2D_OK) return rc;
+    if ((rc = adopt_table(h, W2, (size_t)H1 * H2, table_flags, &h->mlp_w2, &own)) != M2D_OK) return rc;
+    if ((rc = adopt_table(h, b2, (size_t)H2, table_flags, &h->mlp_b2, &own)) != M2D_OK) return rc;
+    if ((rc = adopt_table(h, w3, (size_t)H2, table_flags, &h->mlp_w3, &own)) != M2D_OK) return rc;
+    if (!aligned16(h->mlp_w1) || !aligned16(h->mlp_w2)) return fail(h, M2D_ERR_INVALID_ARG, "MLP weights must be 16-byte aligned");
+    h->mlp_b3 = b3;
+    h->mlp_h1 = H1;
+    h->mlp_h2 = H2;
+    return M2D_OK;
+}
+
+int m2d_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_t *items, int64_t B, float *out,
+                        void *stream)
+{
+    if (!h) return M2D_ERR_INVALID_ARG;
+    if (B < 0) return fail(h, M2D_ERR_INVALID_ARG, "m2d_score_pairs_mlp: negative batch");
+    if (B == 0) return M2D_OK;
+    if (!users || !items || !out) return fail(h, M2D_ERR_INVALID_ARG, "m2d_score_pairs_mlp: null buffer");
+    if (!h->mlp_w1) return fail(h, M2D_ERR_NOT_CONFIGURED, "call m2d_set_mlp_head first");
+    if (!h->dish_cats) return fail(h, M2D_ERR_NOT_CONFIGURED, "call m2d_set_dish_categories first");
+    M2D_HIP_TRY(h, hipSetDevice(h->device));
+    return m2d_launch_score_pairs_mlp(h, users, items, B, out, (hipStream_t)stream);
 }
 
 int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_index)

@@ -333,7 +333,9 @@ __global__ void m2d_topk_merge_splits(const float *ps, const int32_t *pi, int64_
     }
 }
 
-int ensure_dish_vectors(m2d_engine *h, hipStream_t st)
+}  // namespace
+
+int m2d_ensure_dish_vectors(m2d_engine *h, hipStream_t st)
 {
     if (h->dish_vec_valid) return M2D_OK;
     const int64_t rows = (h->I + 31) / 32 * 32;
@@ -350,6 +352,8 @@ int ensure_dish_vectors(m2d_engine *h, hipStream_t st)
     h->dish_vec_valid = true;
     return M2D_OK;
 }
+
+namespace {
 
 template <int NB, int WAVES>
 int launch_mfma(m2d_engine *h, TopkArgs &a, float *final_s, int32_t *final_i, hipStream_t st)
@@ -405,7 +409,7 @@ int launch_mfma(m2d_engine *h, TopkArgs &a, float *final_s, int32_t *final_i, hi
 int m2d_launch_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, float *out_scores,
                           int32_t *out_ids, hipStream_t stream)
 {
-    int rc = ensure_dish_vectors(h, stream);
+    int rc = m2d_ensure_dish_vectors(h, stream);
     if (rc != M2D_OK) return rc;
     const int K = (h->C + 1) * h->E;
     TopkArgs a;

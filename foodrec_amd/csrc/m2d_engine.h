@@ -36,6 +36,12 @@ struct m2d_engine {
     int64_t ing_rows = 0, ing_nnz = 0;
     float *dish_high = nullptr;        // [I, E]  H[d] = sum_j w_j ING[id_j] / sum_j w_j
 
+    // build-defined extension: 3-layer scoring head
+    const float *mlp_w1 = nullptr, *mlp_b1 = nullptr, *mlp_w2 = nullptr, *mlp_b2 = nullptr, *mlp_w3 = nullptr;
+    float mlp_b3 = 0.f;
+    int32_t mlp_h1 = 0, mlp_h2 = 0;
+    bool own_mlp = false;
+
     // factored dish vectors for catalogue retrieval (built lazily by m2d_topk_users)
     float *dish_vec = nullptr;  // [I_pad, (C+1)*E]
     int64_t dish_vec_rows = 0;
@@ -70,6 +76,9 @@ int m2d_launch_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *i
                            bool use_ingredients = false);
 int m2d_launch_build_dish_high(m2d_engine *h, hipStream_t stream);
 int m2d_launch_check_csr(m2d_engine *h, hipStream_t stream);
+int m2d_ensure_dish_vectors(m2d_engine *h, hipStream_t stream);
+int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_t *items, int64_t B, float *out,
+                               hipStream_t stream);
 int m2d_launch_rank_candidates(m2d_engine *h, const int32_t *users, const int32_t *items,
                                const int32_t *lens, int64_t nseg, int32_t L, int32_t k, float *out_scores,
                                int32_t *out_items, int32_t *out_flags, hipStream_t stream);

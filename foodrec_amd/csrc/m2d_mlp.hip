@@ -1,0 +1,266 @@
+// Build-defined extension (NO reference counterpart; BASELINE.json configs[2]):
+// a 3-layer scoring head on top of the reference score.
+//
+//   z[k]  = flatten(PM[u])[k] * Dt[d][k]            k < K = (C+1)*E; sum_k z[k] IS the reference score
+//                                                   (factored form of Model_Recommender.py:67-96)
+//   h1    = relu(W1^T z + b1)   W1 [K, H1]
+//   h2    = relu(W2^T h1 + b2)  W2 [H1, H2]
+//   score = sum_k z[k] + (w3 . h2 + b3)
+//
+// With the head absent (or w3 = 0, b3 = 0) the score is the reference formula.  The closest reference
+// material for a dense head is in the OTHER model (Code/WIRCNN/Model_WIRCNN.py:174, :208); it is not the
+// Recommender's scorer and nothing pins this head except the build's own CPU restatement.
+//
+// MFMA kernel (H1 = 256, H2 = 64, K % 64 == 0), exact-f32 v_mfma_f32_32x32x2_f32:
+//   * a wave owns 32 pairs; pairs sit on the MFMA *column* (B operand = z, 32 k-values per lane per
+//     64-wide K chunk, built in registers from two gathered rows), hidden units on the rows, so the
+//     layer-1 accumulators (8 tiles x 16 VGPRs) are already the B operand of layer 2 -- no transpose,
+//     no LDS round trip between layers -- and layer 3 is a per-lane dot over the layer-2 accumulators;
+//   * W1 streams through a 2 x 64 KiB LDS ring by LDS-DMA (one 1-KiB piece = one k-row), one barrier per
+//     256 MFMAs per wave; W2 rides the same ring as the (K/64 + 1)-th stage;
+//   * 8 waves (2 per SIMD) per workgroup = 256 pairs per tile, persistent grid-stride over tiles.
+// Roofline: MFMA (2*(K*H1 + H1*H2 + H2) flop per pair = 360 704 at E = 128) vs 157.3 TFLOP/s f32.
+#include "m2d_engine.h"
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+struct MlpArgs {
+    const float *pm;   // [U, K]
+    const float *dt;   // [rows, K]
+    const float *w1;   // [K, H1]
+    const float *b1;   // [H1]
+    const float *w2;   // [H1, H2]
+    const float *b2;   // [H2]
+    const float *w3;   // [H2]
+    float b3;
+    const int32_t *users;
+    const int32_t *items;
+    float *out;
+    int64_t B, U, I, user_base;
+    int32_t K, H1, H2;
+    int32_t *err;
+};
+
+__device__ __forceinline__ void latch(int32_t *err, int code, int64_t value, int64_t index)
+{
+    if (atomicCAS(&err[0], 0, code) == 0) {
+        err[1] = (int32_t)value;
+        err[2] = (int32_t)(index & 0xffffffff);
+        err[3] = (int32_t)(index >> 32);
+    }
+}
+
+constexpr int MH1 = 256, MH2 = 64, MWAVES = 8;
+constexpr int RING_FLOATS = 64 * MH1;   // one stage: 64 k-rows of W1 (= all of W2: 256 x 64)
+
+template <int KCH /* K / 64 */>
+__global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
+{
+    extern __shared__ __align__(16) float smem[];
+    float *ring = smem;                       // [2][RING_FLOATS]
+    float *sb1 = smem + 2 * RING_FLOATS;      // [256]
+    float *sb2 = sb1 + MH1;                   // [64]
+    float *sw3 = sb2 + MH2;                   // [64]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int pl = lane & 31, h = lane >> 5;
+    constexpr int K = KCH * 64;
+    constexpr int NST = KCH + 1;              // stages per tile: KCH chunks of W1, then W2
+
+    for (int i = threadIdx.x; i < MH1; i += MWAVES * 64) sb1[i] = p.b1[i];
+    if (threadIdx.x < MH2) {
+        sb2[threadIdx.x] = p.b2[threadIdx.x];
+        sw3[threadIdx.x] = p.w3[threadIdx.x];
+    }
+
+    // stage s (mod NST): s < KCH -> rows [64 s, 64 s + 64) of W1; s == KCH -> W2.  64 pieces of 1 KiB.
+    auto issue_stage = [&](int s, int buf) {
+        const float *src = s < KCH ? p.w1 + (size_t)s * 64 * MH1 : p.w2;
+        float *dst = ring + (size_t)buf * RING_FLOATS;
+        for (int pc = wave; pc < 64; pc += MWAVES)
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + pc * 256 + lane * 4),
+                                             (void __attribute__((address_space(3))) *)(dst + pc * 256), 16, 0, 0);
+    };
+
+    const int64_t ntiles = (p.B + 32 * MWAVES - 1) / (32 * MWAVES);
+    int ringpos = 0;                          // parity of the stage being consumed
+    if ((int64_t)blockIdx.x < ntiles) issue_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t pi = tile * (32 * MWAVES) + wave * 32 + pl;
+        const bool valid = pi < p.B;
+        int32_t uid = valid ? p.users[pi] : (int32_t)p.user_base;
+        int32_t did = valid ? p.items[pi] : 0;
+        int64_t ul = (int64_t)uid - p.user_base;
+        bool bad = false;
+        if (ul < 0 || ul >= p.U) { latch(p.err, M2D_ERR_BAD_USER_ID, uid, pi); ul = 0; bad = true; }
+        if (did < 0 || (int64_t)did >= p.I) { latch(p.err, M2D_ERR_BAD_ITEM_ID, did, pi); did = 0; bad = true; }
+        const v4f *pu = reinterpret_cast<const v4f *>(p.pm) + (size_t)ul * (K / 4) + 8 * h;
+        const v4f *pd = reinterpret_cast<const v4f *>(p.dt) + (size_t)did * (K / 4) + 8 * h;
+
+        v16f acc1[8];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[nt][r] = 0.f;
+        float base = 0.f;
+
+        // ---- layer 1: K in chunks of 64; lane (pair pl, half h) owns k = 64 kc + 32 h + t ----------------
+        for (int kc = 0; kc < KCH; ++kc) {
+            const int buf = ringpos & 1;
+            issue_stage((kc + 1) % NST, buf ^ 1);          // kc + 1 == KCH -> W2
+            float z[32];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const v4f a = pu[kc * 16 + i], b = pd[kc * 16 + i];
+                const v4f zz = a * b;
+                z[4 * i + 0] = zz.x; z[4 * i + 1] = zz.y; z[4 * i + 2] = zz.z; z[4 * i + 3] = zz.w;
+                base += (zz.x + zz.y) + (zz.z + zz.w);
+            }
+            const float *wrow = ring + (size_t)buf * RING_FLOATS + (size_t)(32 * h) * MH1 + pl;
+#pragma unroll
+            for (int t = 0; t < 32; ++t) {
+#pragma unroll
+                for (int nt = 0; nt < 8; ++nt) {
+                    const float a = wrow[t * MH1 + 32 * nt];
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z[t], acc1[nt], 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            ++ringpos;
+        }
+
+        // ---- layer 2: acc1 (rows n = 32 nt + (r&3) + 8 (r>>2) + 4 h, column = pair) is the B operand ----
+        {
+            const int buf = ringpos & 1;
+            issue_stage(0, buf ^ 1);                       // next tile's first W1 chunk (harmless if none)
+            const float *w2s = ring + (size_t)buf * RING_FLOATS + pl;
+            v16f acc2[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float hv = fmaxf(acc1[nt][r] + sb1[n], 0.f);
+                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2s[n * MH2], hv, acc2[0], 0, 0, 0);
+                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2s[n * MH2 + 32], hv, acc2[1], 0, 0, 0);
+                }
+            }
+            // ---- layer 3: per-lane dot over the layer-2 accumulators, halves combined by one shuffle ----
+            float o = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    o = fmaf(sw3[m], fmaxf(acc2[mt][r] + sb2[m], 0.f), o);
+                }
+            o += __shfl_xor(o, 32, 64);
+            base += __shfl_xor(base, 32, 64);
+            if (h == 0 && valid) p.out[pi] = bad ? __builtin_nanf("") : (base + (o + p.b3));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            ++ringpos;
+        }
+    }
+}
+
+// Any K / H1 / H2: one wave per pair, activations in LDS.  Slow; for shapes the MFMA kernel does not cover.
+__global__ __launch_bounds__(256) void m2d_mlp_generic(MlpArgs p)
+{
+    extern __shared__ __align__(16) float smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    float *z = smem + (size_t)wave * (p.K + p.H1 + p.H2);
+    float *h1 = z + p.K, *h2 = h1 + p.H1;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t pi = (int64_t)blockIdx.x * 4 + wave; pi < p.B; pi += nw) {
+        int32_t uid = p.users[pi], did = p.items[pi];
+        int64_t ul = (int64_t)uid - p.user_base;
+        bool bad = false;
+        if (ul < 0 || ul >= p.U) { if (lane == 0) latch(p.err, M2D_ERR_BAD_USER_ID, uid, pi); ul = 0; bad = true; }
+        if (did < 0 || (int64_t)did >= p.I) { if (lane == 0) latch(p.err, M2D_ERR_BAD_ITEM_ID, did, pi); did = 0; bad = true; }
+        float base = 0.f;
+        for (int k = lane; k < p.K; k += 64) {
+            const float v = p.pm[(size_t)ul * p.K + k] * p.dt[(size_t)did * p.K + k];
+            z[k] = v;
+            base += v;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) base += __shfl_xor(base, off, 64);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int n = lane; n < p.H1; n += 64) {
+            float s = 0.f;
+            for (int k = 0; k < p.K; ++k) s = fmaf(z[k], p.w1[(size_t)k * p.H1 + n], s);
+            h1[n] = fmaxf(s + p.b1[n], 0.f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int m = lane; m < p.H2; m += 64) {
+            float s = 0.f;
+            for (int n = 0; n < p.H1; ++n) s = fmaf(h1[n], p.w2[(size_t)n * p.H2 + m], s);
+            h2[m] = fmaxf(s + p.b2[m], 0.f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float o = 0.f;
+        for (int m = lane; m < p.H2; m += 64) o = fmaf(p.w3[m], h2[m], o);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) o += __shfl_xor(o, off, 64);
+        if (lane == 0) p.out[pi] = bad ? __builtin_nanf("") : (base + (o + p.b3));
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace
+
+int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_t *items, int64_t B, float *out,
+                               hipStream_t stream)
+{
+    if (B == 0) return M2D_OK;
+    int rc = m2d_ensure_dish_vectors(h, stream);
+    if (rc != M2D_OK) return rc;
+    MlpArgs a;
+    a.pm = h->pm; a.dt = h->dish_vec; a.w1 = h->mlp_w1; a.b1 = h->mlp_b1; a.w2 = h->mlp_w2; a.b2 = h->mlp_b2;
+    a.w3 = h->mlp_w3; a.b3 = h->mlp_b3; a.users = users; a.items = items; a.out = out;
+    a.B = B; a.U = h->U; a.I = h->I; a.user_base = h->user_base;
+    a.K = (h->C + 1) * h->E; a.H1 = h->mlp_h1; a.H2 = h->mlp_h2; a.err = h->err_dev;
+    const bool mfma_ok = a.H1 == MH1 && a.H2 == MH2 && a.K % 64 == 0 && h->opt_variant != 9;
+    const int kch = a.K / 64;
+    if (mfma_ok && (kch == 5 || kch == 10 || kch == 20 || kch == 3)) {
+        const size_t lds = (size_t)(2 * RING_FLOATS + MH1 + 2 * MH2) * sizeof(float);
+        const int64_t ntiles = (B + 32 * MWAVES - 1) / (32 * MWAVES);
+        const unsigned grid = (unsigned)(ntiles < h->num_cu ? ntiles : h->num_cu);
+#define M2D_MLP_CASE(N)                                                                                     \
+    if (kch == N) {                                                                                         \
+        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_mlp_mfma<N>,                                   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+        hipLaunchKernelGGL(m2d_mlp_mfma<N>, dim3(grid), dim3(MWAVES * 64), lds, stream, a);                 \
+    }
+        M2D_MLP_CASE(3) M2D_MLP_CASE(5) M2D_MLP_CASE(10) M2D_MLP_CASE(20)
+#undef M2D_MLP_CASE
+        h->last_kernel = "m2d_mlp_mfma";
+    } else {
+        const size_t lds = (size_t)4 * (a.K + a.H1 + a.H2) * sizeof(float);
+        if (lds > 160 * 1024) {
+            h->last_error = "m2d_score_pairs_mlp: K + H1 + H2 too large for the generic kernel";
+            return M2D_ERR_UNSUPPORTED;
+        }
+        int64_t blocks = (B + 3) / 4;
+        if (blocks > (int64_t)h->num_cu * 4) blocks = (int64_t)h->num_cu * 4;
+        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_mlp_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(m2d_mlp_generic, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+        h->last_kernel = "m2d_mlp_generic";
+    }
+    M2D_HIP_TRY(h, hipGetLastError());
+    return M2D_OK;
+}

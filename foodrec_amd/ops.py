@@ -122,6 +122,33 @@ class ScoringEngine:
         _native.raise_for(rc, self._h)
         return out
 
+    def set_mlp_head(self, W1, b1, W2, b2, w3, b3: float):
+        """Build-defined extension: score = reference + w3.relu(W2^T relu(W1^T z + b1) + b2) + b3."""
+        K = (self.C + 1) * self.E
+        t = [_dev_f32(x, self.device) for x in (W1, b1, W2, b2, w3)]
+        H1, H2 = t[0].shape[1], t[2].shape[1]
+        if tuple(t[0].shape) != (K, H1) or tuple(t[2].shape) != (H1, H2) or t[1].numel() != H1 or t[3].numel() != H2 or t[4].numel() != H2:
+            raise ValueError("MLP head shapes: W1 [K=%d, H1], b1 [H1], W2 [H1, H2], b2 [H2], w3 [H2]" % K)
+        rc = _native.lib().m2d_set_mlp_head(self._h, *(x.data_ptr() for x in t), float(b3), H1, H2, _native.M2D_TABLES_DEVICE)
+        _native.raise_for(rc, self._h)
+        self._mlp = t
+
+    def clear_mlp_head(self):
+        _native.raise_for(_native.lib().m2d_clear_mlp_head(self._h), self._h)
+        self._mlp = None
+
+    def score_pairs_mlp(self, users: torch.Tensor, items: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Extension: reference score + MLP head, masks from the resident dish table."""
+        self._check_ids(users, items)
+        B = users.numel()
+        users, items = users.contiguous(), items.contiguous()
+        if out is None:
+            out = torch.empty(B, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = _native.lib().m2d_score_pairs_mlp(self._h, users.data_ptr(), items.data_ptr(), B, out.data_ptr(), _stream_ptr())
+        _native.raise_for(rc, self._h)
+        return out
+
     def set_option(self, name: str, value: int):
         _native.raise_for(_native.lib().m2d_set_option(self._h, name.encode(), int(value)), self._h)
 

@@ -112,6 +112,19 @@ int m2d_clear_ingredients(m2d_engine *h);
 int m2d_score_pairs_ingredients(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
                                 int64_t B, float *out, void *stream);
 
+/* ---- build-defined extension, NO reference counterpart (BASELINE.json configs[2]) ----
+ * 3-layer scoring head on the interaction vector z[k] = flatten(PM[u])[k] * Dt[d][k], k < K = (C+1)*E
+ * (sum_k z[k] is the reference score, Model_Recommender.py:67-96 in factored form):
+ *     score = sum_k z[k] + w3 . relu(W2^T relu(W1^T z + b1) + b2) + b3
+ * W1 f32[K, H1], b1 f32[H1], W2 f32[H1, H2], b2 f32[H2], w3 f32[H2].  H1 = 256, H2 = 64 with K % 64 == 0
+ * run on the exact-f32 MFMA kernel; other sizes run a generic kernel.  Dish masks must be resident
+ * (m2d_set_dish_categories); the ingredient table, when set, feeds Dt's high-level part. */
+int m2d_set_mlp_head(m2d_engine *h, const float *W1, const float *b1, const float *W2, const float *b2,
+                     const float *w3, float b3, int32_t H1, int32_t H2, int table_flags);
+int m2d_clear_mlp_head(m2d_engine *h);
+int m2d_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_t *items, int64_t B, float *out,
+                        void *stream);
+
 /* Synchronise `stream` and report (then clear) the first id error latched by kernels since the
  * previous check: M2D_OK, M2D_ERR_BAD_USER_ID or M2D_ERR_BAD_ITEM_ID.  TF-CPU GatherV2 raises
  * InvalidArgument for such ids; the kernels never read out of bounds and write NaN for the pair.

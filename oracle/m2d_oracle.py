@@ -194,6 +194,25 @@ def inference_ingredients(PM, RE, ING, offsets, ids, weights, users, items, cate
         return dtype(a32) * high + dtype(b32) * low
 
 
+def inference_mlp(PM, RE, CE, dish_categories, W1, b1, W2, b2, w3, b3, users, items,
+                  coef: float = DEFAULT_COEF, dtype=np.float64, dish_high=None) -> np.ndarray:
+    """Build-defined 3-layer head (DESIGN.md section 8): z = flatten(PM[u]) * Dt[d];
+    score = sum(z) + w3 . relu(W2^T relu(W1^T z + b1) + b2) + b3.  `dish_high` [I, E] replaces the
+    category high-level vector when the ingredient extension is active."""
+    PMd = np.asarray(PM, dtype=dtype)
+    Dt = dish_vectors(RE, CE, dish_categories, coef, dtype)
+    if dish_high is not None:
+        E = PMd.shape[2]
+        Dt[:, :E] = dtype(blend_coefficients(coef)[0]) * np.asarray(dish_high, dtype=dtype)
+    users = _as_ids(users, PMd.shape[0], "user")
+    items = _as_ids(items, Dt.shape[0], "item")
+    with np.errstate(invalid="ignore"):
+        z = PMd[users].reshape(len(users), -1) * Dt[items]
+        h1 = np.maximum(z @ np.asarray(W1, dtype=dtype) + np.asarray(b1, dtype=dtype), 0)
+        h2 = np.maximum(h1 @ np.asarray(W2, dtype=dtype) + np.asarray(b2, dtype=dtype), 0)
+        return z.sum(axis=1) + (h2 @ np.asarray(w3, dtype=dtype) + dtype(b3))
+
+
 # ----------------------------------------------------------------------------------------------
 # Evaluator (evaluate.py)
 # ----------------------------------------------------------------------------------------------

@@ -1,0 +1,94 @@
+"""GPU parity of the build-defined 3-layer scoring head (m2d_set_mlp_head / m2d_score_pairs_mlp) against
+the build's own float64 restatement.  The reference has no MLP: this pins only
+the documented extension and its reduction to the reference score when the head contributes nothing."""
+import numpy as np
+import pytest
+
+from helpers import assert_scores_close, random_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _head(K, H1, H2, rng, scale=1.0):
+    W1 = (rng.standard_normal((K, H1)) * scale / np.sqrt(K)).astype(np.float32)
+    b1 = (rng.standard_normal(H1) * 0.1).astype(np.float32)
+    W2 = (rng.standard_normal((H1, H2)) * scale / np.sqrt(H1)).astype(np.float32)
+    b2 = (rng.standard_normal(H2) * 0.1).astype(np.float32)
+    w3 = (rng.standard_normal(H2) * scale / np.sqrt(H2)).astype(np.float32)
+    return W1, b1, W2, b2, w3, 0.25
+
+
+@pytest.mark.parametrize("E,C,H1,H2,kernel", [(128, 4, 256, 64, "m2d_mlp_mfma"), (64, 4, 256, 64, "m2d_mlp_mfma"),
+                                              (256, 4, 256, 64, "m2d_mlp_mfma"), (32, 5, 256, 64, "m2d_mlp_mfma"),
+                                              (200, 4, 256, 64, "m2d_mlp_generic"), (64, 4, 128, 32, "m2d_mlp_generic"),
+                                              (6, 3, 10, 7, "m2d_mlp_generic")])
+@pytest.mark.parametrize("B", [1, 255, 256, 257, 3000])
+def test_mlp_scores_match_restatement(E, C, H1, H2, kernel, B):
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    U, I = 300, 200
+    PM, RE, CE, users, items, _ = random_case(U, I, C, E, B, seed=E + B)
+    rng = np.random.default_rng(E + H1)
+    dish_cats = rng.integers(0, 2, (I, C)).astype(np.float32)
+    dish_cats[dish_cats.sum(1) == 0, 0] = 1
+    dish_cats[3] = 0                                      # NaN dish
+    K = (C + 1) * E
+    head = _head(K, H1, H2, rng, scale=4.0)              # large enough that the head matters
+    eng = ScoringEngine(PM, RE, CE)
+    ut, it = torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda")
+    with pytest.raises(ValueError):
+        eng.score_pairs_mlp(ut, it)
+    eng.set_dish_categories(dish_cats)
+    eng.set_mlp_head(*head)
+    got = eng.score_pairs_mlp(ut, it); eng.check()
+    assert eng.last_kernel() == kernel
+    ref = oracle.inference_mlp(PM, RE, CE, dish_cats, *head, users, items)
+    base = oracle.inference_f64(PM, RE, CE, users, items, dish_cats[items])
+    ok = ~np.isnan(ref)
+    if ok.sum() > 10:
+        assert np.abs(ref[ok] - base[ok]).mean() > 1e-2, "head too small to be tested"
+    assert_scores_close(got.cpu().numpy(), ref, what="E%d B%d" % (E, B))
+
+
+def test_mlp_reduces_to_reference_and_reports_bad_ids():
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    U, I, C, E, B = 200, 100, 4, 128, 2000
+    PM, RE, CE, users, items, _ = random_case(U, I, C, E, B, seed=1)
+    dish_cats = np.random.default_rng(3).integers(0, 2, (I, C)).astype(np.float32)
+    dish_cats[dish_cats.sum(1) == 0, 2] = 1
+    rng = np.random.default_rng(2)
+    W1, b1, W2, b2, w3, b3 = _head((C + 1) * E, 256, 64, rng)
+    eng = ScoringEngine(PM, RE, CE); eng.set_dish_categories(dish_cats)
+    eng.set_mlp_head(W1, b1, W2, b2, np.zeros_like(w3), 0.0)          # head contributes exactly 0
+    ut, it = torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda")
+    got = eng.score_pairs_mlp(ut, it).cpu().numpy(); eng.check()
+    assert_scores_close(got, oracle.inference_f64(PM, RE, CE, users, items, dish_cats[items]), 1e-5, "zero head")
+    assert_scores_close(got, eng.score_pairs_bydish(ut, it).cpu().numpy(), 1e-5, "vs reference kernel")
+    bad = users.copy(); bad[77] = U
+    with pytest.raises(IndexError, match="user id %d at position 77" % U):
+        eng.score_pairs_mlp(torch.as_tensor(bad, device="cuda"), it); eng.check()
+    eng.clear_mlp_head()
+    with pytest.raises(ValueError):
+        eng.score_pairs_mlp(ut, it)
+
+
+def test_mlp_with_ingredient_table():
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    U, I, C, E, R, B = 100, 80, 4, 64, 50, 1000
+    PM, RE, CE, users, items, _ = random_case(U, I, C, E, B, seed=9)
+    rng = np.random.default_rng(5)
+    dish_cats = np.ones((I, C), np.float32)
+    ING = (rng.standard_normal((R, E)) / 8).astype(np.float32)
+    lens = rng.integers(1, 12, I); off = np.zeros(I + 1, np.int32); off[1:] = np.cumsum(lens)
+    ids = rng.integers(0, R, off[-1]).astype(np.int32)
+    head = _head((C + 1) * E, 256, 64, rng, scale=3.0)
+    eng = ScoringEngine(PM, RE, CE); eng.set_dish_categories(dish_cats)
+    eng.set_ingredients(ING, off, ids); eng.set_mlp_head(*head)
+    got = eng.score_pairs_mlp(torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda")); eng.check()
+    H = oracle.dish_high_vectors(ING, off, ids)
+    assert_scores_close(got.cpu().numpy(), oracle.inference_mlp(PM, RE, CE, dish_cats, *head, users, items, dish_high=H))
