@@ -44,6 +44,9 @@ def parse():
     p.add_argument("--dishes", type=int, default=100_000)
     p.add_argument("--embed", type=int, default=64)
     p.add_argument("--pairs", type=int, default=1 << 22, help="pairs per step per GPU")
+    p.add_argument("--workload", choices=["pairs", "mlp"], default="pairs",
+                   help="pairs = BASELINE configs[1] (reference forward, HBM-bound); mlp = configs[2] "
+                        "(E=128 + build-defined 3-layer head, MFMA-bound; pass --embed 128)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     p.add_argument("--topk-users", type=int, default=65536, help="users in the catalogue top-k side leg (0 = skip)")
@@ -69,14 +72,17 @@ def make_inputs(torch, dev, U, I, C, E, B, seed, user_base):
     return PM, RE, CE, users, items, cats.contiguous()
 
 
-def time_steps(torch, eng, users, items, cats, out, steps):
+def time_steps(torch, eng, users, items, cats, out, steps, mlp=False):
     """K launches; per-launch HIP-event durations (ms) on the current stream + wall seconds."""
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     evs[0].record()
     for i in range(steps):
-        eng.score_pairs(users, items, cats, out=out)
+        if mlp:
+            eng.score_pairs_mlp(users, items, out=out)
+        else:
+            eng.score_pairs(users, items, cats, out=out)
         evs[i + 1].record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -253,6 +259,14 @@ def main():
         k, v = kv.split("=")
         eng.set_option(k, int(v))
     out = torch.empty(B, dtype=torch.float32, device=dev)
+    mlp = a.workload == "mlp"
+    if mlp:
+        g = torch.Generator(device=dev); g.manual_seed(20260101 + 3)
+        K = (C + 1) * E
+        pat = torch.randint(1, 2 ** C, (I,), generator=g, device=dev, dtype=torch.int32)
+        eng.set_dish_categories(((pat[:, None] >> torch.arange(C, device=dev, dtype=torch.int32)[None, :]) & 1).float())
+        rn = lambda *shape: torch.randn(shape, generator=g, device=dev)
+        eng.set_mlp_head(rn(K, 256) / K ** 0.5, rn(256) * 0.1, rn(256, 64) / 16.0, rn(64) * 0.1, rn(64) / 8.0, 0.0)
 
     def barrier():
         torch.cuda.synchronize()
@@ -261,10 +275,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        eng.score_pairs(users, items, cats, out=out)
+        if mlp:
+            eng.score_pairs_mlp(users, items, out=out)
+        else:
+            eng.score_pairs(users, items, cats, out=out)
     eng.check()
     barrier()
-    wall, per_launch_ms = time_steps(torch, eng, users, items, cats, out, a.steps)
+    wall, per_launch_ms = time_steps(torch, eng, users, items, cats, out, a.steps, mlp)
     barrier()
     eng.check()
     t = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -323,18 +340,30 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel_avg_ms": avg_ms, "algorithmic_bytes_per_pair": bpp, "pairs_per_launch": B},
         }
-        if not a.no_side:
+        if mlp:
+            K = (C + 1) * E
+            fl = 2.0 * (K * 256 + 256 * 64 + 64)
+            tf = fl * B / (avg_ms * 1e-3) / 1e12
+            line["config"]["workload"] = ("BASELINE configs[2]: synthetic %d users x %d dishes per GPU, C=%d, E=%d + "
+                                          "BUILD-DEFINED 3-layer head %d->256->64->1 on the interaction vector (no "
+                                          "reference counterpart; parity vs the build's own restatement only); "
+                                          "uniform random pairs, masks from the resident dish table" % (U, I, C, E, K))
+            line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                                "traffic": None, "kernel_avg_ms": avg_ms, "flop_per_pair": fl, "pairs_per_launch": B,
+                                "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact)",
+                                "hbm_algorithmic_GBps": (2 * K * 4 + 12) * B / (avg_ms * 1e-3) / 1e9}
+        if not a.no_side and not mlp:
             nr, probe = side_measurements(torch, eng, PM, U, I, C, E, dev, user_base)
             line["roofline"]["no_reuse"] = nr
             line["roofline"]["stream_read_probe"] = probe
             line["roofline"]["frac_of_stream_probe"] = achieved / probe["GBps"]
-        if a.topk_users > 0 and not a.no_side:
+        if a.topk_users > 0 and not a.no_side and not mlp:
             line["catalogue_topk"] = catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U))
         if topk_ag is not None:
             line["sharded_topk_allgather"] = topk_ag
         if a.unique_users:
             line["config"]["workload"] += " [--unique-users: every user at most once per step]"
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not mlp:
             cb, ref, Bc = cpu_baseline(torch, PM, RE, CE, users, items, cats, a.cpu_seconds)
             # the baseline doubles as a live parity check of the timed kernel's output on the same pairs
             got = out[:Bc].cpu()
