@@ -76,7 +76,10 @@ __device__ __forceinline__ bool ahead(float v, float w)
 }
 
 // NB = K / 8: float4 registers of the user operand per lane.  One stage = 32 dishes x KC floats.
-template <int NB, int WAVES>
+// KR > 0: the lane's running list (KR >= k slots) lives in REGISTERS and an insertion is a branch-free
+// compare-exchange sweep (about 8*KR VALU ops, no LDS latency chain), so every wave reaches the
+// per-stage barrier at nearly the same time; KR == 0 keeps the list in LDS (k up to 64).
+template <int NB, int WAVES, int KR>
 __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
 {
     constexpr int KP = NB * 8;                   // K
@@ -94,8 +97,16 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int k = p.k;
-    float *ls = lists + (size_t)wave * 2 * k * 64;
-    int32_t *li = reinterpret_cast<int32_t *>(ls + (size_t)k * 64);
+    const int kl = KR > 0 ? KR : k;             // list slots per lane in the LDS image
+    float *ls = lists + (size_t)wave * 2 * kl * 64;
+    int32_t *li = reinterpret_cast<int32_t *>(ls + (size_t)kl * 64);
+    float rs[KR > 0 ? KR : 1];                  // register-resident list (KR > 0)
+    int32_t ri[KR > 0 ? KR : 1];
+#pragma unroll
+    for (int i = 0; i < (KR > 0 ? KR : 1); ++i) {
+        rs[i] = 0.f;
+        ri[i] = -1;
+    }
 
     // ---- this wave's 32 users -> B operand registers -------------------------------------------
     const int64_t utile = (int64_t)blockIdx.x * WAVES + wave;
@@ -179,14 +190,35 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
             float mx = acc[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-            const bool maybe = (cnt < k) || !(mx <= thr);
+            const bool maybe = (cnt < kl) || !(mx <= thr);
             if (__any(maybe)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = acc[r];
                     const int64_t dish = base + (r & 3) + 8 * (r >> 2);
-                    const bool cand = dish < p.I && ((cnt < k) || ahead(v, thr));
-                    if (cand) {
+                    const bool cand = dish < p.I && ((cnt < kl) || ahead(v, thr));
+                    if constexpr (KR > 0) {
+                        if (__any(cand)) {
+                            // sweep: the carried element drops into the first slot it beats (or the first
+                            // empty slot); from there on everything shifts down one slot.  Stable for ties.
+                            float xs = v;
+                            int32_t xi = (int32_t)dish;
+                            bool placed = false;
+#pragma unroll
+                            for (int i = 0; i < KR; ++i) {
+                                const bool sw = cand && (placed || (i >= cnt) || ahead(xs, rs[i]));
+                                placed = placed || sw;
+                                const float ts = rs[i];
+                                const int32_t ti = ri[i];
+                                rs[i] = sw ? xs : ts;
+                                ri[i] = sw ? xi : ti;
+                                xs = sw ? ts : xs;
+                                xi = sw ? ti : xi;
+                            }
+                            cnt += (cand && cnt < KR) ? 1 : 0;
+                            if (cnt == KR) thr = rs[KR - 1];
+                        }
+                    } else if (cand) {
                         int pos = cnt < k ? cnt : k - 1;
                         while (pos > 0) {
                             const float w = ls[(pos - 1) * 64 + lane];
@@ -205,6 +237,16 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    }
+
+    if constexpr (KR > 0) {   // publish the register lists so the partner lane can be merged in
+#pragma unroll
+        for (int i = 0; i < KR; ++i) {
+            ls[i * 64 + lane] = rs[i];
+            li[i * 64 + lane] = ri[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 
     // ---- merge the two lanes of each user, write this split's sorted list ------------------------
@@ -355,11 +397,12 @@ int m2d_ensure_dish_vectors(m2d_engine *h, hipStream_t st)
 
 namespace {
 
-template <int NB, int WAVES>
+template <int NB, int WAVES, int KR>
 int launch_mfma(m2d_engine *h, TopkArgs &a, float *final_s, int32_t *final_i, hipStream_t st)
 {
     constexpr int KC8 = NB < 40 ? NB : 40;
-    const size_t lds = (size_t)2 * 32 * (KC8 * 2) * 4 * sizeof(float) + (size_t)WAVES * 2 * a.k * 64 * sizeof(float);
+    const int kl = KR > 0 ? KR : a.k;
+    const size_t lds = (size_t)2 * 32 * (KC8 * 2) * 4 * sizeof(float) + (size_t)WAVES * 2 * kl * 64 * sizeof(float);
     const int64_t ublocks = (a.nU + 32 * WAVES - 1) / (32 * WAVES);
     // split the dish range when there are too few user blocks to fill the chip
     int nsplit = 1;
@@ -391,7 +434,7 @@ int launch_mfma(m2d_engine *h, TopkArgs &a, float *final_s, int32_t *final_i, hi
         a.out_scores = final_s;
         a.out_ids = final_i;
     }
-    auto kern = m2d_topk_mfma<NB, WAVES>;
+    auto kern = m2d_topk_mfma<NB, WAVES, KR>;
     M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(WAVES * 64), lds, st, a);
     M2D_HIP_TRY(h, hipGetLastError());
@@ -420,9 +463,16 @@ int m2d_launch_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32
     if (!force_generic && K % 8 == 0) {
         const int NB = K / 8;
         // list space: 8 waves up to k = 16, 2 waves beyond (LDS: 2 stages + waves * k * 512 B)
-        if (NB == 20) return k <= 16 ? launch_mfma<20, 8>(h, a, out_scores, out_ids, stream) : launch_mfma<20, 2>(h, a, out_scores, out_ids, stream);
-        if (NB == 40) return k <= 16 ? launch_mfma<40, 8>(h, a, out_scores, out_ids, stream) : launch_mfma<40, 2>(h, a, out_scores, out_ids, stream);
-        if (NB == 80) return k <= 16 ? launch_mfma<80, 4>(h, a, out_scores, out_ids, stream) : launch_mfma<80, 2>(h, a, out_scores, out_ids, stream);
+        // k <= 16: register-resident lists (10 or 16 slots); beyond: LDS lists, 2 waves (LDS: 2 stages + waves*k*512 B)
+        const bool lds_lists = k > 16 || h->opt_variant == 8;
+#define M2D_TOPK(NBV, WV)                                                                              \
+    if (NB == NBV) {                                                                                  \
+        if (lds_lists) return launch_mfma<NBV, 2, 0>(h, a, out_scores, out_ids, stream);               \
+        return k <= 10 ? launch_mfma<NBV, WV, 10>(h, a, out_scores, out_ids, stream)                   \
+                       : launch_mfma<NBV, WV, 16>(h, a, out_scores, out_ids, stream);                  \
+    }
+        M2D_TOPK(20, 8) M2D_TOPK(40, 8) M2D_TOPK(80, 4)
+#undef M2D_TOPK
     }
     const size_t lds = (size_t)4 * 2 * k * sizeof(float);
     hipLaunchKernelGGL(m2d_topk_generic, dim3((unsigned)nU), dim3(256), lds, stream, a, K);
