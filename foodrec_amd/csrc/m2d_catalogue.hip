@@ -20,6 +20,13 @@
 
 #include "m2d_engine.h"
 
+// Timing-only ablation hooks for scripts/diag/topk_diag.cpp (never defined in the product build):
+// bit 0 = no epilogue, bit 1 = no LDS-DMA refill, bit 2 = no per-stage barrier/wait, bit 3 = epilogue
+// fast path only (no insertions).  Outputs are wrong.
+#ifndef M2D_DIAG
+#define M2D_DIAG 0
+#endif
+
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
 
     for (int64_t s = 0; s < nstages; ++s) {
         const int buf = (int)(s & 1);
-        if (s + 1 < nstages) issue_stage(s + 1, buf ^ 1);
+        if (!(M2D_DIAG & 2) && s + 1 < nstages) issue_stage(s + 1, buf ^ 1);
         const int c = (int)(s % NKC);
         if (c == 0) {
 #pragma unroll
@@ -184,40 +191,25 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
                 }
             }
         }
-        if (c == NKC - 1) {
+        if (M2D_DIAG & 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[r]));
+        } else if (c == NKC - 1) {
             // ---- epilogue: lane holds user j, dishes base + (r&3) + 8*(r>>2) + 4*h, ascending in r
             const int64_t base = (t_begin + s / NKC) * 32 + 4 * h;
             float mx = acc[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
             const bool maybe = (cnt < kl) || !(mx <= thr);
-            if (__any(maybe)) {
+            if ((M2D_DIAG & 8) ? (mx == 12345.678f) : __any(maybe)) {   // bit 3: fast path only
+                unsigned cmask = 0;   // KR > 0: which of this lane's 16 scores pass its (current) threshold
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = acc[r];
                     const int64_t dish = base + (r & 3) + 8 * (r >> 2);
                     const bool cand = dish < p.I && ((cnt < kl) || ahead(v, thr));
                     if constexpr (KR > 0) {
-                        if (__any(cand)) {
-                            // sweep: the carried element drops into the first slot it beats (or the first
-                            // empty slot); from there on everything shifts down one slot.  Stable for ties.
-                            float xs = v;
-                            int32_t xi = (int32_t)dish;
-                            bool placed = false;
-#pragma unroll
-                            for (int i = 0; i < KR; ++i) {
-                                const bool sw = cand && (placed || (i >= cnt) || ahead(xs, rs[i]));
-                                placed = placed || sw;
-                                const float ts = rs[i];
-                                const int32_t ti = ri[i];
-                                rs[i] = sw ? xs : ts;
-                                ri[i] = sw ? xi : ti;
-                                xs = sw ? ts : xs;
-                                xi = sw ? ti : xi;
-                            }
-                            cnt += (cand && cnt < KR) ? 1 : 0;
-                            if (cnt == KR) thr = rs[KR - 1];
-                        }
+                        cmask |= cand ? (1u << r) : 0u;
                     } else if (cand) {
                         int pos = cnt < k ? cnt : k - 1;
                         while (pos > 0) {
@@ -233,10 +225,43 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
                         if (cnt == k) thr = ls[(k - 1) * 64 + lane];
                     }
                 }
+                if constexpr (KR > 0) {
+                    // Rolled insertion loop (small code: the unrolled form was ~40 KB and thrashed the
+                    // instruction cache).  Each pass every lane with candidates left inserts its lowest-r
+                    // one -- ascending dish id, so ties stay stable -- re-checked against the threshold
+                    // its previous insertions may have raised.
+                    while (__any(cmask != 0u)) {
+                        const bool has = cmask != 0u;
+                        const int r = has ? (__ffs((int)cmask) - 1) : 0;
+                        cmask &= cmask - 1u;
+                        float v = acc[0];
+#pragma unroll
+                        for (int q = 1; q < 16; ++q) v = (r == q) ? acc[q] : v;
+                        const bool cand = has && ((cnt < KR) || ahead(v, thr));
+                        float xs = v;
+                        int32_t xi = (int32_t)(base + (r & 3) + 8 * (r >> 2));
+                        bool placed = false;   // once placed, everything below shifts down one slot
+#pragma unroll
+                        for (int i = 0; i < KR; ++i) {
+                            const bool sw = cand && (placed || (i >= cnt) || ahead(xs, rs[i]));
+                            placed = placed || sw;
+                            const float ts = rs[i];
+                            const int32_t ti = ri[i];
+                            rs[i] = sw ? xs : ts;
+                            ri[i] = sw ? xi : ti;
+                            xs = sw ? ts : xs;
+                            xi = sw ? ti : xi;
+                        }
+                        cnt += (cand && cnt < KR) ? 1 : 0;
+                        if (cnt == KR) thr = rs[KR - 1];
+                    }
+                }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!(M2D_DIAG & 4)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
     }
 
     if constexpr (KR > 0) {   // publish the register lists so the partner lane can be merged in

@@ -1,0 +1,8 @@
+#!/bin/bash
+# Run ON THE GPU BOX.  Builds and times the ablation variants of the catalogue top-k kernel.
+set -e
+mkdir -p gpurun_out/diag
+for M in ${MASKS:-0 1 8}; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-fast-math -DM2D_DIAG=$M scripts/diag/topk_diag.cpp -o gpurun_out/diag/topk_diag_$M 2> gpurun_out/diag/build_$M.log
+  timeout -k 5 60 gpurun_out/diag/topk_diag_$M
+done
