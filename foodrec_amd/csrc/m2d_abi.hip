@@ -312,6 +312,19 @@ int m2d_score_pairs_ingredients(m2d_engine *h, const int32_t *users, const int32
                                   (hipStream_t)stream, /*use_ingredients=*/true);
 }
 
+int m2d_write_memory(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
+                     const float *write_sign, const float *labels, int64_t B, int32_t L, float *general_memory,
+                     float beta_1, float beta_2, float alpha, double *out_sums, void *stream)
+{
+    if (!h) return M2D_ERR_INVALID_ARG;
+    if (B < 0 || L <= 0) return fail(h, M2D_ERR_INVALID_ARG, "m2d_write_memory: need B >= 0 and L > 0");
+    if (!general_memory || (B > 0 && (!users || !items || !cats || !write_sign || !labels)))
+        return fail(h, M2D_ERR_INVALID_ARG, "m2d_write_memory: null buffer");
+    M2D_HIP_TRY(h, hipSetDevice(h->device));
+    return m2d_launch_write_memory(h, users, items, cats, write_sign, labels, B, L, general_memory, beta_1, beta_2,
+                                   alpha, out_sums, (hipStream_t)stream);
+}
+
 int m2d_clear_mlp_head(m2d_engine *h)
 {
     if (!h) return M2D_ERR_INVALID_ARG;

@@ -77,6 +77,9 @@ int m2d_launch_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *i
 int m2d_launch_build_dish_high(m2d_engine *h, hipStream_t stream);
 int m2d_launch_check_csr(m2d_engine *h, hipStream_t stream);
 int m2d_ensure_dish_vectors(m2d_engine *h, hipStream_t stream);
+int m2d_launch_write_memory(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
+                            const float *sign, const float *labels, int64_t B, int32_t L, float *gm, float beta_1,
+                            float beta_2, float alpha, double *out_sums, hipStream_t stream);
 int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_t *items, int64_t B, float *out,
                                hipStream_t stream);
 int m2d_launch_rank_candidates(m2d_engine *h, const int32_t *users, const int32_t *items,

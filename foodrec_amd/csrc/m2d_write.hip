@@ -1,0 +1,144 @@
+// Memory write (training side): Model.Write_Memory, Model_Recommender.py:106-220, as a scatter-add.
+//
+// The reference scatters through dense one-hot batched matmuls -- one_hot(user, num_users) [B, U, 1] times
+// a [B, 1, (C+1)E] row (:151-158, :190, :201, :207) -- O(B * U * (C+1) * E) work and memory, which is why
+// its driver feeds this branch 8 pairs at a time (Train_recommender.py:170-186).  Semantically it is
+//
+//   n_b   = sum_c m_bc                                                          :130
+//   v_b   = [ beta_2 s_b (sum_c m_bc CE_c) / n_b ;  beta_1 s_b m_bc RE[d_b] , c = 0..C-1 ]   :108-147, :160
+//   g_b   = (sum_l y_bl GM[l]) / (sum_l y_bl)          (GM = General_Memory before this call)  :166-184
+//   PM[u] += sum_{b: u_b = u} ( v_b + alpha * g_b )                                            :162, :186-198
+//   GM[l] += sum_b y_bl v_b                                                                    :200-215
+//
+// with s = write_sign, y = user_one_hot_label, m = categories.  Here it is O(B * (C+1) * E): one wave per
+// pair adds its row into PM[u_b] (and into every GM[l] with y_bl != 0) with float atomics, 256 contiguous
+// bytes per wave-instruction (the shape MI355X's memory-side atomics run fastest at).  Duplicate users in
+// a batch accumulate, as reduce_sum(..., 0) does.  Sums are order-dependent in the last bits.
+//
+// Two launches keep the reference's data flow: every g_b reads General_Memory as it was before the call,
+// so the PM pass (which reads GM) completes before the GM pass writes it.
+#include "m2d_engine.h"
+
+namespace {
+
+struct WriteArgs {
+    float *pm;           // [U, C+1, E]  (written)
+    const float *re;     // [I, E]
+    const float *ce;     // [C, E]
+    float *gm;           // [L, C+1, E]  (read by pass 0, written by pass 1)
+    const int32_t *users;
+    const int32_t *items;
+    const float *cats;   // [B, C]
+    const float *sign;   // [B]
+    const float *labels; // [B, L]
+    int64_t B, U, I, user_base;
+    int32_t C, E, L;
+    float beta_1, beta_2, alpha;
+    int32_t *err;
+};
+
+__device__ __forceinline__ void latch(int32_t *err, int code, int64_t value, int64_t index)
+{
+    if (atomicCAS(&err[0], 0, code) == 0) {
+        err[1] = (int32_t)value;
+        err[2] = (int32_t)(index & 0xffffffff);
+        err[3] = (int32_t)(index >> 32);
+    }
+}
+
+// PASS 0: PM[u_b] += v_b + alpha g_b.   PASS 1: GM[l] += y_bl v_b.
+template <int PASS>
+__global__ __launch_bounds__(256) void m2d_write_memory_kernel(WriteArgs p)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int C = p.C, E = p.E, L = p.L;
+    for (int64_t b = wave0; b < p.B; b += nwaves) {
+        const int32_t uid = p.users[b], did = p.items[b];
+        const int64_t ul = (int64_t)uid - p.user_base;
+        if (ul < 0 || ul >= p.U) {
+            if (PASS == 0 && lane == 0) latch(p.err, M2D_ERR_BAD_USER_ID, uid, b);
+            continue;   // wave-uniform: nothing is written for a bad pair
+        }
+        if (did < 0 || (int64_t)did >= p.I) {
+            if (PASS == 0 && lane == 0) latch(p.err, M2D_ERR_BAD_ITEM_ID, did, b);
+            continue;
+        }
+        const float s = p.sign[b];
+        const float *m = p.cats + (size_t)b * C;
+        const float *y = p.labels + (size_t)b * L;
+        float n = 0.f;
+        for (int c = 0; c < C; ++c) n += m[c];                               // :130
+        float ysum = 0.f;
+        if (PASS == 0)
+            for (int l = 0; l < L; ++l) ysum += y[l];                        // :180
+        const float lo = p.beta_1 * s, hi = p.beta_2 * s;                    // :115, :141
+        for (int r = 0; r <= C; ++r) {
+            for (int e = lane; e < E; e += 64) {
+                float v;
+                if (r == 0) {
+                    float dc = 0.f;
+                    for (int c = 0; c < C; ++c) dc += m[c] * p.ce[(size_t)c * E + e];   // :124-128
+                    v = (dc / n) * hi;                                       // :134, :145
+                } else {
+                    v = (m[r - 1] * p.re[(size_t)did * E + e]) * lo;         // :111, :119
+                }
+                const size_t k = (size_t)r * E + e;
+                if (PASS == 0) {
+                    float g = 0.f;
+                    for (int l = 0; l < L; ++l) {
+                        const float w = y[l];
+                        if (w != 0.f) g = fmaf(w, p.gm[(size_t)l * (C + 1) * E + k], g);   // :172-176
+                    }
+                    atomicAdd(p.pm + (size_t)ul * (C + 1) * E + k, v + p.alpha * (g / ysum));   // :162, :184-198
+                } else {
+                    for (int l = 0; l < L; ++l) {
+                        const float w = y[l];
+                        if (w != 0.f) atomicAdd(p.gm + (size_t)l * (C + 1) * E + k, w * v);      // :200-215
+                    }
+                }
+            }
+        }
+    }
+}
+
+// sum of n floats into acc[0] (double), for the `personal` / `general` fetches (reduce_mean, :217-218)
+__global__ __launch_bounds__(256) void m2d_sum_kernel(const float *x, int64_t n, double *acc)
+{
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) s += x[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(acc, s);
+}
+
+}  // namespace
+
+int m2d_launch_write_memory(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
+                            const float *sign, const float *labels, int64_t B, int32_t L, float *gm, float beta_1,
+                            float beta_2, float alpha, double *out_sums, hipStream_t stream)
+{
+    WriteArgs a;
+    a.pm = const_cast<float *>(h->pm); a.re = h->re; a.ce = h->ce; a.gm = gm;
+    a.users = users; a.items = items; a.cats = cats; a.sign = sign; a.labels = labels;
+    a.B = B; a.U = h->U; a.I = h->I; a.user_base = h->user_base; a.C = h->C; a.E = h->E; a.L = L;
+    a.beta_1 = beta_1; a.beta_2 = beta_2; a.alpha = alpha; a.err = h->err_dev;
+    if (B > 0) {
+        int64_t blocks = (B + 3) / 4;
+        if (blocks > (int64_t)h->num_cu * 8) blocks = (int64_t)h->num_cu * 8;
+        hipLaunchKernelGGL(m2d_write_memory_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        M2D_HIP_TRY(h, hipGetLastError());
+        hipLaunchKernelGGL(m2d_write_memory_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+        M2D_HIP_TRY(h, hipGetLastError());
+    }
+    if (out_sums) {
+        M2D_HIP_TRY(h, hipMemsetAsync(out_sums, 0, 2 * sizeof(double), stream));
+        hipLaunchKernelGGL(m2d_sum_kernel, dim3((unsigned)(h->num_cu * 4)), dim3(256), 0, stream, h->pm,
+                           (int64_t)h->U * (h->C + 1) * h->E, out_sums);
+        hipLaunchKernelGGL(m2d_sum_kernel, dim3(64), dim3(256), 0, stream, gm, (int64_t)L * (h->C + 1) * h->E,
+                           out_sums + 1);
+        M2D_HIP_TRY(h, hipGetLastError());
+    }
+    return M2D_OK;
+}

@@ -149,6 +149,33 @@ class ScoringEngine:
         _native.raise_for(rc, self._h)
         return out
 
+    def write_memory(self, users: torch.Tensor, items: torch.Tensor, cats: torch.Tensor, write_sign: torch.Tensor,
+                     labels: torch.Tensor, general_memory: torch.Tensor, beta_1: float, beta_2: float, alpha: float,
+                     want_means: bool = False):
+        """Model.Write_Memory (Model_Recommender.py:106-220) as a scatter-add: updates self.pm and
+        `general_memory` ([L, C+1, E], device float32) IN PLACE.  Returns (mean(PM), mean(GM)) when asked."""
+        self._check_ids(users, items)
+        B = users.numel()
+        L = labels.shape[-1]
+        if general_memory.device != self.device or general_memory.dtype != torch.float32 or not general_memory.is_contiguous():
+            raise ValueError("general_memory must be a contiguous float32 tensor on %s" % self.device)
+        if tuple(general_memory.shape) != (L, self.C + 1, self.E):
+            raise ValueError("general_memory must be [L=%d, C+1, E]" % L)
+        f = lambda t, n: t.to(device=self.device, dtype=torch.float32).reshape(B, n).contiguous()
+        cats, write_sign, labels = f(cats, self.C), f(write_sign, 1), f(labels, L)
+        sums = torch.zeros(2, dtype=torch.float64, device=self.device) if want_means else None
+        with torch.cuda.device(self.device):
+            rc = _native.lib().m2d_write_memory(self._h, users.contiguous().data_ptr(), items.contiguous().data_ptr(),
+                                                cats.data_ptr(), write_sign.data_ptr(), labels.data_ptr(), B, L,
+                                                general_memory.data_ptr(), float(beta_1), float(beta_2), float(alpha),
+                                                sums.data_ptr() if want_means else None, _stream_ptr())
+        _native.raise_for(rc, self._h)
+        if want_means:
+            self.check()
+            s = sums.cpu().numpy()
+            return float(s[0] / self.pm.numel()), float(s[1] / general_memory.numel())
+        return None
+
     def set_option(self, name: str, value: int):
         _native.raise_for(_native.lib().m2d_set_option(self._h, name.encode(), int(value)), self._h)
 

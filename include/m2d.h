@@ -93,6 +93,19 @@ int m2d_rank_candidates(m2d_engine *h, const int32_t *users, const int32_t *item
 int m2d_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, float *out_scores,
                    int32_t *out_ids, void *stream);
 
+/* Memory write (training side).  Replaces Model.Write_Memory
+ * (Model_Recommender.py:106-220) -- the `personal` / `general` fetches of Train_recommender.py:180-199 --
+ * with an O(B (C+1) E) atomic scatter-add in place of the reference's dense one-hot matmuls:
+ *     PM[u_b] += v_b + alpha * g_b ;   GM[l] += sum_b y_bl v_b          (v_b, g_b: see csrc/m2d_write.hip)
+ *   users/items i32[B], cats f32[B, C], write_sign f32[B] (the [B, 1] placeholder flattened),
+ *   labels f32[B, L] (user_one_hot_label), general_memory f32[L, C+1, E] (device, updated in place).
+ * Personal_Memory is updated IN PLACE in the buffer given to m2d_create, which must therefore be
+ * writable device memory (M2D_TABLES_DEVICE) or engine-owned (M2D_TABLES_HOST).  out_sums (device
+ * f64[2], may be NULL) receives sum(PM) and sum(GM) after the write (the reference returns their means). */
+int m2d_write_memory(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
+                     const float *write_sign, const float *labels, int64_t B, int32_t L, float *general_memory,
+                     float beta_1, float beta_2, float alpha, double *out_sums, void *stream);
+
 /* ---- build-defined extension, NO reference counterpart (BASELINE.json configs 2-5) ----
  * Multi-hot ingredient table for the high-level path:
  *     H[d]  = sum_j w_j ING[id_j] / sum_j w_j     over dish d's list ids[off[d] .. off[d+1])

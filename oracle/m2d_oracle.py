@@ -151,6 +151,49 @@ def inference_factored(PM, RE, CE, users, items, dish_categories, coef: float = 
 
 
 # ----------------------------------------------------------------------------------------------
+# Memory write (training side) -- Model.Write_Memory, Model_Recommender.py:106-220, op for op including the
+# dense one-hot matmuls (small sizes only).  PARITY UNPINNED (TF arithmetic).  General_Memory is read
+# before it is written: the two PM assigns and the GM assign all consume the pre-call value (:168, :215).
+# ----------------------------------------------------------------------------------------------
+
+def write_memory(PM, RE, CE, GM, users, items, categories, write_sign, user_one_hot_label,
+                 beta_1=0.01, beta_2=0.01, alpha=0.01, dtype=np.float64):
+    """Returns (Personal_Memory', General_Memory', mean(PM'), mean(GM'))."""
+    PM = np.asarray(PM, dtype=dtype); RE = np.asarray(RE, dtype=dtype); CE = np.asarray(CE, dtype=dtype)
+    GM = np.asarray(GM, dtype=dtype)
+    U, C1, E = PM.shape
+    C = C1 - 1
+    users = _as_ids(users, U, "user"); items = _as_ids(items, RE.shape[0], "item")
+    B = len(users)
+    cat = _as_mask(categories, C).astype(dtype)                                   # [B, C, 1]
+    s = np.asarray(write_sign, dtype=dtype).reshape(B, 1)                         # [B, 1]   :30
+    y = np.asarray(user_one_hot_label, dtype=dtype).reshape(B, -1)                # [B, L]   :33
+    with np.errstate(divide="ignore", invalid="ignore"):
+        item_embedding = RE[items][:, None, :]                                    # :107-109
+        dish_memory = cat * item_embedding                                        # :111
+        dish_memory = dish_memory * (beta_1 * s)[:, None, :]                      # :115-119
+        dish_category = (cat * CE).sum(axis=1)                                    # :124-128
+        category_num = cat.sum(axis=(1, 2))[:, None]                              # :130-132
+        dish_category = dish_category / category_num                              # :134
+        dish_category = dish_category[:, None, :] * (beta_2 * s)[:, None, :]      # :138-145
+        dish_memory = dish_memory.reshape(B, 1, C * E)                            # :149
+        onehot = np.zeros((B, U, 1), dtype=dtype); onehot[np.arange(B), users, 0] = 1   # :151
+        dish_bias = (onehot @ dish_memory).sum(axis=0).reshape(U, C, E)           # :154-156
+        category_bias = (onehot @ dish_category).sum(axis=0)[:, None, :]          # :158-162
+        PM1 = PM + np.concatenate([category_bias, dish_bias], axis=1)             # :164-167
+        general_memory = GM.reshape(GM.shape[0], C1 * E)                          # :172
+        ulm = (y[:, :, None] * general_memory).sum(axis=1)                        # :174-178
+        ulm = ulm / y.sum(axis=1)[:, None]                                        # :180-184
+        general_bias = (onehot @ ulm[:, None, :]).sum(axis=0).reshape(U, C1, E)   # :188-192
+        PM2 = PM1 + alpha * general_bias                                          # :194-197
+        ylab = y[:, :, None]                                                      # :169
+        dgb = (ylab @ dish_memory).sum(axis=0).reshape(-1, C, E)                  # :200-205
+        cgb = (ylab @ dish_category).sum(axis=0)[:, None, :]                      # :207-212
+        GM2 = GM + np.concatenate([cgb, dgb], axis=1)                             # :213-215
+    return PM2, GM2, PM2.mean(), GM2.mean()
+
+
+# ----------------------------------------------------------------------------------------------
 # Build-defined extensions (NO reference counterpart; BASELINE.json configs 2-5).  These restate the
 # build's own definitions (DESIGN.md section 8); nothing in the reference pins them.
 # ----------------------------------------------------------------------------------------------

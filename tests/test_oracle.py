@@ -113,3 +113,15 @@ def test_ingredient_extension_reduces_to_reference_in_the_oracle():
     ids = np.tile(np.arange(4), 30)
     ext = oracle.inference_ingredients(PM, RE, CE, off, ids, dish_cats.reshape(-1), users, items, dish_cats[items])
     assert_scores_close(ext, oracle.inference_f64(PM, RE, CE, users, items, dish_cats[items]), 1e-12)
+
+
+def test_write_memory_restatement_by_hand():
+    """One pair, C = 2, E = 1: every term of Model_Recommender.py:106-215 can be followed by hand."""
+    PM = np.zeros((2, 3, 1)); RE = np.array([[2.0]]); CE = np.array([[1.0], [3.0]])
+    GM = np.array([[[10.0], [20.0], [30.0]], [[1.0], [2.0], [3.0]]])
+    PM2, GM2, mp, mg = oracle.write_memory(PM, RE, CE, GM, [1], [0], [[1.0, 1.0]], [1.0], [[1.0, 1.0]],
+                                           beta_1=0.5, beta_2=0.25, alpha=0.1)
+    # v = [0.25*(1+3)/2, 0.5*1*2, 0.5*1*2] = [0.5, 1, 1]; g = mean over both labels = [5.5, 11, 16.5]
+    assert np.allclose(PM2[1, :, 0], [0.5 + 0.55, 1 + 1.1, 1 + 1.65]) and np.all(PM2[0] == 0)
+    assert np.allclose(GM2[:, :, 0], GM[:, :, 0] + [0.5, 1, 1])
+    assert mp == pytest.approx(PM2.mean()) and mg == pytest.approx(GM2.mean())
