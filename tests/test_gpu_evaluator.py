@@ -82,3 +82,31 @@ def test_nan_segments_are_flagged():
                                       torch.as_tensor(items, device="cuda"), 5)
     eng.check()
     assert flags.cpu().numpy().tolist() == [0, 1, 0]
+
+
+def test_config1_plumbing_end_to_end(tmp_path):
+    """BASELINE configs[0] shape: files in the reference's formats at its default sizes (U = 64 657,
+    I = 4 548, C = 4, L = 95; E = 32), loaded by the format readers, model built from the .npy tables,
+    evaluate_model over the test users -- HR/NDCG identical to the oracle's one-call-per-user loop."""
+    import types
+    from foodrec_amd import Model, Session, evaluate_model, formats
+    from oracle import m2d_oracle as oracle
+    base = formats.write_synthetic_split(str(tmp_path), num_users=64657, num_dishes=4548, embed_size=32,
+                                         num_test_users=1500)
+    ds = formats.Dataset(base)
+    load = lambda n: formats.load_numpy_file(str(tmp_path / n))
+    PM, RE, CE, GM = (load(n) for n in ("Personal_Memory.npy", "Recipe_Embedding.npy", "Category_Embedding.npy",
+                                        "General_Memory.npy"))
+    d2c = formats.load_json_file(str(tmp_path / "dish_to_category.json"))
+    args = types.SimpleNamespace(learner="adam", num_categories=4, num_users=64657, num_labels=95, embed_size=32,
+                                 lr=0.001, decay_steps=1000, decay_rate=1.0, high_level_score_coefficient=0.99,
+                                 beta_1=0.01, beta_2=0.01, alpha=0.01)
+    model = Model(args, PM, RE, CE, GM)
+    hits, ndcgs = evaluate_model(Session(model), model, ds.testRatings, ds.testNegatives, 10, d2c)
+    assert len(hits) == 1500
+    fn = lambda u, i, c: oracle.inference_f32(PM, RE, CE, u, i, c)
+    sub = {u: ds.testRatings[u] for u in list(ds.testRatings)[:300]}
+    rh, rn = oracle.evaluate_model(fn, sub, ds.testNegatives, 10, d2c)
+    # random float scores: a rank flip needs two candidates within ~1e-7 of each other; allow none
+    assert hits[:300] == rh and ndcgs[:300] == rn
+    assert 0.1 < np.mean(hits) < 0.35          # 10 of 51 at random: HR@10 ~ 0.196
