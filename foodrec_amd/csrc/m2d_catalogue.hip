@@ -26,6 +26,7 @@
 #ifndef M2D_DIAG
 #define M2D_DIAG 0
 #endif
+static unsigned long long *g_m2d_diag_buffer = nullptr;   // set by scripts/diag only
 
 namespace {
 
@@ -74,6 +75,7 @@ struct TopkArgs {
     float *out_scores;     // [nU, nsplit, k]
     int32_t *out_ids;
     int32_t *err;
+    unsigned long long *dbg;   // scripts/diag only (M2D_DIAG & 16): per-wave phase cycle sums
 };
 
 __device__ __forceinline__ bool ahead(float v, float w)
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
     int32_t ri[KR > 0 ? KR : 1];
 #pragma unroll
     for (int i = 0; i < (KR > 0 ? KR : 1); ++i) {
-        rs[i] = 0.f;
+        rs[i] = -INFINITY;                      // empty slot: any finite score beats it
         ri[i] = -1;
     }
 
@@ -167,13 +169,29 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+#if M2D_DIAG & 16
+    unsigned long long t_mfma = 0, t_epi = 0, t_bar = 0, t_slow = 0, n_slow = 0, t0_, t1_;
+#define STAMP(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
+#else
+#define STAMP(x)
+#endif
     for (int64_t s = 0; s < nstages; ++s) {
         const int buf = (int)(s & 1);
+#if M2D_DIAG & 16
+        STAMP(t0_);
+#endif
         if (!(M2D_DIAG & 2) && s + 1 < nstages) issue_stage(s + 1, buf ^ 1);
         const int c = (int)(s % NKC);
         if (c == 0) {
+            const int64_t tile0 = (t_begin + s / NKC) * 32;
+            if (KR > 0 && tile0 + 32 > p.I) {   // last, partial tile: pad rows start at -inf and never rank
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                for (int r = 0; r < 16; ++r)
+                    acc[r] = (tile0 + 4 * h + (r & 3) + 8 * (r >> 2) < p.I) ? 0.f : -INFINITY;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            }
         }
         const float *img = stage0 + (size_t)buf * STAGE_FLOATS + (size_t)j * (S * 4);
 #pragma unroll
@@ -191,59 +209,38 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
                 }
             }
         }
+#if M2D_DIAG & 16
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[r]));
+        STAMP(t1_); t_mfma += t1_ - t0_; t0_ = t1_;
+        bool was_slow = false;
+#endif
         if (M2D_DIAG & 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[r]));
         } else if (c == NKC - 1) {
             // ---- epilogue: lane holds user j, dishes base + (r&3) + 8*(r>>2) + 4*h, ascending in r
             const int64_t base = (t_begin + s / NKC) * 32 + 4 * h;
-            float mx = acc[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
-            const bool maybe = (cnt < kl) || !(mx <= thr);
-            if ((M2D_DIAG & 8) ? (mx == 12345.678f) : __any(maybe)) {   // bit 3: fast path only
-                unsigned cmask = 0;   // KR > 0: which of this lane's 16 scores pass its (current) threshold
+            if constexpr (KR > 0) {
+                // Exact-f32 MFMA runs on the same FMA lanes as the VALU, so every VALU instruction here is
+                // matrix time lost: one compare per score, and only where some lane beats its threshold a
+                // branch-free sweep (5 VALU per slot).  Non-finite scores never beat a threshold; they are
+                // appended after the scan (m2d_topk_fill_absent).  Dishes arrive in ascending id and the
+                // sweep is stable, so ties keep the lower id first.
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = acc[r];
-                    const int64_t dish = base + (r & 3) + 8 * (r >> 2);
-                    const bool cand = dish < p.I && ((cnt < kl) || ahead(v, thr));
-                    if constexpr (KR > 0) {
-                        cmask |= cand ? (1u << r) : 0u;
-                    } else if (cand) {
-                        int pos = cnt < k ? cnt : k - 1;
-                        while (pos > 0) {
-                            const float w = ls[(pos - 1) * 64 + lane];
-                            if (!ahead(v, w)) break;
-                            ls[pos * 64 + lane] = w;
-                            li[pos * 64 + lane] = li[(pos - 1) * 64 + lane];
-                            --pos;
-                        }
-                        ls[pos * 64 + lane] = v;
-                        li[pos * 64 + lane] = (int32_t)dish;
-                        if (cnt < k) ++cnt;
-                        if (cnt == k) thr = ls[(k - 1) * 64 + lane];
-                    }
-                }
-                if constexpr (KR > 0) {
-                    // Rolled insertion loop (small code: the unrolled form was ~40 KB and thrashed the
-                    // instruction cache).  Each pass every lane with candidates left inserts its lowest-r
-                    // one -- ascending dish id, so ties stay stable -- re-checked against the threshold
-                    // its previous insertions may have raised.
-                    while (__any(cmask != 0u)) {
-                        const bool has = cmask != 0u;
-                        const int r = has ? (__ffs((int)cmask) - 1) : 0;
-                        cmask &= cmask - 1u;
-                        float v = acc[0];
-#pragma unroll
-                        for (int q = 1; q < 16; ++q) v = (r == q) ? acc[q] : v;
-                        const bool cand = has && ((cnt < KR) || ahead(v, thr));
+                    const bool cand = v > thr;
+                    if ((M2D_DIAG & 8) ? false : __any(cand)) {
+#if M2D_DIAG & 16
+                        was_slow = true;
+#endif
                         float xs = v;
-                        int32_t xi = (int32_t)(base + (r & 3) + 8 * (r >> 2));
-                        bool placed = false;   // once placed, everything below shifts down one slot
+                        int32_t xi = (int32_t)base + (r & 3) + 8 * (r >> 2);
+                        bool placed = false;      // once placed, everything below shifts down one slot
 #pragma unroll
                         for (int i = 0; i < KR; ++i) {
-                            const bool sw = cand && (placed || (i >= cnt) || ahead(xs, rs[i]));
+                            const bool sw = cand && (placed || xs > rs[i]);
                             placed = placed || sw;
                             const float ts = rs[i];
                             const int32_t ti = ri[i];
@@ -252,23 +249,63 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
                             xs = sw ? ts : xs;
                             xi = sw ? ti : xi;
                         }
-                        cnt += (cand && cnt < KR) ? 1 : 0;
-                        if (cnt == KR) thr = rs[KR - 1];
+                        thr = rs[KR - 1];
+                    }
+                }
+            } else {
+                float mx = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+                const bool maybe = (cnt < k) || !(mx <= thr);
+                if ((M2D_DIAG & 8) ? (mx == 12345.678f) : __any(maybe)) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[r];
+                        const int64_t dish = base + (r & 3) + 8 * (r >> 2);
+                        const bool cand = dish < p.I && ((cnt < k) || ahead(v, thr));
+                        if (cand) {
+                            int pos = cnt < k ? cnt : k - 1;
+                            while (pos > 0) {
+                                const float w = ls[(pos - 1) * 64 + lane];
+                                if (!ahead(v, w)) break;
+                                ls[pos * 64 + lane] = w;
+                                li[pos * 64 + lane] = li[(pos - 1) * 64 + lane];
+                                --pos;
+                            }
+                            ls[pos * 64 + lane] = v;
+                            li[pos * 64 + lane] = (int32_t)dish;
+                            if (cnt < k) ++cnt;
+                            if (cnt == k) thr = ls[(k - 1) * 64 + lane];
+                        }
                     }
                 }
             }
         }
+#if M2D_DIAG & 16
+        STAMP(t1_); t_epi += t1_ - t0_; if (was_slow) { t_slow += t1_ - t0_; ++n_slow; } t0_ = t1_;
+#endif
         if (!(M2D_DIAG & 4)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+#if M2D_DIAG & 16
+        STAMP(t1_); t_bar += t1_ - t0_;
+#endif
     }
 
+#if M2D_DIAG & 16
+    if (lane == 0 && p.dbg) {
+        unsigned long long *d = p.dbg + ((size_t)blockIdx.x * WAVES + wave) * 8;
+        d[0] = t_mfma; d[1] = t_epi; d[2] = t_bar; d[3] = t_slow; d[4] = n_slow; d[5] = (unsigned long long)nstages;
+    }
+#endif
     if constexpr (KR > 0) {   // publish the register lists so the partner lane can be merged in
+        cnt = 0;
 #pragma unroll
         for (int i = 0; i < KR; ++i) {
             ls[i * 64 + lane] = rs[i];
             li[i * 64 + lane] = ri[i];
+            cnt += ri[i] >= 0 ? 1 : 0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -400,6 +437,28 @@ __global__ void m2d_topk_merge_splits(const float *ps, const int32_t *pi, int64_
     }
 }
 
+// Users with fewer than k ranked dishes (every finite-scored dish is already in their list, the rest of the
+// catalogue scored NaN -- an empty category mask, Model_Recommender.py:79 -- or -inf): append the dishes not
+// in the list in ascending id with a NaN score, which is where heapq.nlargest-style "NaN last" puts them.
+__global__ void m2d_topk_fill_absent(float *scores, int32_t *ids, int64_t nU, int k, int64_t I)
+{
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nU) return;
+    float *s = scores + u * k;
+    int32_t *id = ids + u * k;
+    int n = 0;
+    while (n < k && id[n] >= 0) ++n;
+    for (int64_t d = 0; n < k && d < I; ++d) {
+        bool present = false;
+        for (int q = 0; q < n; ++q) present = present || (id[q] == (int32_t)d);
+        if (!present) {
+            id[n] = (int32_t)d;
+            s[n] = __builtin_nanf("");
+            ++n;
+        }
+    }
+}
+
 }  // namespace
 
 int m2d_ensure_dish_vectors(m2d_engine *h, hipStream_t st)
@@ -468,6 +527,9 @@ int launch_mfma(m2d_engine *h, TopkArgs &a, float *final_s, int32_t *final_i, hi
                            a.out_ids, a.nU, nsplit, a.k, final_s, final_i);
         M2D_HIP_TRY(h, hipGetLastError());
     }
+    hipLaunchKernelGGL(m2d_topk_fill_absent, dim3((unsigned)((a.nU + 127) / 128)), dim3(128), 0, st, final_s, final_i,
+                       a.nU, a.k, a.I);
+    M2D_HIP_TRY(h, hipGetLastError());
     h->last_kernel = "m2d_topk_mfma";
     return M2D_OK;
 }
@@ -484,6 +546,7 @@ int m2d_launch_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32
     a.pm = h->pm; a.dt = h->dish_vec; a.users = users; a.nU = nU; a.U = h->U; a.I = h->I;
     a.user_base = h->user_base; a.k = k; a.nsplit = 1; a.tiles = (h->I + 31) / 32;
     a.out_scores = out_scores; a.out_ids = out_ids; a.err = h->err_dev;
+    a.dbg = g_m2d_diag_buffer;
     const bool force_generic = h->opt_variant == 9;
     if (!force_generic && K % 8 == 0) {
         const int NB = K / 8;

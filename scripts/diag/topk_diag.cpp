@@ -33,6 +33,10 @@ int main(int argc, char **argv)
     for (int64_t i = 0; i < U; ++i) hu[i] = (int32_t)i;
     hipMemcpy(users, hu.data(), U * 4, hipMemcpyHostToDevice);
     h.pm = dpm; h.re = dre; h.ce = dce; h.dish_cats = dcats;
+#if M2D_DIAG & 16
+    unsigned long long *dbg; hipMalloc(&dbg, 4096 * 8 * 8); hipMemset(dbg, 0, 4096 * 8 * 8);
+    g_m2d_diag_buffer = dbg;
+#endif
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     m2d_launch_topk_users(&h, users, U, k, outs, outi, nullptr);
@@ -47,6 +51,16 @@ int main(int argc, char **argv)
         if (rc) printf("rc=%d %s\n", rc, h.last_error.c_str());
         if (ms < best) best = ms;
     }
+#if M2D_DIAG & 16
+    {
+        std::vector<unsigned long long> hd(2048 * 8);
+        hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
+        double m = 0, e = 0, b = 0, sl = 0, ns = 0, st = 0;
+        for (int w = 0; w < 2048; ++w) { m += hd[w*8]; e += hd[w*8+1]; b += hd[w*8+2]; sl += hd[w*8+3]; ns += hd[w*8+4]; st += hd[w*8+5]; }
+        printf("per stage per wave (cycles): mfma %.0f  epilogue %.0f  wait+barrier %.0f | slow-path stages %.1f%%, %.0f cycles each\n",
+               m / st, e / st, b / st, 100.0 * ns / st, ns ? sl / ns : 0.0);
+    }
+#endif
     const double flops = 2.0 * K * (double)U * (double)I;
     printf("M2D_DIAG=%d  %.3f ms  %.1f TFLOP/s  (%.1f%% of 157.3)\n", M2D_DIAG, best, flops / best / 1e9, flops / best / 1e9 / 157.3 * 100);
     return 0;
