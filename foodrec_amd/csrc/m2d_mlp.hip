@@ -109,33 +109,68 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
             for (int r = 0; r < 16; ++r) acc1[nt][r] = 0.f;
         float base = 0.f;
 
-        // ---- layer 1: K in chunks of 64; lane (pair pl, half h) owns k = 64 kc + 32 h + t ----------------
-        for (int kc = 0; kc < KCH; ++kc) {
-            const int buf = ringpos & 1;
-            issue_stage((kc + 1) % NST, buf ^ 1);          // kc + 1 == KCH -> W2
-            float z[32];
+        // ---- layer 1: K in chunks of 64 (one LDS stage); lane (pair pl, half h) owns k = 64 kc + 32 h + t.
+        // Each chunk is multiplied in two halves of 16 k-values per lane so that the NEXT half's two gathered
+        // rows (2 x 4 float4) are in flight under the current half's 128 MFMAs: the random-row latency is off
+        // the critical path at 176 live registers (acc 128 + z 16 + raw 32), inside the 2-waves/SIMD budget.
+        v4f ra[4], rb[4];
+        float z[16];
+        auto load_raw = [&](int g) {                        // g = 2 kc + half
+            const int f4 = (g >> 1) * 16 + (g & 1) * 4;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const v4f a = pu[kc * 16 + i], b = pd[kc * 16 + i];
-                const v4f zz = a * b;
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = pu[f4 + i];
+                rb[i] = pd[f4 + i];
+            }
+        };
+        auto make_z = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const v4f zz = ra[i] * rb[i];
                 z[4 * i + 0] = zz.x; z[4 * i + 1] = zz.y; z[4 * i + 2] = zz.z; z[4 * i + 3] = zz.w;
                 base += (zz.x + zz.y) + (zz.z + zz.w);
             }
-            const float *wrow = ring + (size_t)buf * RING_FLOATS + (size_t)(32 * h) * MH1 + pl;
+        };
+        load_raw(0);
+        make_z();
+        for (int kc = 0; kc < KCH; ++kc) {
+            const int buf = ringpos & 1;
+            issue_stage((kc + 1) % NST, buf ^ 1);          // kc + 1 == KCH -> W2
+            // A operand: one ds_read_b128 gives W1[k][128 g + 4 pl + q], q = 0..3, i.e. four hidden-unit tiles
+            // at once; tile (g, q) row i is hidden unit n = 128 g + 4 i + q.  Reads run one step ahead.
+            const v4f *wrow = reinterpret_cast<const v4f *>(ring + (size_t)buf * RING_FLOATS + (size_t)(32 * h) * MH1) + pl;
 #pragma unroll
-            for (int t = 0; t < 32; ++t) {
+            for (int half = 0; half < 2; ++half) {
+                const int g = 2 * kc + half;
+                if (g + 1 < 2 * KCH) load_raw(g + 1);
+                v4f a_cur[2], a_nxt[2];
+                a_cur[0] = wrow[(16 * half) * (MH1 / 4)];
+                a_cur[1] = wrow[(16 * half) * (MH1 / 4) + 32];
 #pragma unroll
-                for (int nt = 0; nt < 8; ++nt) {
-                    const float a = wrow[t * MH1 + 32 * nt];
-                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, z[t], acc1[nt], 0, 0, 0);
+                for (int tt = 0; tt < 16; ++tt) {
+                    if (tt + 1 < 16) {
+                        a_nxt[0] = wrow[(16 * half + tt + 1) * (MH1 / 4)];
+                        a_nxt[1] = wrow[(16 * half + tt + 1) * (MH1 / 4) + 32];
+                    }
+#pragma unroll
+                    for (int gq = 0; gq < 2; ++gq) {
+                        acc1[4 * gq + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[gq].x, z[tt], acc1[4 * gq + 0], 0, 0, 0);
+                        acc1[4 * gq + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[gq].y, z[tt], acc1[4 * gq + 1], 0, 0, 0);
+                        acc1[4 * gq + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[gq].z, z[tt], acc1[4 * gq + 2], 0, 0, 0);
+                        acc1[4 * gq + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[gq].w, z[tt], acc1[4 * gq + 3], 0, 0, 0);
+                    }
+                    a_cur[0] = a_nxt[0];
+                    a_cur[1] = a_nxt[1];
                 }
+                if (g + 1 < 2 * KCH) make_z();
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             ++ringpos;
         }
 
-        // ---- layer 2: acc1 (rows n = 32 nt + (r&3) + 8 (r>>2) + 4 h, column = pair) is the B operand ----
+        // ---- layer 2: acc1[4 g + q] (row i = (r&3) + 8 (r>>2) + 4 h is hidden unit 128 g + 4 i + q; column =
+        // pair) is the B operand as it stands ------------------------------------------------------------
         {
             const int buf = ringpos & 1;
             issue_stage(0, buf ^ 1);                       // next tile's first W1 chunk (harmless if none)
@@ -149,7 +184,7 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
             for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int n = 128 * (nt >> 2) + 4 * ((r & 3) + 8 * (r >> 2) + 4 * h) + (nt & 3);
                     const float hv = fmaxf(acc1[nt][r] + sb1[n], 0.f);
                     acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2s[n * MH2], hv, acc2[0], 0, 0, 0);
                     acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2s[n * MH2 + 32], hv, acc2[1], 0, 0, 0);
