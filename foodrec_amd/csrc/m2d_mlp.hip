@@ -22,6 +22,19 @@
 // Roofline: MFMA (2*(K*H1 + H1*H2 + H2) flop per pair = 360 704 at E = 128) vs 157.3 TFLOP/s f32.
 #include "m2d_engine.h"
 
+// Timing-only instrumentation for scripts/diag/mlp_diag.cpp (never defined in the product build).
+#ifndef M2D_MLP_DIAG
+#define M2D_MLP_DIAG 0
+#endif
+static unsigned long long *g_m2d_mlp_diag_buffer = nullptr;
+#if M2D_MLP_DIAG
+#define MSTAMP(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
+#define MACC(dst) do { MSTAMP(t1_); dst += t1_ - t0_; t0_ = t1_; } while (0)
+#else
+#define MSTAMP(x)
+#define MACC(dst)
+#endif
+
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -42,6 +55,7 @@ struct MlpArgs {
     int64_t B, U, I, user_base;
     int32_t K, H1, H2;
     int32_t *err;
+    unsigned long long *dbg;   // scripts/diag only
 };
 
 __device__ __forceinline__ void latch(int32_t *err, int code, int64_t value, int64_t index)
@@ -90,39 +104,55 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t pi = tile * (32 * MWAVES) + wave * 32 + pl;
-        const bool valid = pi < p.B;
-        int32_t uid = valid ? p.users[pi] : (int32_t)p.user_base;
+#if M2D_MLP_DIAG
+    unsigned long long t_pro = 0, t_l1 = 0, t_bar = 0, t_l23 = 0, t_vm = 0, n_tiles = 0, t0_, t1_;
+    MSTAMP(t0_);
+#endif
+    // this lane's pair of a tile: ids -> the two row pointers (out-of-range ids are latched and clamped)
+    int64_t pi = 0;
+    bool valid = false, bad = false;
+    const v4f *pu = nullptr, *pd = nullptr;
+    auto locate = [&](int64_t tile) {
+        pi = tile * (32 * MWAVES) + wave * 32 + pl;
+        valid = pi < p.B;
+        const int32_t uid = valid ? p.users[pi] : (int32_t)p.user_base;
         int32_t did = valid ? p.items[pi] : 0;
         int64_t ul = (int64_t)uid - p.user_base;
-        bool bad = false;
+        bad = false;
         if (ul < 0 || ul >= p.U) { latch(p.err, M2D_ERR_BAD_USER_ID, uid, pi); ul = 0; bad = true; }
         if (did < 0 || (int64_t)did >= p.I) { latch(p.err, M2D_ERR_BAD_ITEM_ID, did, pi); did = 0; bad = true; }
-        const v4f *pu = reinterpret_cast<const v4f *>(p.pm) + (size_t)ul * (K / 4) + 8 * h;
-        const v4f *pd = reinterpret_cast<const v4f *>(p.dt) + (size_t)did * (K / 4) + 8 * h;
+        pu = reinterpret_cast<const v4f *>(p.pm) + (size_t)ul * (K / 4) + 8 * h;
+        pd = reinterpret_cast<const v4f *>(p.dt) + (size_t)did * (K / 4) + 8 * h;
+    };
+    v4f ra[4], rb[4];
+    auto load_raw = [&](int g) {                            // g = 2 kc + half
+        const int f4 = (g >> 1) * 16 + (g & 1) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = pu[f4 + i];
+            rb[i] = pd[f4 + i];
+        }
+    };
+    if ((int64_t)blockIdx.x < ntiles) {
+        locate(blockIdx.x);
+        load_raw(0);
+    }
 
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // biases ride in as the initial accumulators: layer 2 / 3 then need no add and no LDS read per step
         v16f acc1[8];
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[nt][r] = 0.f;
+            for (int r = 0; r < 16; ++r)
+                acc1[nt][r] = sb1[128 * (nt >> 2) + 4 * ((r & 3) + 8 * (r >> 2) + 4 * h) + (nt & 3)];
         float base = 0.f;
 
         // ---- layer 1: K in chunks of 64 (one LDS stage); lane (pair pl, half h) owns k = 64 kc + 32 h + t.
         // Each chunk is multiplied in two halves of 16 k-values per lane so that the NEXT half's two gathered
         // rows (2 x 4 float4) are in flight under the current half's 128 MFMAs: the random-row latency is off
         // the critical path at 176 live registers (acc 128 + z 16 + raw 32), inside the 2-waves/SIMD budget.
-        v4f ra[4], rb[4];
         float z[16];
-        auto load_raw = [&](int g) {                        // g = 2 kc + half
-            const int f4 = (g >> 1) * 16 + (g & 1) * 4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i] = pu[f4 + i];
-                rb[i] = pd[f4 + i];
-            }
-        };
         auto make_z = [&]() {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -131,8 +161,11 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
                 base += (zz.x + zz.y) + (zz.z + zz.w);
             }
         };
-        load_raw(0);
-        make_z();
+        make_z();                                           // rows of half 0 were requested a tile ago
+#if M2D_MLP_DIAG
+        asm volatile("" ::"v"(z[0]), "v"(z[15]));
+        MACC(t_pro); ++n_tiles;
+#endif
         for (int kc = 0; kc < KCH; ++kc) {
             const int buf = ringpos & 1;
             issue_stage((kc + 1) % NST, buf ^ 1);          // kc + 1 == KCH -> W2
@@ -164,8 +197,15 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
                 }
                 if (g + 1 < 2 * KCH) make_z();
             }
+#if M2D_MLP_DIAG
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) asm volatile("" ::"v"(acc1[nt][0]));
+            MACC(t_l1);
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MACC(t_vm);
             __syncthreads();
+            MACC(t_bar);
             ++ringpos;
         }
 
@@ -175,17 +215,24 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
             const int buf = ringpos & 1;
             issue_stage(0, buf ^ 1);                       // next tile's first W1 chunk (harmless if none)
             const float *w2s = ring + (size_t)buf * RING_FLOATS + pl;
+            // the finished tile's bookkeeping, then start the NEXT tile's gather under layers 2-3
+            const int64_t cur_pi = pi;
+            const bool cur_valid = valid, cur_bad = bad;
+            if (tile + gridDim.x < ntiles) {
+                locate(tile + gridDim.x);
+                load_raw(0);
+            }
             v16f acc2[2];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc2[mt][r] = sb2[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h];
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int n = 128 * (nt >> 2) + 4 * ((r & 3) + 8 * (r >> 2) + 4 * h) + (nt & 3);
-                    const float hv = fmaxf(acc1[nt][r] + sb1[n], 0.f);
+                    const float hv = fmaxf(acc1[nt][r], 0.f);
                     acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2s[n * MH2], hv, acc2[0], 0, 0, 0);
                     acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2s[n * MH2 + 32], hv, acc2[1], 0, 0, 0);
                 }
@@ -197,18 +244,27 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    o = fmaf(sw3[m], fmaxf(acc2[mt][r] + sb2[m], 0.f), o);
+                    o = fmaf(sw3[m], fmaxf(acc2[mt][r], 0.f), o);
                 }
             o += __shfl_xor(o, 32, 64);
             base += __shfl_xor(base, 32, 64);
-            if (h == 0 && valid) p.out[pi] = bad ? __builtin_nanf("") : (base + (o + p.b3));
+            if (h == 0 && cur_valid) p.out[cur_pi] = cur_bad ? __builtin_nanf("") : (base + (o + p.b3));
+            MACC(t_l23);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            MACC(t_bar);
             ++ringpos;
         }
     }
+#if M2D_MLP_DIAG
+    if (lane == 0 && p.dbg) {
+        unsigned long long *d = p.dbg + ((size_t)blockIdx.x * MWAVES + wave) * 8;
+        d[0] = t_pro; d[1] = t_l1; d[2] = t_bar; d[3] = t_l23; d[4] = n_tiles; d[5] = t_vm;
+    }
+#endif
 }
 
+// (diag epilogue is emitted by the macro below, inside the kernel)
 // Any K / H1 / H2: one wave per pair, activations in LDS.  Slow; for shapes the MFMA kernel does not cover.
 __global__ __launch_bounds__(256) void m2d_mlp_generic(MlpArgs p)
 {
@@ -269,6 +325,7 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
     a.w3 = h->mlp_w3; a.b3 = h->mlp_b3; a.users = users; a.items = items; a.out = out;
     a.B = B; a.U = h->U; a.I = h->I; a.user_base = h->user_base;
     a.K = (h->C + 1) * h->E; a.H1 = h->mlp_h1; a.H2 = h->mlp_h2; a.err = h->err_dev;
+    a.dbg = g_m2d_mlp_diag_buffer;
     const bool mfma_ok = a.H1 == MH1 && a.H2 == MH2 && a.K % 64 == 0 && h->opt_variant != 9;
     const int kch = a.K / 64;
     if (mfma_ok && (kch == 5 || kch == 10 || kch == 20 || kch == 3)) {
