@@ -168,14 +168,14 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
 #endif
         for (int kc = 0; kc < KCH; ++kc) {
             const int buf = ringpos & 1;
-            issue_stage((kc + 1) % NST, buf ^ 1);          // kc + 1 == KCH -> W2
+            if (!(M2D_MLP_DIAG & 4)) issue_stage((kc + 1) % NST, buf ^ 1);   // kc + 1 == KCH -> W2 (diag bit 2: no DMA)
             // A operand: one ds_read_b128 gives W1[k][128 g + 4 pl + q], q = 0..3, i.e. four hidden-unit tiles
             // at once; tile (g, q) row i is hidden unit n = 128 g + 4 i + q.  Reads run one step ahead.
             const v4f *wrow = reinterpret_cast<const v4f *>(ring + (size_t)buf * RING_FLOATS + (size_t)(32 * h) * MH1) + pl;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const int g = 2 * kc + half;
-                if (g + 1 < 2 * KCH) load_raw(g + 1);
+                if (!(M2D_MLP_DIAG & 2) && g + 1 < 2 * KCH) load_raw(g + 1);   // diag bit 1: no in-tile gather
                 v4f a_cur[2], a_nxt[2];
                 a_cur[0] = wrow[(16 * half) * (MH1 / 4)];
                 a_cur[1] = wrow[(16 * half) * (MH1 / 4) + 32];
