@@ -66,6 +66,10 @@ void release(m2d_engine *h)
     if (h->own_ce && h->ce) (void)hipFree((void *)h->ce);
     if (h->own_dish_cats && h->dish_cats) (void)hipFree((void *)h->dish_cats);
     if (h->dish_vec) (void)hipFree(h->dish_vec);
+    if (h->grp_rs) (void)hipFree(h->grp_rs);
+    if (h->grp_perm) (void)hipFree(h->grp_perm);
+    if (h->grp_tile_info) (void)hipFree(h->grp_tile_info);
+    if (h->grp_work) (void)hipFree(h->grp_work);
     if (h->own_mlp) {
         for (const float *q : {h->mlp_w1, h->mlp_b1, h->mlp_w2, h->mlp_b2, h->mlp_w3})
             if (q) (void)hipFree((void *)q);
@@ -170,6 +174,7 @@ int m2d_set_dish_categories(m2d_engine *h, const float *cats, int table_flags)
     h->dish_cats = nullptr;
     h->own_dish_cats = false;
     h->dish_vec_valid = false;
+    h->grp_valid = false;
     int rc = adopt_table(h, cats, (size_t)h->I * h->C, table_flags, &h->dish_cats, &h->own_dish_cats);
     if (rc != M2D_OK) return rc;
     if (!aligned16(h->dish_cats)) return fail(h, M2D_ERR_INVALID_ARG, "dish categories must be 16-byte aligned");

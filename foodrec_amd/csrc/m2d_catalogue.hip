@@ -481,6 +481,410 @@ int m2d_ensure_dish_vectors(m2d_engine *h, hipStream_t st)
 
 namespace {
 
+// =====================================================================================================
+// Pattern-grouped retrieval (binary category masks, no ingredient table).
+//
+// With m in {0,1}^C a dish's mask is one of 2^C - 1 patterns P, and Model_Recommender.py:67-96 collapses to
+//     score(u, d) = alpha_P[u] + < w_P[u], RE[d] >,
+//     alpha_P[u] = (a / n_P) sum_{c in P} <U_high[u], CE_c>,   w_P[u] = ((1-a) / n_P) sum_{c in P} U_low,c[u]
+// so after sorting the dishes by pattern the contraction runs over K = E instead of (C+1)*E: 5x fewer
+// MFMAs, 5x fewer bytes through the LDS ring, and a user operand of E/2 registers instead of 5E/2.
+// alpha_P rides in as the initial accumulator.  Dishes with an empty mask (0/0 -> NaN) are left out and
+// appended by m2d_topk_fill_absent.  Masks with other weights use the dense kernel above.
+// =====================================================================================================
+constexpr int GRP_MAXPAT = 16;
+
+__global__ __launch_bounds__(256) void m2d_grp_hist(const float *cats, int64_t I, int C, int32_t *blk_hist,
+                                                    int32_t *flags)
+{
+    __shared__ int sh[GRP_MAXPAT];
+    if (threadIdx.x < GRP_MAXPAT) sh[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d < I) {
+        int pat = 0;
+        for (int c = 0; c < C; ++c) {
+            const float m = cats[d * C + c];
+            if (m != 0.f) {
+                pat |= 1 << c;
+                if (m != 1.f) atomicOr(flags, 1);      // not a 0/1 mask: the grouped form does not apply
+            }
+        }
+        atomicAdd(&sh[pat], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < GRP_MAXPAT) blk_hist[(size_t)blockIdx.x * GRP_MAXPAT + threadIdx.x] = sh[threadIdx.x];
+}
+
+// one block of 16 threads: per-pattern exclusive scan over the blocks (in place), padded group offsets,
+// and the tile table  info = pattern | (valid rows << 8)
+__global__ void m2d_grp_scan(int32_t *blk_hist, int nblk, int32_t *grp, int32_t *tile_info)
+{
+    __shared__ int total[GRP_MAXPAT];
+    const int pat = threadIdx.x;
+    int run = 0;
+    for (int b = 0; b < nblk; ++b) {
+        const int c = blk_hist[(size_t)b * GRP_MAXPAT + pat];
+        blk_hist[(size_t)b * GRP_MAXPAT + pat] = run;
+        run += c;
+    }
+    total[pat] = run;
+    __syncthreads();
+    if (pat == 0) {
+        int off = 0, t = 0;
+        grp[0] = -1;
+        for (int q = 1; q < GRP_MAXPAT; ++q) {
+            grp[q] = off;
+            const int nt = (total[q] + 31) / 32;
+            for (int i = 0; i < nt; ++i) tile_info[t++] = q | (min(32, total[q] - 32 * i) << 8);
+            off += nt * 32;
+        }
+        grp[16] = t;
+        grp[17] = off;
+    }
+}
+
+__global__ __launch_bounds__(256) void m2d_grp_scatter(const float *cats, int64_t I, int C, const int32_t *blk_base,
+                                                       const int32_t *grp, int32_t *perm)
+{
+    __shared__ unsigned char sp[256];
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int pat = 255;
+    if (d < I) {
+        pat = 0;
+        for (int c = 0; c < C; ++c) pat |= (cats[d * C + c] != 0.f) ? (1 << c) : 0;
+    }
+    sp[threadIdx.x] = (unsigned char)pat;
+    __syncthreads();
+    if (d < I && pat != 0) {
+        int rank = 0;
+        for (int q = 0; q < (int)threadIdx.x; ++q) rank += sp[q] == pat ? 1 : 0;   // stable: ascending dish id
+        perm[grp[pat] + blk_base[(size_t)blockIdx.x * GRP_MAXPAT + pat] + rank] = (int32_t)d;
+    }
+}
+
+// one wave per slot: RS[slot] = RE[perm[slot]] (zeros for padding)
+__global__ __launch_bounds__(256) void m2d_grp_gather(const float *re, const int32_t *perm, int64_t slots, int E,
+                                                      float *rs)
+{
+    const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= slots) return;
+    const int32_t d = perm[slot];
+    for (int e = threadIdx.x & 63; e < E; e += 64) rs[slot * E + e] = d >= 0 ? re[(size_t)d * E + e] : 0.f;
+}
+
+struct GroupedArgs {
+    const float *pm;         // [U, (C+1) E]
+    const float *ce;         // [C, E]
+    const float *rs;         // [slots, E]   Recipe_Embedding rows sorted by (pattern, dish id)
+    const int32_t *perm;     // [slots]      slot -> dish id (-1 = padding)
+    const int32_t *tile_info;
+    const int32_t *users;
+    int64_t nU, U, user_base;
+    int32_t k, nsplit;
+    int64_t tiles;
+    float a, b;
+    float *out_scores;
+    int32_t *out_ids;
+    int32_t *err;
+};
+
+template <int E8, int WAVES, int KR>
+__global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
+{
+    constexpr int E = E8 * 8, C = 4;
+    constexpr int S = E / 4;                               // 16-B slots per row
+    constexpr int TPS = E <= 32 ? 16 : (E == 64 ? 8 : 4);  // tiles per stage: 64 KiB stages
+    constexpr int STAGE_FLOATS = TPS * 32 * E;
+    constexpr int PIECES = TPS * 32 * S / 64;              // 1-KiB DMA pieces per stage
+    constexpr int SW = S < 16 ? S : 16;                    // XOR-swizzle modulus (bank row = 16 slots)
+
+    extern __shared__ __align__(16) float smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int k = p.k;
+
+    const int64_t uidx = ((int64_t)blockIdx.x * WAVES + wave) * 32 + j;
+    const bool uvalid = uidx < p.nU;
+    int64_t ul = 0;
+    if (uvalid) {
+        const int32_t uid = p.users[uidx];
+        ul = (int64_t)uid - p.user_base;
+        if (ul < 0 || ul >= p.U) {
+            if (atomicCAS(&p.err[0], 0, M2D_ERR_BAD_USER_ID) == 0) {
+                p.err[1] = uid;
+                p.err[2] = (int32_t)(uidx & 0xffffffff);
+                p.err[3] = (int32_t)(uidx >> 32);
+            }
+            ul = 0;
+        }
+    }
+    const v4f *pmu = reinterpret_cast<const v4f *>(p.pm) + (size_t)ul * ((C + 1) * S);
+    float hc[C];                                           // <U_high, CE_c>   Model_Recommender.py:67-75
+    {
+        const v4f *ce4 = reinterpret_cast<const v4f *>(p.ce);
+#pragma unroll
+        for (int c = 0; c < C; ++c) hc[c] = 0.f;
+#pragma unroll 1
+        for (int q = 0; q < S; ++q) {
+            const v4f u = pmu[q];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const v4f w = ce4[c * S + q];
+                hc[c] += (u.x * w.x + u.y * w.y) + (u.z * w.z + u.w * w.w);
+            }
+        }
+    }
+    v4f wP[E8];
+    float alpha = 0.f;
+    int cur_pat = -1;
+
+    float rs[KR];
+    int32_t ri[KR];
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        rs[i] = -INFINITY;
+        ri[i] = -1;
+    }
+    float thr = -INFINITY;
+
+    const int64_t per = (p.tiles + p.nsplit - 1) / p.nsplit;
+    const int64_t t_begin = (int64_t)blockIdx.y * per;
+    const int64_t t_end = min(p.tiles, t_begin + per);
+    const int64_t nstages = t_end > t_begin ? (t_end - t_begin + TPS - 1) / TPS : 0;
+
+    auto issue_stage = [&](int64_t s, int buf) {
+        const float *src0 = p.rs + (size_t)(t_begin + s * TPS) * 32 * E;   // rows past the last tile are zero padding
+        float *dst = smem + (size_t)buf * STAGE_FLOATS;
+        for (int pc = wave; pc < PIECES; pc += WAVES) {
+            const int ps = pc * 64 + lane;
+            const int r = ps / S, sl = ps - r * S;
+            const int q = sl ^ (r & (SW - 1));
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src0 + (size_t)r * E + q * 4),
+                                             (void __attribute__((address_space(3))) *)(dst + pc * 256), 16, 0, 0);
+        }
+    };
+
+    if (nstages > 0) issue_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    v16f acc;
+    for (int64_t s = 0; s < nstages; ++s) {
+        const int buf = (int)(s & 1);
+        if (s + 1 < nstages) issue_stage(s + 1, buf ^ 1);
+        for (int tl = 0; tl < TPS; ++tl) {
+            const int64_t t = t_begin + s * TPS + tl;
+            if (t >= t_end) break;                                      // wave-uniform
+            const int info = __builtin_amdgcn_readfirstlane(p.tile_info[t]);
+            const int pat = info & 255, nvalid = info >> 8;
+            if (pat != cur_pat) {                                       // at most 2^C - 1 times per block
+                cur_pat = pat;
+                const float inv_n = 1.0f / (float)__builtin_popcount(pat);
+                float hs = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) hs += ((pat >> c) & 1) ? hc[c] : 0.f;
+                alpha = p.a * (hs * inv_n);
+                const float beta = p.b * inv_n;
+#pragma unroll
+                for (int T = 0; T < E8; ++T) wP[T] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                for (int c = 0; c < C; ++c) {           // rolled: E8 loads in flight, not C * E8
+                    if (!((pat >> c) & 1)) continue;
+                    const v4f *row = pmu + (c + 1) * S + h;
+#pragma unroll
+                    for (int T = 0; T < E8; ++T) wP[T] += row[2 * T];
+                }
+#pragma unroll
+                for (int T = 0; T < E8; ++T) wP[T] *= beta;
+            }
+            // alpha_P[u] is the initial accumulator; padding rows of a group's last tile start at -inf
+            if (nvalid == 32) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = alpha;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = (4 * h + (r & 3) + 8 * (r >> 2) < nvalid) ? alpha : -INFINITY;
+            }
+            const float *img = smem + (size_t)buf * STAGE_FLOATS + (size_t)(tl * 32 + j) * E;
+#pragma unroll
+            for (int T = 0; T < E8; ++T) {
+                const int q = (2 * T + h) ^ (j & (SW - 1));
+                const v4f av = *reinterpret_cast<const v4f *>(img + q * 4);
+                const v4f bv = wP[T];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+            }
+            // epilogue: lane holds user j, slots t*32 + 4h + (r&3) + 8(r>>2), ascending in r (see m2d_topk_mfma)
+            const int32_t sbase = (int32_t)(t * 32) + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[r];
+                const bool cand = v > thr;
+                if (__any(cand)) {
+                    float xs = v;
+                    int32_t xi = sbase + (r & 3) + 8 * (r >> 2);
+                    bool placed = false;
+#pragma unroll
+                    for (int i = 0; i < KR; ++i) {
+                        const bool sw = cand && (placed || xs > rs[i]);
+                        placed = placed || sw;
+                        const float ts = rs[i];
+                        const int32_t ti = ri[i];
+                        rs[i] = sw ? xs : ts;
+                        ri[i] = sw ? xi : ti;
+                        xs = sw ? ts : xs;
+                        xi = sw ? ti : xi;
+                    }
+                    thr = rs[KR - 1];
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- publish (slot -> dish id), merge the two lanes of each user -------------------------------------
+    float *ls = smem + (size_t)wave * 2 * KR * 64;       // aliases stage 0: every wave is past the last barrier
+    int32_t *li = reinterpret_cast<int32_t *>(ls + (size_t)KR * 64);
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        ls[i * 64 + lane] = rs[i];
+        li[i * 64 + lane] = ri[i] >= 0 ? p.perm[ri[i]] : -1;
+        cnt += ri[i] >= 0 ? 1 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int cnt_hi = __shfl(cnt, j + 32, 64);
+    if (h == 0 && uvalid) {
+        const int ca = cnt, cb = cnt_hi;
+        int pa = 0, pb = 0;
+        float *os = p.out_scores + ((size_t)uidx * p.nsplit + blockIdx.y) * k;
+        int32_t *oi = p.out_ids + ((size_t)uidx * p.nsplit + blockIdx.y) * k;
+        for (int o = 0; o < k; ++o) {
+            const bool ha = pa < ca, hb = pb < cb;
+            if (!ha && !hb) {
+                os[o] = __builtin_nanf("");
+                oi[o] = -1;
+                continue;
+            }
+            const float sa = ha ? ls[pa * 64 + lane] : 0.f, sb = hb ? ls[pb * 64 + lane + 32] : 0.f;
+            const int32_t ia = ha ? li[pa * 64 + lane] : 0, ib = hb ? li[pb * 64 + lane + 32] : 0;
+            bool take_a;
+            if (!hb) take_a = true;
+            else if (!ha) take_a = false;
+            else take_a = sa > sb || (sa == sb && ia < ib);
+            os[o] = take_a ? sa : sb;
+            oi[o] = take_a ? ia : ib;
+            pa += take_a ? 1 : 0;
+            pb += take_a ? 0 : 1;
+        }
+    }
+}
+
+int ensure_grouped(m2d_engine *h, hipStream_t st)
+{
+    if (h->grp_valid) return M2D_OK;
+    const int64_t I = h->I;
+    const int nblk = (int)((I + 255) / 256);
+    const int64_t max_tiles = (I + 31) / 32 + GRP_MAXPAT;
+    const int64_t cap_rows = (max_tiles + 16) * 32;          // + one stage of zero rows past the last tile
+    if (h->grp_cap_rows != cap_rows || !h->grp_rs) {
+        for (void *q : {(void *)h->grp_rs, (void *)h->grp_perm, (void *)h->grp_tile_info, (void *)h->grp_work})
+            if (q) M2D_HIP_TRY(h, hipFree(q));
+        h->grp_rs = nullptr; h->grp_perm = nullptr; h->grp_tile_info = nullptr; h->grp_work = nullptr;
+        M2D_HIP_TRY(h, hipMalloc((void **)&h->grp_rs, (size_t)cap_rows * h->E * sizeof(float)));
+        M2D_HIP_TRY(h, hipMalloc((void **)&h->grp_perm, (size_t)cap_rows * sizeof(int32_t)));
+        M2D_HIP_TRY(h, hipMalloc((void **)&h->grp_tile_info, (size_t)max_tiles * sizeof(int32_t)));
+        M2D_HIP_TRY(h, hipMalloc((void **)&h->grp_work, ((size_t)nblk * GRP_MAXPAT + 64) * sizeof(int32_t)));
+        h->grp_cap_rows = cap_rows;
+    }
+    int32_t *blk_hist = h->grp_work, *grp = h->grp_work + (size_t)nblk * GRP_MAXPAT, *flags = grp + 32;
+    M2D_HIP_TRY(h, hipMemsetAsync(flags, 0, sizeof(int32_t), st));
+    M2D_HIP_TRY(h, hipMemsetAsync(h->grp_perm, 0xFF, (size_t)cap_rows * sizeof(int32_t), st));
+    hipLaunchKernelGGL(m2d_grp_hist, dim3(nblk), dim3(256), 0, st, h->dish_cats, I, h->C, blk_hist, flags);
+    hipLaunchKernelGGL(m2d_grp_scan, dim3(1), dim3(GRP_MAXPAT), 0, st, blk_hist, nblk, grp, h->grp_tile_info);
+    hipLaunchKernelGGL(m2d_grp_scatter, dim3(nblk), dim3(256), 0, st, h->dish_cats, I, h->C, blk_hist, grp, h->grp_perm);
+    hipLaunchKernelGGL(m2d_grp_gather, dim3((unsigned)((cap_rows + 3) / 4)), dim3(256), 0, st, h->re, h->grp_perm,
+                       cap_rows, h->E, h->grp_rs);
+    M2D_HIP_TRY(h, hipGetLastError());
+    int32_t host[3] = {0, 0, 0};   // tiles, slots, flags  (a table build may synchronise)
+    M2D_HIP_TRY(h, hipMemcpyAsync(host, grp + 16, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    M2D_HIP_TRY(h, hipMemcpyAsync(host + 2, flags, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    M2D_HIP_TRY(h, hipStreamSynchronize(st));
+    h->grp_tiles = host[0];
+    h->grp_binary = host[2] == 0;
+    h->grp_valid = true;
+    return M2D_OK;
+}
+
+// shared tail of every MFMA retrieval launch: dish-range splits -> partial lists in scratch
+int pick_splits(m2d_engine *h, int64_t ublocks, int64_t tiles, int64_t min_tiles_per_split)
+{
+    int nsplit = 1;
+    const int64_t want = 2 * (int64_t)h->num_cu;
+    if (ublocks < want) {
+        int64_t ns = (want + ublocks - 1) / ublocks;
+        const int64_t cap = tiles / min_tiles_per_split > 1 ? tiles / min_tiles_per_split : 1;
+        if (ns > 64) ns = 64;
+        if (ns > cap) ns = cap;
+        nsplit = (int)ns;
+    }
+    if (h->opt_variant >= 100) {   // test hook: force the number of dish-range splits
+        nsplit = h->opt_variant - 100;
+        if (nsplit < 1) nsplit = 1;
+        if (nsplit > 64) nsplit = 64;
+    }
+    return nsplit;
+}
+
+template <int E8, int WAVES, int KR>
+int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, float *final_s, int32_t *final_i,
+                   hipStream_t st)
+{
+    constexpr int E = E8 * 8;
+    constexpr int TPS = E <= 32 ? 16 : (E == 64 ? 8 : 4);
+    const size_t lds = (size_t)2 * TPS * 32 * E * sizeof(float);
+    GroupedArgs a;
+    a.pm = h->pm; a.ce = h->ce; a.rs = h->grp_rs; a.perm = h->grp_perm; a.tile_info = h->grp_tile_info;
+    a.users = users; a.nU = nU; a.U = h->U; a.user_base = h->user_base; a.k = k; a.tiles = h->grp_tiles;
+    a.a = h->a; a.b = h->b; a.err = h->err_dev;
+    const int64_t ublocks = (nU + 32 * WAVES - 1) / (32 * WAVES);
+    const int nsplit = pick_splits(h, ublocks, a.tiles, 4 * TPS);
+    a.nsplit = nsplit;
+    if (nsplit > 1) {
+        const size_t need = (size_t)nU * nsplit * k * 8 + 256;
+        if (h->scratch_bytes < need) {
+            if (h->scratch) M2D_HIP_TRY(h, hipFree(h->scratch));
+            h->scratch = nullptr; h->scratch_bytes = 0;
+            M2D_HIP_TRY(h, hipMalloc((void **)&h->scratch, need));
+            h->scratch_bytes = need;
+        }
+        a.out_scores = h->scratch;
+        a.out_ids = reinterpret_cast<int32_t *>(h->scratch + (size_t)nU * nsplit * k);
+    } else {
+        a.out_scores = final_s;
+        a.out_ids = final_i;
+    }
+    auto kern = m2d_topk_grouped<E8, WAVES, KR>;
+    M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(WAVES * 64), lds, st, a);
+    M2D_HIP_TRY(h, hipGetLastError());
+    if (nsplit > 1) {
+        hipLaunchKernelGGL(m2d_topk_merge_splits, dim3((unsigned)((nU + 127) / 128)), dim3(128), 0, st, a.out_scores,
+                           a.out_ids, nU, nsplit, k, final_s, final_i);
+        M2D_HIP_TRY(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(m2d_topk_fill_absent, dim3((unsigned)((nU + 127) / 128)), dim3(128), 0, st, final_s, final_i, nU, k,
+                       h->I);
+    M2D_HIP_TRY(h, hipGetLastError());
+    h->last_kernel = "m2d_topk_grouped";
+    return M2D_OK;
+}
+
 template <int NB, int WAVES, int KR>
 int launch_mfma(m2d_engine *h, TopkArgs &a, float *final_s, int32_t *final_i, hipStream_t st)
 {
@@ -539,7 +943,21 @@ int launch_mfma(m2d_engine *h, TopkArgs &a, float *final_s, int32_t *final_i, hi
 int m2d_launch_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, float *out_scores,
                           int32_t *out_ids, hipStream_t stream)
 {
-    int rc = m2d_ensure_dish_vectors(h, stream);
+    int rc;
+    // 0/1 category masks, no ingredient table: contraction over E after sorting dishes by mask pattern
+    if (h->C == 4 && !h->dish_high && k <= 16 && (h->E == 32 || h->E == 64 || h->E == 128) && h->opt_variant != 7 &&
+        h->opt_variant != 8 && h->opt_variant != 9) {
+        if ((rc = ensure_grouped(h, stream)) != M2D_OK) return rc;
+        if (h->grp_binary && h->grp_tiles > 0) {
+#define M2D_GRP(EV)                                                                                      \
+    if (h->E == EV)                                                                                      \
+        return k <= 10 ? launch_grouped<EV / 8, 8, 10>(h, users, nU, k, out_scores, out_ids, stream)        \
+                       : launch_grouped<EV / 8, 8, 16>(h, users, nU, k, out_scores, out_ids, stream);
+            M2D_GRP(32) M2D_GRP(64) M2D_GRP(128)
+#undef M2D_GRP
+        }
+    }
+    rc = m2d_ensure_dish_vectors(h, stream);
     if (rc != M2D_OK) return rc;
     const int K = (h->C + 1) * h->E;
     TopkArgs a;

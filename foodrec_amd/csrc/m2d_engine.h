@@ -47,6 +47,14 @@ struct m2d_engine {
     int64_t dish_vec_rows = 0;
     bool dish_vec_valid = false;
 
+    // pattern-grouped retrieval tables (0/1 masks only; built lazily by m2d_topk_users)
+    float *grp_rs = nullptr;            // [grp_cap_rows, E] Recipe_Embedding rows sorted by (mask pattern, dish id)
+    int32_t *grp_perm = nullptr;        // [grp_cap_rows]    slot -> dish id, -1 = padding
+    int32_t *grp_tile_info = nullptr;   // [tiles]           pattern | valid rows << 8
+    int32_t *grp_work = nullptr;        // block histograms / group offsets / flags
+    int64_t grp_tiles = 0, grp_cap_rows = 0;
+    bool grp_valid = false, grp_binary = false;
+
     // scratch for rank_candidates
     float *scratch = nullptr;
     size_t scratch_bytes = 0;

@@ -44,7 +44,7 @@ def _check(eng, PM, RE, CE, cats, users, k, user_base=0):
         assert np.all(key[:-1] >= key[1:]), "not descending / NaN not last"
         # optimality: nothing left out beats the k-th returned score by more than the tolerance
         rest = np.delete(np.where(np.isnan(ref), -np.inf, ref), got_ids[:n_valid])
-        if rest.size:
+        if rest.size and np.isfinite(key[n_valid - 1]):
             kth = key[n_valid - 1]
             assert rest.max() <= kth + TOL * max(1.0, abs(kth)), (u, rest.max(), kth)
         # exact ties (bit-equal scores) go to the lower dish id
@@ -63,8 +63,13 @@ def test_topk_users_shapes(E, C, k):
     eng.set_dish_categories(cats)
     users = np.random.default_rng(1).integers(0, U, 45)
     _check(eng, PM, RE, CE, cats, users, k)
-    want = "m2d_topk_mfma" if (C, E) in ((4, 32), (4, 64), (4, 128)) else "m2d_topk_generic"
+    mfma = (C, E) in ((4, 32), (4, 64), (4, 128))
+    want = "m2d_topk_generic" if not mfma else ("m2d_topk_grouped" if k <= 16 else "m2d_topk_mfma")
     assert eng.last_kernel() == want
+    if mfma and k <= 16:
+        eng.set_option("variant", 7)                  # the dense (C+1)E contraction on the same data
+        _check(eng, PM, RE, CE, cats, users, k)
+        assert eng.last_kernel() == "m2d_topk_mfma"
 
 
 def test_topk_dish_splits_and_tail_tiles():
@@ -118,3 +123,33 @@ def test_topk_matches_pair_kernel_scores():
     s, ids = eng.topk_users(users, 10); eng.check()
     pair = eng.score_pairs_bydish(users.repeat_interleave(10), ids.reshape(-1).contiguous()); eng.check()
     assert_scores_close(s.reshape(-1).cpu().numpy(), pair.cpu().numpy())
+
+
+def test_topk_weighted_masks_use_the_dense_kernel():
+    """Masks that are not 0/1 (the placeholder is float: any weight is legal) cannot be pattern-grouped."""
+    from foodrec_amd import ScoringEngine
+    U, I, E = 100, 500, 64
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=21, n_nan=2)
+    cats = cats * np.random.default_rng(3).uniform(0.5, 2.0, cats.shape).astype(np.float32)
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    _check(eng, PM, RE, CE, cats, np.arange(0, 100, 3), 10)
+    assert eng.last_kernel() == "m2d_topk_mfma"
+
+
+def test_topk_grouped_group_boundaries():
+    """Few dishes per pattern (every group ends in a partial tile), a pattern with no dish, many empty masks."""
+    from foodrec_amd import ScoringEngine
+    rng = np.random.default_rng(8)
+    U, I, E = 70, 150, 64
+    PM, RE, CE, _ = _tables(U, I, 4, E, seed=22)
+    pat = rng.choice([0, 1, 2, 3, 5, 8, 15], I)              # patterns 4,6,7,9.. unused; pattern 0 -> NaN
+    cats = ((pat[:, None] >> np.arange(4)[None, :]) & 1).astype(np.float32)
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    for k in (3, 10, 16):
+        _check(eng, PM, RE, CE, cats, np.arange(U), k)
+        assert eng.last_kernel() == "m2d_topk_grouped"
+    cats2 = np.zeros_like(cats); cats2[:5, 1] = 1             # 5 rankable dishes, the rest NaN
+    eng.set_dish_categories(cats2)
+    _check(eng, PM, RE, CE, cats2, np.arange(10), 10)
