@@ -719,6 +719,12 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
             }
             // epilogue: lane holds user j, slots t*32 + 4h + (r&3) + 8(r>>2), ascending in r (see m2d_topk_mfma)
             const int32_t sbase = (int32_t)(t * 32) + 4 * h;
+            // one max tree + one branch settles the tiles in which no lane beats its threshold
+            float mx = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
+            mx = fmaxf(mx, acc[15]);
+            if (!__any(mx > thr)) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = acc[r];
