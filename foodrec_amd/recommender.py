@@ -146,6 +146,44 @@ class Model:
         return table
 
 
+    # -- retrieval and build-defined extensions (no reference counterpart; DESIGN.md sections 4.3-4.4, 8) ---
+    def topk(self, users, k: int = 10):
+        """The k best dishes of every user in `users` over the whole catalogue -- the ranking rule of
+        evaluate.py:63 applied to all dishes instead of 51 candidates.  Needs `set_dish_categories`.
+        Returns (scores float32 [n, k], dish ids int32 [n, k])."""
+        u = _ids(users, "user")
+        ut = u.to(self.device, torch.int32) if isinstance(u, torch.Tensor) else torch.from_numpy(u).to(self.device)
+        s, i = torch.ops.m2d.topk_users(self.engine.id, ut, int(k))
+        self.engine.check()
+        return s.cpu().numpy(), i.cpu().numpy()
+
+    def set_ingredients(self, ingredient_table, offsets, ids, weights=None):
+        """EXTENSION: multi-hot ingredient lists per dish (CSR) replacing the category sum of the high-level path."""
+        self.engine.set_ingredients(ingredient_table, offsets, ids, weights)
+
+    def set_mlp_head(self, W1, b1, W2, b2, w3, b3: float):
+        """EXTENSION: 3-layer head added to the reference score (interaction vector -> 256 -> 64 -> 1)."""
+        self.engine.set_mlp_head(W1, b1, W2, b2, w3, b3)
+
+    def predict_extended(self, user_input, item_input, categories=None, head: bool = False) -> np.ndarray:
+        """EXTENSION predict: ingredient high-level path (`head=False`; `categories=None` -> resident dish masks)
+        or reference score + MLP head (`head=True`, resident dish masks)."""
+        u, d = _ids(user_input, "user"), _ids(item_input, "item")
+        dev = self.device
+        ut = u.to(dev, torch.int32) if isinstance(u, torch.Tensor) else torch.from_numpy(u).to(dev)
+        dt = d.to(dev, torch.int32) if isinstance(d, torch.Tensor) else torch.from_numpy(d).to(dev)
+        if head:
+            out = self.engine.score_pairs_mlp(ut, dt)
+        else:
+            m = None
+            if categories is not None:
+                m = _mask(categories, self.num_categories, len(u))
+                m = m.to(dev) if isinstance(m, torch.Tensor) else torch.from_numpy(m).to(dev)
+            out = self.engine.score_pairs_ingredients(ut, dt, m)
+        self.engine.check()
+        return out.cpu().numpy()
+
+
 class Session:
     """Shim for ``tf.Session`` at the one place the scoring path uses it: ``sess.run(fetches, feed_dict)``
     with ``fetches`` = ``model.logits`` or ``[model.logits]`` (evaluate.py:58)."""
