@@ -9,6 +9,13 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# `import foodrec_amd` refuses to load without libm2d.so (there is no CPU fallback), and the .so is not in
+# git: build it before anything is collected (hipcc cross-compiles gfx950 without a GPU, ~15 s).
+if not os.path.exists(os.path.join(ROOT, "foodrec_amd", "libm2d.so")):
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(ROOT, "foodrec_amd", "csrc"), "-j", "4"], check=True,
+                   stdout=subprocess.DEVNULL)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
@@ -23,6 +30,4 @@ def golden_dir():
 def native_lib():
     """libm2d.so, built on demand (hipcc cross-compiles gfx950 without a GPU)."""
     from foodrec_amd import _native
-    if not os.path.exists(_native.LIB_PATH):
-        _native.build()
     return _native.lib()
