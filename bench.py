@@ -307,6 +307,12 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    if not os.path.exists(os.path.join(ROOT, "foodrec_amd", "libm2d.so")):      # clean checkout: hipcc, ~15 s
+        if local == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        if use_dist:
+            dist.barrier()
     import foodrec_amd
     C, E, U, I, B = 4, a.embed, a.users, a.dishes, a.pairs
     user_base = rank * U
