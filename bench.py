@@ -44,9 +44,12 @@ def parse():
     p.add_argument("--dishes", type=int, default=100_000)
     p.add_argument("--embed", type=int, default=64)
     p.add_argument("--pairs", type=int, default=1 << 22, help="pairs per step per GPU")
-    p.add_argument("--workload", choices=["pairs", "mlp"], default="pairs",
-                   help="pairs = BASELINE configs[1] (reference forward, HBM-bound); mlp = configs[2] "
-                        "(E=128 + build-defined 3-layer head, MFMA-bound; pass --embed 128)")
+    p.add_argument("--workload", choices=["pairs", "ingredients", "mlp", "topk"], default="pairs",
+                   help="pairs = BASELINE configs[1] (reference forward, HBM-bound); ingredients = configs[1] with the "
+                        "build-defined 10k-row ingredient table on the high-level path; mlp = configs[2] (build-defined "
+                        "3-layer head, MFMA-bound; pass --embed 128); topk = configs[3]/[4] retrieval: full-catalogue "
+                        "top-10 for --topk-users users per GPU + all-gather of the results (MFMA-bound)")
+    p.add_argument("--ingredients", type=int, default=10_000, help="rows of the ingredient table (workload ingredients)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     p.add_argument("--topk-users", type=int, default=65536, help="users in the catalogue top-k side leg (0 = skip)")
@@ -72,17 +75,16 @@ def make_inputs(torch, dev, U, I, C, E, B, seed, user_base):
     return PM, RE, CE, users, items, cats.contiguous()
 
 
-def time_steps(torch, eng, users, items, cats, out, steps, mlp=False):
+def time_steps(torch, eng, users, items, cats, out, steps, step=None):
     """K launches; per-launch HIP-event durations (ms) on the current stream + wall seconds."""
+    if step is None:
+        step = lambda: eng.score_pairs(users, items, cats, out=out)
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     evs[0].record()
     for i in range(steps):
-        if mlp:
-            eng.score_pairs_mlp(users, items, out=out)
-        else:
-            eng.score_pairs(users, items, cats, out=out)
+        step()
         evs[i + 1].record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -326,13 +328,43 @@ def main():
         eng.set_option(k, int(v))
     out = torch.empty(B, dtype=torch.float32, device=dev)
     mlp = a.workload == "mlp"
-    if mlp:
-        g = torch.Generator(device=dev); g.manual_seed(20260101 + 3)
-        K = (C + 1) * E
+    wl = a.workload
+    g = torch.Generator(device=dev); g.manual_seed(20260101 + 3)          # same on every rank: replicated tables
+    K = (C + 1) * E
+    if wl in ("mlp", "topk"):
         pat = torch.randint(1, 2 ** C, (I,), generator=g, device=dev, dtype=torch.int32)
         eng.set_dish_categories(((pat[:, None] >> torch.arange(C, device=dev, dtype=torch.int32)[None, :]) & 1).float())
+    if wl == "mlp":
         rn = lambda *shape: torch.randn(shape, generator=g, device=dev)
         eng.set_mlp_head(rn(K, 256) / K ** 0.5, rn(256) * 0.1, rn(256, 64) / 16.0, rn(64) * 0.1, rn(64) / 8.0, 0.0)
+    if wl == "ingredients":
+        R = a.ingredients
+        lens = torch.randint(1, 21, (I,), generator=g, device=dev)          # 1..20 ingredients per dish (build-chosen)
+        off = torch.zeros(I + 1, dtype=torch.int32, device=dev)
+        off[1:] = torch.cumsum(lens, 0).to(torch.int32)
+        nnz = int(off[-1].item())
+        eng.set_ingredients(torch.randn((R, E), generator=g, device=dev) * E ** -0.5, off,
+                            torch.randint(0, R, (nnz,), generator=g, device=dev, dtype=torch.int32))
+    tk_users = None
+    if wl == "topk":
+        n_tk = min(a.topk_users if a.topk_users > 0 else 65536, U)
+        tk_users = (torch.randperm(U, generator=torch.Generator(device=dev).manual_seed(11 + rank), device=dev)[:n_tk]
+                    .to(torch.int32) + int(user_base)).contiguous()
+        gs = torch.empty((world * n_tk, 10), dtype=torch.float32, device=dev)
+        gi = torch.empty((world * n_tk, 10), dtype=torch.int32, device=dev)
+
+    def step():
+        if wl == "pairs":
+            eng.score_pairs(users, items, cats, out=out)
+        elif wl == "ingredients":
+            eng.score_pairs_ingredients(users, items, cats, out=out)
+        elif wl == "mlp":
+            eng.score_pairs_mlp(users, items, out=out)
+        else:                                                            # retrieval: per-shard top-k, then the exchange
+            s_, i_ = eng.topk_users(tk_users, 10)
+            if use_dist:
+                dist.all_gather_into_tensor(gs, s_)
+                dist.all_gather_into_tensor(gi, i_)
 
     def barrier():
         torch.cuda.synchronize()
@@ -341,13 +373,10 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        if mlp:
-            eng.score_pairs_mlp(users, items, out=out)
-        else:
-            eng.score_pairs(users, items, cats, out=out)
+        step()
     eng.check()
     barrier()
-    wall, per_launch_ms = time_steps(torch, eng, users, items, cats, out, a.steps, mlp)
+    wall, per_launch_ms = time_steps(torch, eng, users, items, cats, out, a.steps, step)
     barrier()
     eng.check()
     t = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -357,7 +386,7 @@ def main():
 
     # user-sharded retrieval: per-shard top-k + RCCL all-gather of the results (outside the timed region)
     topk_ag = None
-    if use_dist and a.topk_users > 0 and not a.no_side:
+    if use_dist and a.topk_users > 0 and not a.no_side and wl == "pairs":
         try:
             topk_ag = sharded_topk_leg(torch, dist, eng, U, I, C, E, dev, user_base, min(a.topk_users, U), world)
         except Exception as e:                                         # noqa: BLE001 -- never lose the headline line
@@ -391,8 +420,9 @@ def main():
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        units = (tk_users.numel() * I) if wl == "topk" else B           # (user, dish) pairs scored per step per GPU
         line = {
-            "metric": "scored (user,dish) pairs/sec", "value": world * B * a.steps / wall_max, "unit": "pairs/s",
+            "metric": "scored (user,dish) pairs/sec", "value": world * units * a.steps / wall_max, "unit": "pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall_max / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic %d users x %d dishes per GPU, C=%d categories, "
@@ -418,14 +448,37 @@ def main():
                                 "traffic": None, "kernel_avg_ms": avg_ms, "flop_per_pair": fl, "pairs_per_launch": B,
                                 "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact)",
                                 "hbm_algorithmic_GBps": (2 * K * 4 + 12) * B / (avg_ms * 1e-3) / 1e9}
-        if not a.no_side and not mlp:
+        if wl == "ingredients":
+            bpp_i = (C + 3) * E * 4 + C * 4 + 12                       # one extra E-float row per pair
+            ach = bpp_i * B / (avg_ms * 1e-3) / 1e9
+            line["config"]["workload"] = ("BASELINE configs[1] WITH the build-defined ingredient table: %d users x %d dishes "
+                                          "x %d ingredients per GPU, 1-20 ingredients per dish, E=%d; high-level path from the "
+                                          "per-dish multi-hot ingredient sum (hoisted to a per-table segment-sum kernel), "
+                                          "low-level path and blend as Model_Recommender.py:82-96; no reference counterpart"
+                                          % (U, I, a.ingredients, E))
+            line["roofline"].update({"achieved": ach, "frac": ach / HBM_PEAK_GBS, "algorithmic_bytes_per_pair": bpp_i,
+                                     "traffic": None})
+        if wl == "topk":
+            kern = eng.last_kernel()
+            fl = (2.0 * E if kern == "m2d_topk_grouped" else 2.0 * K) * units
+            tf = fl / (avg_ms * 1e-3) / 1e12
+            line["config"]["workload"] = ("BASELINE configs[3]/[4] retrieval: full-catalogue top-10 for %d users per GPU over %d "
+                                          "replicated dishes (users from this GPU's %d-user shard), E=%d, then all-gather of "
+                                          "[users,10] x (f32 score, i32 id); build-defined generalisation of evaluate.py:39-63"
+                                          % (tk_users.numel(), I, U, E))
+            line["config"]["kernel"] = kern
+            line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                                "traffic": None, "step_avg_ms": avg_ms, "flop_per_pair_executed": fl / units,
+                                "dense_equivalent_tflops": 2.0 * K * units / (avg_ms * 1e-3) / 1e12,
+                                "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact)"}
+        if not a.no_side and wl == "pairs":
             nr, probe = side_measurements(torch, eng, PM, U, I, C, E, dev, user_base)
             line["roofline"]["no_reuse"] = nr
             line["roofline"]["stream_read_probe"] = probe
             line["roofline"]["frac_of_stream_probe"] = achieved / probe["GBps"]
-        if a.topk_users > 0 and not a.no_side and not mlp:
+        if a.topk_users > 0 and not a.no_side and wl == "pairs":
             line["catalogue_topk"] = catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U))
-        if world == 1 and not a.no_side and not mlp and not a.no_cpu_baseline:
+        if world == 1 and not a.no_side and wl == "pairs" and not a.no_cpu_baseline:
             try:
                 line["evaluator"] = evaluator_leg(torch, dev)
             except Exception as e:                                     # noqa: BLE001
@@ -434,7 +487,7 @@ def main():
             line["sharded_topk_allgather"] = topk_ag
         if a.unique_users:
             line["config"]["workload"] += " [--unique-users: every user at most once per step]"
-        if world == 1 and not a.no_cpu_baseline and not mlp:
+        if world == 1 and not a.no_cpu_baseline and wl == "pairs":
             cb, ref, Bc = cpu_baseline(torch, PM, RE, CE, users, items, cats, a.cpu_seconds)
             # the baseline doubles as a live parity check of the timed kernel's output on the same pairs
             got = out[:Bc].cpu()
