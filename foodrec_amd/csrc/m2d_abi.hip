@@ -67,6 +67,7 @@ void release(m2d_engine *h)
     if (h->own_dish_cats && h->dish_cats) (void)hipFree((void *)h->dish_cats);
     if (h->dish_vec) (void)hipFree(h->dish_vec);
     if (h->grp_rs) (void)hipFree(h->grp_rs);
+    if (h->grp_rs16) (void)hipFree(h->grp_rs16);
     if (h->grp_perm) (void)hipFree(h->grp_perm);
     if (h->grp_tile_info) (void)hipFree(h->grp_tile_info);
     if (h->grp_work) (void)hipFree(h->grp_work);
@@ -422,6 +423,7 @@ int m2d_set_option(m2d_engine *h, const char *name, int64_t value)
     else if (!strcmp(name, "nt_loads")) h->opt_nt = (int)value;
     else if (!strcmp(name, "blocks_per_cu")) h->opt_blocks_per_cu = (int)value;
     else if (!strcmp(name, "variant")) h->opt_variant = (int)value;
+    else if (!strcmp(name, "topk_bf16x3")) h->opt_topk_bf16x3 = (int)value;
     else return fail(h, M2D_ERR_INVALID_ARG, "m2d_set_option: unknown option");
     return M2D_OK;
 }
@@ -433,6 +435,7 @@ int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value)
     else if (!strcmp(name, "nt_loads")) *value = h->opt_nt;
     else if (!strcmp(name, "blocks_per_cu")) *value = h->opt_blocks_per_cu;
     else if (!strcmp(name, "variant")) *value = h->opt_variant;
+    else if (!strcmp(name, "topk_bf16x3")) *value = h->opt_topk_bf16x3;
     else if (!strcmp(name, "num_cu")) *value = h->num_cu;
     else return M2D_ERR_INVALID_ARG;
     return M2D_OK;

@@ -563,20 +563,30 @@ __global__ __launch_bounds__(256) void m2d_grp_scatter(const float *cats, int64_
     }
 }
 
-// one wave per slot: RS[slot] = RE[perm[slot]] (zeros for padding)
+// one wave per slot: RS[slot] = RE[perm[slot]] (zeros for padding), plus the split-bf16 image used by
+// m2d_topk_grouped_bf16: per 32-row tile [hi: 32 x E bf16][lo: 32 x E bf16], x ~= hi + lo to 2^-17 |x|
 __global__ __launch_bounds__(256) void m2d_grp_gather(const float *re, const int32_t *perm, int64_t slots, int E,
-                                                      float *rs)
+                                                      float *rs, __bf16 *rs16)
 {
     const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= slots) return;
     const int32_t d = perm[slot];
-    for (int e = threadIdx.x & 63; e < E; e += 64) rs[slot * E + e] = d >= 0 ? re[(size_t)d * E + e] : 0.f;
+    __bf16 *hi = rs16 + ((slot >> 5) * 64 + (slot & 31)) * (size_t)E;
+    __bf16 *lo = hi + 32 * (size_t)E;
+    for (int e = threadIdx.x & 63; e < E; e += 64) {
+        const float x = d >= 0 ? re[(size_t)d * E + e] : 0.f;
+        rs[slot * E + e] = x;
+        const __bf16 xh = (__bf16)x;
+        hi[e] = xh;
+        lo[e] = (__bf16)(x - (float)xh);
+    }
 }
 
 struct GroupedArgs {
     const float *pm;         // [U, (C+1) E]
     const float *ce;         // [C, E]
     const float *rs;         // [slots, E]   Recipe_Embedding rows sorted by (pattern, dish id)
+    const __bf16 *rs16;      // the same rows as split bf16 (hi | lo blocks per 32-row tile)
     const int32_t *perm;     // [slots]      slot -> dish id (-1 = padding)
     const int32_t *tile_info;
     const int32_t *users;
@@ -791,6 +801,234 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
     }
 }
 
+// ---- split-bf16 ("bf16x3") variant of m2d_topk_grouped ---------------------------------------------------
+// Exact-f32 MFMA runs at 1/16 of the bf16 matrix rate.  Here every operand is split x = hi + lo into two bf16
+// and the product is a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+// (lo*lo, <= 2^-18 |a||b|, is dropped; bf16 x bf16 products are exact in fp32).  Per-product relative
+// error <= ~1.2e-5, so the score error is ~1e-5 of sqrt(sum (a_k b_k)^2) -- inside the 1e-4 parity bar, and
+// checked against the float64 restatement by the same tests as the exact kernel.  3 MFMAs of 16 k-values
+// in 96 cycles replace 8 f32 MFMAs in 512.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int E, int WAVES, int KR>
+__global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs p)
+{
+    constexpr int C = 4;
+    constexpr int KS = E / 16;                             // k-steps (16 k-values) per tile
+    constexpr int S8 = E / 8;                              // 16-B slots per bf16 row
+    constexpr int RPB = 256 / (E * 2) > 0 ? 256 / (E * 2) : 1;   // rows per 256-B bank row
+    constexpr int TPS = E == 64 ? 8 : 4;                   // tiles per stage: 64 KiB stages
+    constexpr int ROW_BYTES = E * 2, TILE_BYTES = 64 * ROW_BYTES, STAGE_BYTES = TPS * TILE_BYTES;
+    constexpr int PIECES = STAGE_BYTES / 1024;
+    constexpr int S4 = E / 4;                              // float4 per f32 row of Personal_Memory
+
+    extern __shared__ __align__(16) unsigned char smem8[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int k = p.k;
+
+    const int64_t uidx = ((int64_t)blockIdx.x * WAVES + wave) * 32 + j;
+    const bool uvalid = uidx < p.nU;
+    int64_t ul = 0;
+    if (uvalid) {
+        const int32_t uid = p.users[uidx];
+        ul = (int64_t)uid - p.user_base;
+        if (ul < 0 || ul >= p.U) {
+            if (atomicCAS(&p.err[0], 0, M2D_ERR_BAD_USER_ID) == 0) {
+                p.err[1] = uid;
+                p.err[2] = (int32_t)(uidx & 0xffffffff);
+                p.err[3] = (int32_t)(uidx >> 32);
+            }
+            ul = 0;
+        }
+    }
+    const v4f *pmu = reinterpret_cast<const v4f *>(p.pm) + (size_t)ul * ((C + 1) * S4);
+    float hc[C];
+    {
+        const v4f *ce4 = reinterpret_cast<const v4f *>(p.ce);
+#pragma unroll
+        for (int c = 0; c < C; ++c) hc[c] = 0.f;
+#pragma unroll 1
+        for (int q = 0; q < S4; ++q) {
+            const v4f u = pmu[q];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const v4f w = ce4[c * S4 + q];
+                hc[c] += (u.x * w.x + u.y * w.y) + (u.z * w.z + u.w * w.w);
+            }
+        }
+    }
+    bf16x8 wh[KS], wl[KS];                                 // w_P[u] for k = 16 s + 8 h + (0..7), split hi / lo
+    float alpha = 0.f;
+    int cur_pat = -1;
+
+    float rs[KR];
+    int32_t ri[KR];
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        rs[i] = -INFINITY;
+        ri[i] = -1;
+    }
+    float thr = -INFINITY;
+
+    const int64_t per = (p.tiles + p.nsplit - 1) / p.nsplit;
+    const int64_t t_begin = (int64_t)blockIdx.y * per;
+    const int64_t t_end = min(p.tiles, t_begin + per);
+    const int64_t nstages = t_end > t_begin ? (t_end - t_begin + TPS - 1) / TPS : 0;
+
+    auto issue_stage = [&](int64_t s, int buf) {
+        const unsigned char *src0 = reinterpret_cast<const unsigned char *>(p.rs16) + (size_t)(t_begin + s * TPS) * TILE_BYTES;
+        unsigned char *dst = smem8 + (size_t)buf * STAGE_BYTES;
+        for (int pc = wave; pc < PIECES; pc += WAVES) {
+            const int g = pc * 64 + lane;                  // physical 16-B slot in the stage image
+            const int rw = g / S8, sl = g - rw * S8;       // stage row (hi and lo rows alike), slot in row
+            const int q = sl ^ ((rw / RPB) & (S8 - 1));    // logical slot that must land here
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src0 + (size_t)rw * ROW_BYTES + q * 16),
+                                             (void __attribute__((address_space(3))) *)(dst + pc * 1024), 16, 0, 0);
+        }
+    };
+
+    if (nstages > 0) issue_stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int key = (j / RPB) & (S8 - 1);                  // this lane's row swizzle (same for hi and lo rows)
+    v16f acc;
+    for (int64_t s = 0; s < nstages; ++s) {
+        const int buf = (int)(s & 1);
+        if (s + 1 < nstages) issue_stage(s + 1, buf ^ 1);
+        for (int tl = 0; tl < TPS; ++tl) {
+            const int64_t t = t_begin + s * TPS + tl;
+            if (t >= t_end) break;                                      // wave-uniform
+            const int info = __builtin_amdgcn_readfirstlane(p.tile_info[t]);
+            const int pat = info & 255, nvalid = info >> 8;
+            if (pat != cur_pat) {                                       // at most 2^C - 1 times per block
+                cur_pat = pat;
+                const float inv_n = 1.0f / (float)__builtin_popcount(pat);
+                float hs = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) hs += ((pat >> c) & 1) ? hc[c] : 0.f;
+                alpha = p.a * (hs * inv_n);
+                const float beta = p.b * inv_n;
+#pragma unroll 1
+                for (int ks = 0; ks < KS; ++ks) {                       // rolled over k-steps: 2 x C loads in flight
+                    v4f w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        if ((pat >> c) & 1) {
+                            const v4f *row = pmu + (c + 1) * S4 + 4 * ks + 2 * h;
+                            w0 += row[0];
+                            w1 += row[1];
+                        }
+                    }
+                    w0 *= beta;
+                    w1 *= beta;
+                    const float x[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                    bf16x8 vh, vl;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const __bf16 xh = (__bf16)x[i];
+                        vh[i] = xh;
+                        vl[i] = (__bf16)(x[i] - (float)xh);
+                    }
+                    // static register indices: select by compare (KS <= 8)
+#pragma unroll
+                    for (int q = 0; q < KS; ++q) {
+                        if (q == ks) {
+                            wh[q] = vh;
+                            wl[q] = vl;
+                        }
+                    }
+                }
+            }
+            if (nvalid == 32) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = alpha;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = (4 * h + (r & 3) + 8 * (r >> 2) < nvalid) ? alpha : -INFINITY;
+            }
+            const unsigned char *img = smem8 + (size_t)buf * STAGE_BYTES + (size_t)tl * TILE_BYTES + (size_t)j * ROW_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int q = (2 * ks + h) ^ key;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(img + q * 16);
+                const bf16x8 al = *reinterpret_cast<const bf16x8 *>(img + 32 * ROW_BYTES + q * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, wh[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wl[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh[ks], acc, 0, 0, 0);
+            }
+            const int32_t sbase = (int32_t)(t * 32) + 4 * h;
+            float mx = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
+            mx = fmaxf(mx, acc[15]);
+            if (!__any(mx > thr)) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[r];
+                const bool cand = v > thr;
+                if (__any(cand)) {
+                    float xs = v;
+                    int32_t xi = sbase + (r & 3) + 8 * (r >> 2);
+                    bool placed = false;
+#pragma unroll
+                    for (int i = 0; i < KR; ++i) {
+                        const bool sw = cand && (placed || xs > rs[i]);
+                        placed = placed || sw;
+                        const float ts = rs[i];
+                        const int32_t ti = ri[i];
+                        rs[i] = sw ? xs : ts;
+                        ri[i] = sw ? xi : ti;
+                        xs = sw ? ts : xs;
+                        xi = sw ? ti : xi;
+                    }
+                    thr = rs[KR - 1];
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    float *ls = reinterpret_cast<float *>(smem8) + (size_t)wave * 2 * KR * 64;   // aliases stage 0
+    int32_t *li = reinterpret_cast<int32_t *>(ls + (size_t)KR * 64);
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        ls[i * 64 + lane] = rs[i];
+        li[i * 64 + lane] = ri[i] >= 0 ? p.perm[ri[i]] : -1;
+        cnt += ri[i] >= 0 ? 1 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int cnt_hi = __shfl(cnt, j + 32, 64);
+    if (h == 0 && uvalid) {
+        const int ca = cnt, cb = cnt_hi;
+        int pa = 0, pb = 0;
+        float *os = p.out_scores + ((size_t)uidx * p.nsplit + blockIdx.y) * k;
+        int32_t *oi = p.out_ids + ((size_t)uidx * p.nsplit + blockIdx.y) * k;
+        for (int o = 0; o < k; ++o) {
+            const bool ha = pa < ca, hb = pb < cb;
+            if (!ha && !hb) {
+                os[o] = __builtin_nanf("");
+                oi[o] = -1;
+                continue;
+            }
+            const float sa = ha ? ls[pa * 64 + lane] : 0.f, sb = hb ? ls[pb * 64 + lane + 32] : 0.f;
+            const int32_t ia = ha ? li[pa * 64 + lane] : 0, ib = hb ? li[pb * 64 + lane + 32] : 0;
+            bool take_a;
+            if (!hb) take_a = true;
+            else if (!ha) take_a = false;
+            else take_a = sa > sb || (sa == sb && ia < ib);
+            os[o] = take_a ? sa : sb;
+            oi[o] = take_a ? ia : ib;
+            pa += take_a ? 1 : 0;
+            pb += take_a ? 0 : 1;
+        }
+    }
+}
+
 int ensure_grouped(m2d_engine *h, hipStream_t st)
 {
     if (h->grp_valid) return M2D_OK;
@@ -799,10 +1037,11 @@ int ensure_grouped(m2d_engine *h, hipStream_t st)
     const int64_t max_tiles = (I + 31) / 32 + GRP_MAXPAT;
     const int64_t cap_rows = (max_tiles + 16) * 32;          // + one stage of zero rows past the last tile
     if (h->grp_cap_rows != cap_rows || !h->grp_rs) {
-        for (void *q : {(void *)h->grp_rs, (void *)h->grp_perm, (void *)h->grp_tile_info, (void *)h->grp_work})
+        for (void *q : {(void *)h->grp_rs, (void *)h->grp_rs16, (void *)h->grp_perm, (void *)h->grp_tile_info, (void *)h->grp_work})
             if (q) M2D_HIP_TRY(h, hipFree(q));
-        h->grp_rs = nullptr; h->grp_perm = nullptr; h->grp_tile_info = nullptr; h->grp_work = nullptr;
+        h->grp_rs = nullptr; h->grp_rs16 = nullptr; h->grp_perm = nullptr; h->grp_tile_info = nullptr; h->grp_work = nullptr;
         M2D_HIP_TRY(h, hipMalloc((void **)&h->grp_rs, (size_t)cap_rows * h->E * sizeof(float)));
+        M2D_HIP_TRY(h, hipMalloc((void **)&h->grp_rs16, (size_t)cap_rows * h->E * 4));
         M2D_HIP_TRY(h, hipMalloc((void **)&h->grp_perm, (size_t)cap_rows * sizeof(int32_t)));
         M2D_HIP_TRY(h, hipMalloc((void **)&h->grp_tile_info, (size_t)max_tiles * sizeof(int32_t)));
         M2D_HIP_TRY(h, hipMalloc((void **)&h->grp_work, ((size_t)nblk * GRP_MAXPAT + 64) * sizeof(int32_t)));
@@ -815,7 +1054,7 @@ int ensure_grouped(m2d_engine *h, hipStream_t st)
     hipLaunchKernelGGL(m2d_grp_scan, dim3(1), dim3(GRP_MAXPAT), 0, st, blk_hist, nblk, grp, h->grp_tile_info);
     hipLaunchKernelGGL(m2d_grp_scatter, dim3(nblk), dim3(256), 0, st, h->dish_cats, I, h->C, blk_hist, grp, h->grp_perm);
     hipLaunchKernelGGL(m2d_grp_gather, dim3((unsigned)((cap_rows + 3) / 4)), dim3(256), 0, st, h->re, h->grp_perm,
-                       cap_rows, h->E, h->grp_rs);
+                       cap_rows, h->E, h->grp_rs, reinterpret_cast<__bf16 *>(h->grp_rs16));
     M2D_HIP_TRY(h, hipGetLastError());
     int32_t host[3] = {0, 0, 0};   // tiles, slots, flags  (a table build may synchronise)
     M2D_HIP_TRY(h, hipMemcpyAsync(host, grp + 16, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -847,7 +1086,7 @@ int pick_splits(m2d_engine *h, int64_t ublocks, int64_t tiles, int64_t min_tiles
     return nsplit;
 }
 
-template <int E8, int WAVES, int KR>
+template <int E8, int WAVES, int KR, bool BF16X3>
 int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, float *final_s, int32_t *final_i,
                    hipStream_t st)
 {
@@ -855,7 +1094,8 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     constexpr int TPS = E <= 32 ? 16 : (E == 64 ? 8 : 4);
     const size_t lds = (size_t)2 * TPS * 32 * E * sizeof(float);
     GroupedArgs a;
-    a.pm = h->pm; a.ce = h->ce; a.rs = h->grp_rs; a.perm = h->grp_perm; a.tile_info = h->grp_tile_info;
+    a.pm = h->pm; a.ce = h->ce; a.rs = h->grp_rs; a.rs16 = reinterpret_cast<const __bf16 *>(h->grp_rs16);
+    a.perm = h->grp_perm; a.tile_info = h->grp_tile_info;
     a.users = users; a.nU = nU; a.U = h->U; a.user_base = h->user_base; a.k = k; a.tiles = h->grp_tiles;
     a.a = h->a; a.b = h->b; a.err = h->err_dev;
     const int64_t ublocks = (nU + 32 * WAVES - 1) / (32 * WAVES);
@@ -875,9 +1115,15 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         a.out_scores = final_s;
         a.out_ids = final_i;
     }
-    auto kern = m2d_topk_grouped<E8, WAVES, KR>;
-    M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(WAVES * 64), lds, st, a);
+    if constexpr (BF16X3) {
+        auto kern = m2d_topk_grouped_bf16<E, WAVES, KR>;
+        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(WAVES * 64), lds, st, a);
+    } else {
+        auto kern = m2d_topk_grouped<E8, WAVES, KR>;
+        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(WAVES * 64), lds, st, a);
+    }
     M2D_HIP_TRY(h, hipGetLastError());
     if (nsplit > 1) {
         hipLaunchKernelGGL(m2d_topk_merge_splits, dim3((unsigned)((nU + 127) / 128)), dim3(128), 0, st, a.out_scores,
@@ -887,7 +1133,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     hipLaunchKernelGGL(m2d_topk_fill_absent, dim3((unsigned)((nU + 127) / 128)), dim3(128), 0, st, final_s, final_i, nU, k,
                        h->I);
     M2D_HIP_TRY(h, hipGetLastError());
-    h->last_kernel = "m2d_topk_grouped";
+    h->last_kernel = BF16X3 ? "m2d_topk_grouped_bf16x3" : "m2d_topk_grouped";
     return M2D_OK;
 }
 
@@ -955,11 +1201,13 @@ int m2d_launch_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32
         h->opt_variant != 8 && h->opt_variant != 9) {
         if ((rc = ensure_grouped(h, stream)) != M2D_OK) return rc;
         if (h->grp_binary && h->grp_tiles > 0) {
-#define M2D_GRP(EV)                                                                                      \
-    if (h->E == EV)                                                                                      \
-        return k <= 10 ? launch_grouped<EV / 8, 8, 10>(h, users, nU, k, out_scores, out_ids, stream)        \
-                       : launch_grouped<EV / 8, 8, 16>(h, users, nU, k, out_scores, out_ids, stream);
-            M2D_GRP(32) M2D_GRP(64) M2D_GRP(128)
+            // "topk_bf16x3" option: 1 = split-bf16 MFMA (E = 64 / 128), 0 = exact-f32 MFMA
+            const bool x3 = h->opt_topk_bf16x3 != 0 && (h->E == 64 || h->E == 128);
+#define M2D_GRP(EV, X3)                                                                                       \
+    if (h->E == EV && x3 == X3)                                                                               \
+        return k <= 10 ? launch_grouped<EV / 8, 8, 10, X3>(h, users, nU, k, out_scores, out_ids, stream)         \
+                       : launch_grouped<EV / 8, 8, 16, X3>(h, users, nU, k, out_scores, out_ids, stream);
+            M2D_GRP(32, false) M2D_GRP(64, false) M2D_GRP(128, false) M2D_GRP(64, true) M2D_GRP(128, true)
 #undef M2D_GRP
         }
     }

@@ -49,6 +49,7 @@ struct m2d_engine {
 
     // pattern-grouped retrieval tables (0/1 masks only; built lazily by m2d_topk_users)
     float *grp_rs = nullptr;            // [grp_cap_rows, E] Recipe_Embedding rows sorted by (mask pattern, dish id)
+    void *grp_rs16 = nullptr;           // the same rows split into bf16 hi | lo blocks per 32-row tile
     int32_t *grp_perm = nullptr;        // [grp_cap_rows]    slot -> dish id, -1 = padding
     int32_t *grp_tile_info = nullptr;   // [tiles]           pattern | valid rows << 8
     int32_t *grp_work = nullptr;        // block histograms / group offsets / flags
@@ -64,6 +65,7 @@ struct m2d_engine {
     int opt_nt = 1;
     int opt_blocks_per_cu = 8;
     int opt_variant = 0;
+    int opt_topk_bf16x3 = 0;            // retrieval on split-bf16 MFMA instead of exact-f32 MFMA
 
     std::string last_error;
     const char *last_kernel = "";

@@ -153,3 +153,30 @@ def test_topk_grouped_group_boundaries():
     cats2 = np.zeros_like(cats); cats2[:5, 1] = 1             # 5 rankable dishes, the rest NaN
     eng.set_dish_categories(cats2)
     _check(eng, PM, RE, CE, cats2, np.arange(10), 10)
+
+
+@pytest.mark.parametrize("E", [64, 128])
+@pytest.mark.parametrize("k", [1, 10, 16])
+def test_topk_split_bf16_variant(E, k):
+    """The opt-in split-bf16 ("bf16x3") retrieval kernel obeys the same 1e-4 bar as the exact-f32 one."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    U, I = 200, 3000
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=E + k + 1, n_nan=5, dup=40)
+    PM *= 3.0                                            # |score| up to a few units: the tolerance is relative there
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    eng.set_option("topk_bf16x3", 1)
+    users = np.random.default_rng(2).integers(0, U, 90)
+    _check(eng, PM, RE, CE, cats, users, k)
+    assert eng.last_kernel() == "m2d_topk_grouped_bf16x3"
+    for forced in (101, 104):
+        eng.set_option("variant", forced)
+        _check(eng, PM, RE, CE, cats, users, k)
+    # measured error of the split product against the exact kernel on the same (user, dish) pairs
+    eng.set_option("variant", 0)
+    s3, i3 = eng.topk_users(torch.arange(U, dtype=torch.int32, device="cuda"), k); eng.check()
+    exact = eng.score_pairs_bydish(torch.arange(U, dtype=torch.int32, device="cuda").repeat_interleave(k),
+                                   i3.reshape(-1).contiguous()); eng.check()
+    err = (s3.reshape(-1) - exact).abs().max().item()
+    assert err < 3e-5, err
