@@ -154,13 +154,18 @@ def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10):
     kernel = eng.last_kernel()
     dense = 2.0 * (C + 1) * E * n_users * I                 # the [users x (C+1)E] . [(C+1)E x dishes] contraction
     # the pattern-grouped kernel (0/1 masks) contracts over E only: price it on the flops it executes
-    flops = 2.0 * E * n_users * I if kernel == "m2d_topk_grouped" else dense
+    flops = 2.0 * E * n_users * I if kernel.startswith("m2d_topk_grouped") else dense
+    x3 = kernel.endswith("bf16x3")                         # 3 bf16 MFMAs per 16 k-values: 6*E flop per pair on the bf16 pipe
     return {"users": n_users, "dishes": I, "k": k, "median_ms": ms, "users_per_s": n_users / ms * 1e3,
             "pairs_per_s": n_users * I / ms * 1e3, "tflops": flops / ms / 1e9,
             "dense_equivalent_tflops": dense / ms / 1e9,
-            "roofline": {"bound": "mfma", "achieved": flops / ms / 1e9, "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": flops / ms / 1e9 / 157.3, "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact)",
-                         "flop_per_pair": flops / n_users / I},
+            "roofline": ({"bound": "mfma", "achieved": 3 * flops / ms / 1e9, "peak": 2500.0, "unit": "TFLOP/s",
+                          "frac": 3 * flops / ms / 1e9 / 2500.0, "flop_per_pair": 3 * flops / n_users / I,
+                          "dtype": "split bf16 (x = hi + lo, 3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
+                          "note": "epilogue-bound (running top-k), not MFMA-bound: see DESIGN.md 4.4"} if x3 else
+                         {"bound": "mfma", "achieved": flops / ms / 1e9, "peak": 157.3, "unit": "TFLOP/s",
+                          "frac": flops / ms / 1e9 / 157.3, "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact)",
+                          "flop_per_pair": flops / n_users / I}),
             "kernel": kernel}
 
 
@@ -460,17 +465,22 @@ def main():
                                      "traffic": None})
         if wl == "topk":
             kern = eng.last_kernel()
-            fl = (2.0 * E if kern == "m2d_topk_grouped" else 2.0 * K) * units
+            x3 = kern.endswith("bf16x3")
+            fl = (2.0 * E * (3 if x3 else 1) if kern.startswith("m2d_topk_grouped") else 2.0 * K) * units
             tf = fl / (avg_ms * 1e-3) / 1e12
+            peak = 2500.0 if x3 else 157.3
             line["config"]["workload"] = ("BASELINE configs[3]/[4] retrieval: full-catalogue top-10 for %d users per GPU over %d "
                                           "replicated dishes (users from this GPU's %d-user shard), E=%d, then all-gather of "
                                           "[users,10] x (f32 score, i32 id); build-defined generalisation of evaluate.py:39-63"
                                           % (tk_users.numel(), I, U, E))
             line["config"]["kernel"] = kern
-            line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+            line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                                 "traffic": None, "step_avg_ms": avg_ms, "flop_per_pair_executed": fl / units,
                                 "dense_equivalent_tflops": 2.0 * K * units / (avg_ms * 1e-3) / 1e12,
-                                "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact)"}
+                                "dtype": ("split bf16 (3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate; the ranking epilogue, "
+                                          "not the MFMA pipe, bounds this kernel)" if x3 else
+                                          "f32 (v_mfma_f32_32x32x2_f32, exact)")}
+            line["dtype"] = "bf16x3" if x3 else "f32"
         if not a.no_side and wl == "pairs":
             nr, probe = side_measurements(torch, eng, PM, U, I, C, E, dev, user_base)
             line["roofline"]["no_reuse"] = nr

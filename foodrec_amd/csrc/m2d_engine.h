@@ -65,7 +65,7 @@ struct m2d_engine {
     int opt_nt = 1;
     int opt_blocks_per_cu = 8;
     int opt_variant = 0;
-    int opt_topk_bf16x3 = 0;            // retrieval on split-bf16 MFMA instead of exact-f32 MFMA
+    int opt_topk_bf16x3 = 1;            // retrieval (build-defined) on split-bf16 MFMA; 0 = exact-f32 MFMA
 
     std::string last_error;
     const char *last_kernel = "";

@@ -89,7 +89,9 @@ int m2d_rank_candidates(m2d_engine *h, const int32_t *users, const int32_t *item
 
 /* Full-catalogue retrieval (build-defined generalisation of evaluate.py:39-63 to every dish; BASELINE
  * config 5): for each of nU users the k best dishes over all I, descending score, ties to the lower
- * dish id, NaN scores last.  out_scores f32[nU, k], out_ids i32[nU, k].  1 <= k <= 64. */
+ * dish id, NaN scores last.  out_scores f32[nU, k], out_ids i32[nU, k].  1 <= k <= 64.
+ * Scores agree with m2d_score_pairs_bydish within the 1e-4 bar, not bit for bit (factored form; see the
+ * "topk_bf16x3" option below). */
 int m2d_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, float *out_scores,
                    int32_t *out_ids, void *stream);
 
@@ -144,8 +146,11 @@ int m2d_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_t *item
  * bad_value / bad_index (host pointers, may be NULL) receive the offending id and its position. */
 int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_index);
 
-/* Kernel-selection knobs for benchmarking ("prefetch", "nt_loads", "blocks_per_cu", "variant").
- * Unknown names return M2D_ERR_INVALID_ARG.  Results never depend on them. */
+/* Kernel-selection knobs for benchmarking ("prefetch", "nt_loads", "blocks_per_cu", "variant"): results
+ * never depend on them.  One numerical switch: "topk_bf16x3" (default 1) lets m2d_topk_users contract on
+ * split-bf16 MFMA (x = hi + lo, three bf16 products, fp32 accumulation; score error ~1e-5 relative, inside
+ * the 1e-4 bar) where the mask table is 0/1 and E is 64 or 128; 0 forces the exact-f32 MFMA kernels.
+ * m2d_score_pairs* (the reference path) is always exact float32.  Unknown names: M2D_ERR_INVALID_ARG. */
 int m2d_set_option(m2d_engine *h, const char *name, int64_t value);
 int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value);
 

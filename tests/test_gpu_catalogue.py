@@ -64,9 +64,13 @@ def test_topk_users_shapes(E, C, k):
     users = np.random.default_rng(1).integers(0, U, 45)
     _check(eng, PM, RE, CE, cats, users, k)
     mfma = (C, E) in ((4, 32), (4, 64), (4, 128))
-    want = "m2d_topk_generic" if not mfma else ("m2d_topk_grouped" if k <= 16 else "m2d_topk_mfma")
+    grouped = "m2d_topk_grouped_bf16x3" if E in (64, 128) else "m2d_topk_grouped"      # default: split-bf16
+    want = "m2d_topk_generic" if not mfma else (grouped if k <= 16 else "m2d_topk_mfma")
     assert eng.last_kernel() == want
     if mfma and k <= 16:
+        eng.set_option("topk_bf16x3", 0)              # exact-f32 MFMA, pattern-grouped
+        _check(eng, PM, RE, CE, cats, users, k)
+        assert eng.last_kernel() == "m2d_topk_grouped"
         eng.set_option("variant", 7)                  # the dense (C+1)E contraction on the same data
         _check(eng, PM, RE, CE, cats, users, k)
         assert eng.last_kernel() == "m2d_topk_mfma"
@@ -147,9 +151,11 @@ def test_topk_grouped_group_boundaries():
     cats = ((pat[:, None] >> np.arange(4)[None, :]) & 1).astype(np.float32)
     eng = ScoringEngine(PM, RE, CE)
     eng.set_dish_categories(cats)
-    for k in (3, 10, 16):
-        _check(eng, PM, RE, CE, cats, np.arange(U), k)
-        assert eng.last_kernel() == "m2d_topk_grouped"
+    for x3 in (1, 0):
+        eng.set_option("topk_bf16x3", x3)
+        for k in (3, 10, 16):
+            _check(eng, PM, RE, CE, cats, np.arange(U), k)
+            assert eng.last_kernel() == ("m2d_topk_grouped_bf16x3" if x3 else "m2d_topk_grouped")
     cats2 = np.zeros_like(cats); cats2[:5, 1] = 1             # 5 rankable dishes, the rest NaN
     eng.set_dish_categories(cats2)
     _check(eng, PM, RE, CE, cats2, np.arange(10), 10)
@@ -166,7 +172,7 @@ def test_topk_split_bf16_variant(E, k):
     PM *= 3.0                                            # |score| up to a few units: the tolerance is relative there
     eng = ScoringEngine(PM, RE, CE)
     eng.set_dish_categories(cats)
-    eng.set_option("topk_bf16x3", 1)
+    assert eng.get_option("topk_bf16x3") == 1           # the default for retrieval
     users = np.random.default_rng(2).integers(0, U, 90)
     _check(eng, PM, RE, CE, cats, users, k)
     assert eng.last_kernel() == "m2d_topk_grouped_bf16x3"
