@@ -27,6 +27,11 @@
 #define M2D_DIAG 0
 #endif
 static unsigned long long *g_m2d_diag_buffer = nullptr;   // set by scripts/diag only
+#if M2D_DIAG & 16
+#define STAMP(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
+#else
+#define STAMP(x)
+#endif
 
 namespace {
 
@@ -82,6 +87,37 @@ __device__ __forceinline__ bool ahead(float v, float w)
 {
     // does v rank strictly before w?  NaN ranks after everything.
     return (v > w) || (w != w && v == v);
+}
+
+// Insert (x, id) into a descending register list of N slots and drop the last one -- for EVERY lane at once,
+// with no per-lane predicate and no serial chain through the slots:
+//     new[i] = med3(old[i-1], x, old[i])          (old[-1] = +inf)
+// which is old[i-1] when x goes above slot i-1, x when it lands in slot i, and old[i] otherwise; a lane whose x
+// does not beat its last slot is left unchanged.  The ids follow the same two compares.  Equal scores keep
+// the earlier arrival first (x > old[i] is strict), so ties stay in ascending-id order.  A NaN x is demoted
+// to -inf and can never enter.  About 4 VALU per slot, dependency depth 2 (the earlier compare-exchange
+// sweep spent ~50 cycles per slot on VALU <-> mask round trips).
+template <int N>
+__device__ __forceinline__ void sorted_insert(float (&ls)[N], int32_t (&li)[N], float x, int32_t id)
+{
+    x = fmaxf(x, -INFINITY);                     // maxNum: NaN -> -inf
+    bool above[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) above[i] = x > ls[i];
+    float ns[N];
+    int32_t ni[N];
+    ns[0] = fmaxf(ls[0], x);
+    ni[0] = above[0] ? id : li[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) {
+        ns[i] = __builtin_amdgcn_fmed3f(ls[i - 1], x, ls[i]);
+        ni[i] = above[i - 1] ? li[i - 1] : (above[i] ? id : li[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        ls[i] = ns[i];
+        li[i] = ni[i];
+    }
 }
 
 // NB = K / 8: float4 registers of the user operand per lane.  One stage = 32 dishes x KC floats.
@@ -171,9 +207,6 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
 
 #if M2D_DIAG & 16
     unsigned long long t_mfma = 0, t_epi = 0, t_bar = 0, t_slow = 0, n_slow = 0, t0_, t1_;
-#define STAMP(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
-#else
-#define STAMP(x)
 #endif
     for (int64_t s = 0; s < nstages; ++s) {
         const int buf = (int)(s & 1);
@@ -235,20 +268,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
 #if M2D_DIAG & 16
                         was_slow = true;
 #endif
-                        float xs = v;
-                        int32_t xi = (int32_t)base + (r & 3) + 8 * (r >> 2);
-                        bool placed = false;      // once placed, everything below shifts down one slot
-#pragma unroll
-                        for (int i = 0; i < KR; ++i) {
-                            const bool sw = cand && (placed || xs > rs[i]);
-                            placed = placed || sw;
-                            const float ts = rs[i];
-                            const int32_t ti = ri[i];
-                            rs[i] = sw ? xs : ts;
-                            ri[i] = sw ? xi : ti;
-                            xs = sw ? ts : xs;
-                            xi = sw ? ti : xi;
-                        }
+                        sorted_insert<KR>(rs, ri, v, (int32_t)base + (r & 3) + 8 * (r >> 2));
                         thr = rs[KR - 1];
                     }
                 }
@@ -597,6 +617,7 @@ struct GroupedArgs {
     float *out_scores;
     int32_t *out_ids;
     int32_t *err;
+    unsigned long long *dbg;   // scripts/diag only
 };
 
 template <int E8, int WAVES, int KR>
@@ -740,20 +761,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
                 const float v = acc[r];
                 const bool cand = v > thr;
                 if (__any(cand)) {
-                    float xs = v;
-                    int32_t xi = sbase + (r & 3) + 8 * (r >> 2);
-                    bool placed = false;
-#pragma unroll
-                    for (int i = 0; i < KR; ++i) {
-                        const bool sw = cand && (placed || xs > rs[i]);
-                        placed = placed || sw;
-                        const float ts = rs[i];
-                        const int32_t ti = ri[i];
-                        rs[i] = sw ? xs : ts;
-                        ri[i] = sw ? xi : ti;
-                        xs = sw ? ts : xs;
-                        xi = sw ? ti : xi;
-                    }
+                    sorted_insert<KR>(rs, ri, v, sbase + (r & 3) + 8 * (r >> 2));
                     thr = rs[KR - 1];
                 }
             }
@@ -894,6 +902,10 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
 
     const int key = (j / RPB) & (S8 - 1);                  // this lane's row swizzle (same for hi and lo rows)
     v16f acc;
+#if M2D_DIAG & 16
+    unsigned long long t_mfma = 0, t_epi = 0, t_bar = 0, t_slow = 0, n_slow = 0, n_tile = 0, t0_, t1_;
+    STAMP(t0_);
+#endif
     for (int64_t s = 0; s < nstages; ++s) {
         const int buf = (int)(s & 1);
         if (s + 1 < nstages) issue_stage(s + 1, buf ^ 1);
@@ -959,37 +971,46 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, wh[ks], acc, 0, 0, 0);
             }
             const int32_t sbase = (int32_t)(t * 32) + 4 * h;
+#if M2D_DIAG & 16
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[r]));
+            STAMP(t1_); t_mfma += t1_ - t0_; t0_ = t1_; ++n_tile;
+#endif
             float mx = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
 #pragma unroll
             for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
             mx = fmaxf(mx, acc[15]);
-            if (!__any(mx > thr)) continue;
+            if (!__any(mx > thr)) {
+#if M2D_DIAG & 16
+                STAMP(t1_); t_epi += t1_ - t0_; t0_ = t1_;
+#endif
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = acc[r];
                 const bool cand = v > thr;
                 if (__any(cand)) {
-                    float xs = v;
-                    int32_t xi = sbase + (r & 3) + 8 * (r >> 2);
-                    bool placed = false;
-#pragma unroll
-                    for (int i = 0; i < KR; ++i) {
-                        const bool sw = cand && (placed || xs > rs[i]);
-                        placed = placed || sw;
-                        const float ts = rs[i];
-                        const int32_t ti = ri[i];
-                        rs[i] = sw ? xs : ts;
-                        ri[i] = sw ? xi : ti;
-                        xs = sw ? ts : xs;
-                        xi = sw ? ti : xi;
-                    }
+                    sorted_insert<KR>(rs, ri, v, sbase + (r & 3) + 8 * (r >> 2));
                     thr = rs[KR - 1];
                 }
             }
+#if M2D_DIAG & 16
+            STAMP(t1_); t_slow += t1_ - t0_; ++n_slow; t0_ = t1_;
+#endif
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#if M2D_DIAG & 16
+        STAMP(t1_); t_bar += t1_ - t0_; t0_ = t1_;
+#endif
     }
+#if M2D_DIAG & 16
+    if (lane == 0 && p.dbg) {
+        unsigned long long *d = p.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave) * 8;
+        d[0] = t_mfma; d[1] = t_epi; d[2] = t_bar; d[3] = t_slow; d[4] = n_slow; d[5] = n_tile;
+    }
+#endif
 
     float *ls = reinterpret_cast<float *>(smem8) + (size_t)wave * 2 * KR * 64;   // aliases stage 0
     int32_t *li = reinterpret_cast<int32_t *>(ls + (size_t)KR * 64);
@@ -1097,7 +1118,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     a.pm = h->pm; a.ce = h->ce; a.rs = h->grp_rs; a.rs16 = reinterpret_cast<const __bf16 *>(h->grp_rs16);
     a.perm = h->grp_perm; a.tile_info = h->grp_tile_info;
     a.users = users; a.nU = nU; a.U = h->U; a.user_base = h->user_base; a.k = k; a.tiles = h->grp_tiles;
-    a.a = h->a; a.b = h->b; a.err = h->err_dev;
+    a.a = h->a; a.b = h->b; a.err = h->err_dev; a.dbg = g_m2d_diag_buffer;
     const int64_t ublocks = (nU + 32 * WAVES - 1) / (32 * WAVES);
     const int nsplit = pick_splits(h, ublocks, a.tiles, 4 * TPS);
     a.nsplit = nsplit;

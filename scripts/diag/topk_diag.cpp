@@ -53,12 +53,12 @@ int main(int argc, char **argv)
     }
 #if M2D_DIAG & 16
     {
-        std::vector<unsigned long long> hd(2048 * 8);
+        std::vector<unsigned long long> hd(4096 * 8);
         hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
         double m = 0, e = 0, b = 0, sl = 0, ns = 0, st = 0;
-        for (int w = 0; w < 2048; ++w) { m += hd[w*8]; e += hd[w*8+1]; b += hd[w*8+2]; sl += hd[w*8+3]; ns += hd[w*8+4]; st += hd[w*8+5]; }
-        printf("per stage per wave (cycles): mfma %.0f  epilogue %.0f  wait+barrier %.0f | slow-path stages %.1f%%, %.0f cycles each\n",
-               m / st, e / st, b / st, 100.0 * ns / st, ns ? sl / ns : 0.0);
+        for (int w = 0; w < 4096; ++w) { m += hd[w*8]; e += hd[w*8+1]; b += hd[w*8+2]; sl += hd[w*8+3]; ns += hd[w*8+4]; st += hd[w*8+5]; }
+        printf("per tile per wave (cycles): mfma %.0f  fast-epilogue %.0f  slow-epilogue %.0f (%.1f%% of tiles, %.0f each)  wait+barrier %.0f\n",
+               m / st, e / st, sl / st, 100.0 * ns / st, ns ? sl / ns : 0.0, b / st);
     }
 #endif
     const double flops = 2.0 * K * (double)U * (double)I;
