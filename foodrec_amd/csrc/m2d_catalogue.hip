@@ -97,21 +97,29 @@ __device__ __forceinline__ bool ahead(float v, float w)
 // the earlier arrival first (x > old[i] is strict), so ties stay in ascending-id order.  A NaN x is demoted
 // to -inf and can never enter.  About 4 VALU per slot, dependency depth 2 (the earlier compare-exchange
 // sweep spent ~50 cycles per slot on VALU <-> mask round trips).
+// v_cndmask_b32 with an explicit lane mask (hipcc turned the equivalent nested ?: into exec-masked branches)
+__device__ __forceinline__ int32_t lane_select(unsigned long long mask, int32_t if_set, int32_t if_clear)
+{
+    int32_t r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+    return r;
+}
+
 template <int N>
 __device__ __forceinline__ void sorted_insert(float (&ls)[N], int32_t (&li)[N], float x, int32_t id)
 {
     x = fmaxf(x, -INFINITY);                     // maxNum: NaN -> -inf
-    bool above[N];
+    unsigned long long above[N];                 // lane masks: x ranks above slot i
 #pragma unroll
-    for (int i = 0; i < N; ++i) above[i] = x > ls[i];
+    for (int i = 0; i < N; ++i) above[i] = __ballot(x > ls[i]);
     float ns[N];
     int32_t ni[N];
     ns[0] = fmaxf(ls[0], x);
-    ni[0] = above[0] ? id : li[0];
+    ni[0] = lane_select(above[0], id, li[0]);
 #pragma unroll
     for (int i = 1; i < N; ++i) {
         ns[i] = __builtin_amdgcn_fmed3f(ls[i - 1], x, ls[i]);
-        ni[i] = above[i - 1] ? li[i - 1] : (above[i] ? id : li[i]);
+        ni[i] = lane_select(above[i - 1], li[i - 1], lane_select(above[i], id, li[i]));
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -976,11 +984,16 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
             for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[r]));
             STAMP(t1_); t_mfma += t1_ - t0_; t0_ = t1_; ++n_tile;
 #endif
-            float mx = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+            // 16 independent compares against the threshold as it stands -> 16 lane masks in SGPRs.  Their OR
+            // settles most tiles with scalar work; a set mask says which scores to insert (sorted_insert is a
+            // no-op for lanes whose score no longer beats a threshold raised earlier in this tile).
+            unsigned long long m[16], any_mask = 0ull;
 #pragma unroll
-            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
-            mx = fmaxf(mx, acc[15]);
-            if (!__any(mx > thr)) {
+            for (int r = 0; r < 16; ++r) {
+                m[r] = __ballot(acc[r] > thr);
+                any_mask |= m[r];
+            }
+            if (any_mask == 0ull) {
 #if M2D_DIAG & 16
                 STAMP(t1_); t_epi += t1_ - t0_; t0_ = t1_;
 #endif
@@ -988,13 +1001,9 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = acc[r];
-                const bool cand = v > thr;
-                if (__any(cand)) {
-                    sorted_insert<KR>(rs, ri, v, sbase + (r & 3) + 8 * (r >> 2));
-                    thr = rs[KR - 1];
-                }
+                if (m[r] != 0ull) sorted_insert<KR>(rs, ri, acc[r], sbase + (r & 3) + 8 * (r >> 2));
             }
+            thr = rs[KR - 1];
 #if M2D_DIAG & 16
             STAMP(t1_); t_slow += t1_ - t0_; ++n_slow; t0_ = t1_;
 #endif
