@@ -75,6 +75,7 @@ void release(m2d_engine *h)
         for (const float *q : {h->mlp_w1, h->mlp_b1, h->mlp_w2, h->mlp_b2, h->mlp_w3})
             if (q) (void)hipFree((void *)q);
     }
+    if (h->mlp_w1x3) (void)hipFree(h->mlp_w1x3);
     if (h->dish_high) (void)hipFree(h->dish_high);
     if (h->own_ing) {
         if (h->ing) (void)hipFree((void *)h->ing);
@@ -340,6 +341,8 @@ int m2d_clear_mlp_head(m2d_engine *h)
         for (const float *q : {h->mlp_w1, h->mlp_b1, h->mlp_w2, h->mlp_b2, h->mlp_w3})
             if (q) (void)hipFree((void *)q);
     }
+    if (h->mlp_w1x3) (void)hipFree(h->mlp_w1x3);
+    h->mlp_w1x3 = nullptr;
     h->mlp_w1 = h->mlp_b1 = h->mlp_w2 = h->mlp_b2 = h->mlp_w3 = nullptr;
     h->own_mlp = false;
     h->mlp_h1 = h->mlp_h2 = 0;
@@ -424,6 +427,7 @@ int m2d_set_option(m2d_engine *h, const char *name, int64_t value)
     else if (!strcmp(name, "blocks_per_cu")) h->opt_blocks_per_cu = (int)value;
     else if (!strcmp(name, "variant")) h->opt_variant = (int)value;
     else if (!strcmp(name, "topk_bf16x3")) h->opt_topk_bf16x3 = (int)value;
+    else if (!strcmp(name, "mlp_bf16x3")) h->opt_mlp_bf16x3 = (int)value;
     else return fail(h, M2D_ERR_INVALID_ARG, "m2d_set_option: unknown option");
     return M2D_OK;
 }
@@ -436,6 +440,7 @@ int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value)
     else if (!strcmp(name, "blocks_per_cu")) *value = h->opt_blocks_per_cu;
     else if (!strcmp(name, "variant")) *value = h->opt_variant;
     else if (!strcmp(name, "topk_bf16x3")) *value = h->opt_topk_bf16x3;
+    else if (!strcmp(name, "mlp_bf16x3")) *value = h->opt_mlp_bf16x3;
     else if (!strcmp(name, "num_cu")) *value = h->num_cu;
     else return M2D_ERR_INVALID_ARG;
     return M2D_OK;

@@ -41,6 +41,7 @@ struct m2d_engine {
     float mlp_b3 = 0.f;
     int32_t mlp_h1 = 0, mlp_h2 = 0;
     bool own_mlp = false;
+    void *mlp_w1x3 = nullptr;           // split-bf16 image of W1 for the bf16x3 layer-1 path (built lazily)
 
     // factored dish vectors for catalogue retrieval (built lazily by m2d_topk_users)
     float *dish_vec = nullptr;  // [I_pad, (C+1)*E]
@@ -65,6 +66,7 @@ struct m2d_engine {
     int opt_nt = 1;
     int opt_blocks_per_cu = 8;
     int opt_variant = 0;
+    int opt_mlp_bf16x3 = 1;             // MLP head layer 1 (build-defined) on split-bf16 MFMA; 0 = exact-f32 MFMA
     int opt_topk_bf16x3 = 1;            // retrieval (build-defined) on split-bf16 MFMA; 0 = exact-f32 MFMA
 
     std::string last_error;

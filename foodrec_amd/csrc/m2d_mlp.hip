@@ -55,6 +55,7 @@ struct MlpArgs {
     int64_t B, U, I, user_base;
     int32_t K, H1, H2;
     int32_t *err;
+    const __bf16 *w1x3;        // split-bf16 image of W1 (m2d_mlp_split_w1), or null
     unsigned long long *dbg;   // scripts/diag only
 };
 
@@ -70,7 +71,35 @@ __device__ __forceinline__ void latch(int32_t *err, int code, int64_t value, int
 constexpr int MH1 = 256, MH2 = 64, MWAVES = 8;
 constexpr int RING_FLOATS = 64 * MH1;   // one stage: 64 k-rows of W1 (= all of W2: 256 x 64)
 
-template <int KCH /* K / 64 */>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// hidden unit held by accumulator tile nt, register r, lane half h (see the two layer-1 forms below)
+template <bool X3>
+__device__ __forceinline__ int hidden_unit(int nt, int r, int h)
+{
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;           // row of the 32x32 tile
+    return X3 ? 32 * nt + i : 128 * (nt >> 2) + 4 * i + (nt & 3);
+}
+
+// W1 [K, 256] f32 -> per 64-row chunk a transposed split-bf16 image [hi: 256 n x 64 k][lo: 256 n x 64 k]
+// (64 KiB per chunk, the size of one LDS stage): the A fragment of v_mfma_f32_32x32x16_bf16 is 8 consecutive k
+// of one hidden unit, i.e. one 16-byte read from this layout.
+__global__ __launch_bounds__(256) void m2d_mlp_split_w1(const float *w1, int K, __bf16 *out)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one (k, n) element
+    if (t >= (int64_t)K * MH1) return;
+    const int k = (int)(t / MH1), n = (int)(t % MH1);
+    const float x = w1[t];
+    const __bf16 hi = (__bf16)x;
+    __bf16 *chunk = out + (size_t)(k / 64) * (2 * MH1 * 64);
+    chunk[(size_t)n * 64 + (k & 63)] = hi;
+    chunk[(size_t)MH1 * 64 + (size_t)n * 64 + (k & 63)] = (__bf16)(x - (float)hi);
+}
+
+// X3 = false: layer 1 on exact-f32 MFMA.  X3 = true: layer 1 on split-bf16 MFMA (x = hi + lo, three bf16
+// products, fp32 accumulation; per-product relative error <= ~1.2e-5, see m2d_topk_grouped_bf16) -- layer 1 is
+// 91 % of the head's flops and f32 MFMA runs at 1/16 of the bf16 rate.  Layers 2-3 stay exact f32.
+template <int KCH /* K / 64 */, bool X3>
 __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
 {
     extern __shared__ __align__(16) float smem[];
@@ -91,8 +120,20 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
 
     // stage s (mod NST): s < KCH -> rows [64 s, 64 s + 64) of W1; s == KCH -> W2.  64 pieces of 1 KiB.
     auto issue_stage = [&](int s, int buf) {
-        const float *src = s < KCH ? p.w1 + (size_t)s * 64 * MH1 : p.w2;
         float *dst = ring + (size_t)buf * RING_FLOATS;
+        if (X3 && s < KCH) {
+            // split-bf16 image: 512 rows (256 hi + 256 lo) of 128 B; 16-B slots XOR-swizzled by (row >> 1) & 7 so
+            // the b128 fragment reads of 16 consecutive rows hit 16 different slots of the 256-B bank row
+            const unsigned char *src = reinterpret_cast<const unsigned char *>(p.w1x3) + (size_t)s * (RING_FLOATS * 4);
+            for (int pc = wave; pc < 64; pc += MWAVES) {
+                const int rw = pc * 8 + (lane >> 3), sl = lane & 7;
+                const int q = sl ^ ((rw >> 1) & 7);
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + (size_t)rw * 128 + q * 16),
+                                                 (void __attribute__((address_space(3))) *)(dst + pc * 256), 16, 0, 0);
+            }
+            return;
+        }
+        const float *src = s < KCH ? p.w1 + (size_t)s * 64 * MH1 : p.w2;
         for (int pc = wave; pc < 64; pc += MWAVES)
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + pc * 256 + lane * 4),
                                              (void __attribute__((address_space(3))) *)(dst + pc * 256), 16, 0, 0);
@@ -121,16 +162,17 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
         bad = false;
         if (ul < 0 || ul >= p.U) { latch(p.err, M2D_ERR_BAD_USER_ID, uid, pi); ul = 0; bad = true; }
         if (did < 0 || (int64_t)did >= p.I) { latch(p.err, M2D_ERR_BAD_ITEM_ID, did, pi); did = 0; bad = true; }
-        pu = reinterpret_cast<const v4f *>(p.pm) + (size_t)ul * (K / 4) + 8 * h;
-        pd = reinterpret_cast<const v4f *>(p.dt) + (size_t)did * (K / 4) + 8 * h;
+        // f32 form: the lane owns k = 64 kc + 32 h + t; bf16 form: k = 64 kc + 16 ks + 8 h + j (fragment order)
+        pu = reinterpret_cast<const v4f *>(p.pm) + (size_t)ul * (K / 4) + (X3 ? 2 : 8) * h;
+        pd = reinterpret_cast<const v4f *>(p.dt) + (size_t)did * (K / 4) + (X3 ? 2 : 8) * h;
     };
     v4f ra[4], rb[4];
     auto load_raw = [&](int g) {                            // g = 2 kc + half
-        const int f4 = (g >> 1) * 16 + (g & 1) * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = pu[f4 + i];
-            rb[i] = pd[f4 + i];
+            const int f4 = X3 ? (g >> 1) * 16 + (g & 1) * 8 + 4 * (i >> 1) + (i & 1) : (g >> 1) * 16 + (g & 1) * 4 + i;
+            ra[i] = pu[f4];
+            rb[i] = pd[f4];
         }
     };
     if ((int64_t)blockIdx.x < ntiles) {
@@ -145,7 +187,7 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
         for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                acc1[nt][r] = sb1[128 * (nt >> 2) + 4 * ((r & 3) + 8 * (r >> 2) + 4 * h) + (nt & 3)];
+                acc1[nt][r] = sb1[hidden_unit<X3>(nt, r, h)];
         float base = 0.f;
 
         // ---- layer 1: K in chunks of 64 (one LDS stage); lane (pair pl, half h) owns k = 64 kc + 32 h + t.
@@ -153,6 +195,7 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
         // rows (2 x 4 float4) are in flight under the current half's 128 MFMAs: the random-row latency is off
         // the critical path at 176 live registers (acc 128 + z 16 + raw 32), inside the 2-waves/SIMD budget.
         float z[16];
+        bf16x8 zh[2], zl[2];                                // X3: two k-steps of 8 k-values per lane, split hi / lo
         auto make_z = [&]() {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -160,12 +203,22 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
                 z[4 * i + 0] = zz.x; z[4 * i + 1] = zz.y; z[4 * i + 2] = zz.z; z[4 * i + 3] = zz.w;
                 base += (zz.x + zz.y) + (zz.z + zz.w);
             }
+            if constexpr (X3) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const __bf16 hi = (__bf16)z[e];
+                    zh[e >> 3][e & 7] = hi;
+                    zl[e >> 3][e & 7] = (__bf16)(z[e] - (float)hi);
+                }
+            }
         };
         make_z();                                           // rows of half 0 were requested a tile ago
 #if M2D_MLP_DIAG
         asm volatile("" ::"v"(z[0]), "v"(z[15]));
         MACC(t_pro); ++n_tiles;
 #endif
+        const int xkey = (pl >> 1) & 7;                     // X3: this lane's row swizzle (rows 32 nt + pl)
+#pragma unroll 1
         for (int kc = 0; kc < KCH; ++kc) {
             const int buf = ringpos & 1;
             if (!(M2D_MLP_DIAG & 4)) issue_stage((kc + 1) % NST, buf ^ 1);   // kc + 1 == KCH -> W2 (diag bit 2: no DMA)
@@ -176,6 +229,29 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
             for (int half = 0; half < 2; ++half) {
                 const int g = 2 * kc + half;
                 if (!(M2D_MLP_DIAG & 2) && g + 1 < 2 * KCH) load_raw(g + 1);   // diag bit 1: no in-tile gather
+                if constexpr (X3) {
+                    // rows n = 32 nt + pl of the [n][k] image; k-step ks = 2 half + ksl is logical slot 2 ks + h
+                    const unsigned char *img = reinterpret_cast<const unsigned char *>(ring + (size_t)buf * RING_FLOATS) + pl * 128;
+                    // fragments are read one (k-step, tile) ahead of the three MFMAs that consume them
+                    auto frag = [&](int it, bf16x8 &ah, bf16x8 &al) {
+                        const int slot = ((2 * (2 * half + (it >> 3)) + h) ^ xkey) * 16;
+                        ah = *reinterpret_cast<const bf16x8 *>(img + (it & 7) * (32 * 128) + slot);
+                        al = *reinterpret_cast<const bf16x8 *>(img + MH1 * 128 + (it & 7) * (32 * 128) + slot);
+                    };
+                    bf16x8 ah[2], al[2];
+                    frag(0, ah[0], al[0]);
+#pragma unroll
+                    for (int it = 0; it < 16; ++it) {
+                        if (it + 1 < 16) frag(it + 1, ah[(it + 1) & 1], al[(it + 1) & 1]);
+                        const int nt = it & 7, ksl = it >> 3;
+                        acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[it & 1], zh[ksl], acc1[nt], 0, 0, 0);
+                        acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[it & 1], zl[ksl], acc1[nt], 0, 0, 0);
+                        acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[it & 1], zh[ksl], acc1[nt], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (g + 1 < 2 * KCH) make_z();
+                    continue;
+                }
                 v4f a_cur[2], a_nxt[2];
                 a_cur[0] = wrow[(16 * half) * (MH1 / 4)];
                 a_cur[1] = wrow[(16 * half) * (MH1 / 4) + 32];
@@ -231,7 +307,7 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
             for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int n = 128 * (nt >> 2) + 4 * ((r & 3) + 8 * (r >> 2) + 4 * h) + (nt & 3);
+                    const int n = hidden_unit<X3>(nt, r, h);
                     const float hv = fmaxf(acc1[nt][r], 0.f);
                     acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2s[n * MH2], hv, acc2[0], 0, 0, 0);
                     acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2s[n * MH2 + 32], hv, acc2[1], 0, 0, 0);
@@ -326,21 +402,36 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
     a.B = B; a.U = h->U; a.I = h->I; a.user_base = h->user_base;
     a.K = (h->C + 1) * h->E; a.H1 = h->mlp_h1; a.H2 = h->mlp_h2; a.err = h->err_dev;
     a.dbg = g_m2d_mlp_diag_buffer;
+    a.w1x3 = nullptr;
     const bool mfma_ok = a.H1 == MH1 && a.H2 == MH2 && a.K % 64 == 0 && h->opt_variant != 9;
     const int kch = a.K / 64;
     if (mfma_ok && (kch == 5 || kch == 10 || kch == 20 || kch == 3)) {
         const size_t lds = (size_t)(2 * RING_FLOATS + MH1 + 2 * MH2) * sizeof(float);
         const int64_t ntiles = (B + 32 * MWAVES - 1) / (32 * MWAVES);
         const unsigned grid = (unsigned)(ntiles < h->num_cu ? ntiles : h->num_cu);
+        const bool x3 = h->opt_mlp_bf16x3 != 0;
+        if (x3 && !h->mlp_w1x3) {          // built once per head (m2d_set_mlp_head resets it)
+            M2D_HIP_TRY(h, hipMalloc((void **)&h->mlp_w1x3, (size_t)a.K * MH1 * 4));
+            hipLaunchKernelGGL(m2d_mlp_split_w1, dim3((unsigned)(((int64_t)a.K * MH1 + 255) / 256)), dim3(256), 0, stream,
+                               h->mlp_w1, a.K, reinterpret_cast<__bf16 *>(h->mlp_w1x3));
+            M2D_HIP_TRY(h, hipGetLastError());
+        }
+        a.w1x3 = reinterpret_cast<const __bf16 *>(h->mlp_w1x3);
 #define M2D_MLP_CASE(N)                                                                                     \
     if (kch == N) {                                                                                         \
-        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_mlp_mfma<N>,                                   \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
-        hipLaunchKernelGGL(m2d_mlp_mfma<N>, dim3(grid), dim3(MWAVES * 64), lds, stream, a);                 \
+        if (x3) {                                                                                           \
+            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_mlp_mfma<N, true>,                         \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+            hipLaunchKernelGGL((m2d_mlp_mfma<N, true>), dim3(grid), dim3(MWAVES * 64), lds, stream, a);     \
+        } else {                                                                                            \
+            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_mlp_mfma<N, false>,                        \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+            hipLaunchKernelGGL((m2d_mlp_mfma<N, false>), dim3(grid), dim3(MWAVES * 64), lds, stream, a);    \
+        }                                                                                                   \
     }
         M2D_MLP_CASE(3) M2D_MLP_CASE(5) M2D_MLP_CASE(10) M2D_MLP_CASE(20)
 #undef M2D_MLP_CASE
-        h->last_kernel = "m2d_mlp_mfma";
+        h->last_kernel = x3 ? "m2d_mlp_mfma_bf16x3" : "m2d_mlp_mfma";
     } else {
         const size_t lds = (size_t)4 * (a.K + a.H1 + a.H2) * sizeof(float);
         if (lds > 160 * 1024) {
