@@ -56,6 +56,7 @@ struct MlpArgs {
     int32_t K, H1, H2;
     int32_t *err;
     const __bf16 *w1x3;        // split-bf16 image of W1 (m2d_mlp_split_w1), or null
+    const __bf16 *w2x3;        // split-bf16 fragment image of W2 (m2d_mlp_split_w2), or null
     unsigned long long *dbg;   // scripts/diag only
 };
 
@@ -96,9 +97,26 @@ __global__ __launch_bounds__(256) void m2d_mlp_split_w1(const float *w1, int K, 
     chunk[(size_t)MH1 * 64 + (size_t)n * 64 + (k & 63)] = (__bf16)(x - (float)hi);
 }
 
+// W2 [256, 64] f32 -> split-bf16 fragment image [hi | lo], each [mt 2][ks 16][h 2][m 32][j 8]: the 16 bytes at
+// (mt, ks, h, m) are W2[n][32 mt + m] for the 8 hidden units n = 32 (ks >> 1) + 16 (ks & 1) + (j & 3) + 8 (j >> 2) + 4 h
+// that lane half h of the layer-1 accumulator tile ks >> 1 holds in registers 8 (ks & 1) + j -- so the layer-1
+// result is the layer-2 B operand as it stands.  64 KiB = one LDS stage, conflict-free b128 reads.
+__global__ __launch_bounds__(256) void m2d_mlp_split_w2(const float *w2, __bf16 *out)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;                   // one output element, [mt][ks][h][m][j]
+    if (t >= MH1 * MH2) return;
+    const int j = t & 7, m = (t >> 3) & 31, hh = (t >> 8) & 1, ks = (t >> 9) & 15, mt = t >> 13;
+    const int n = 32 * (ks >> 1) + 16 * (ks & 1) + (j & 3) + 8 * (j >> 2) + 4 * hh;
+    const float x = w2[n * MH2 + 32 * mt + m];
+    const __bf16 hi = (__bf16)x;
+    out[t] = hi;
+    out[MH1 * MH2 + t] = (__bf16)(x - (float)hi);
+}
+
 // X3 = false: layer 1 on exact-f32 MFMA.  X3 = true: layer 1 on split-bf16 MFMA (x = hi + lo, three bf16
 // products, fp32 accumulation; per-product relative error <= ~1.2e-5, see m2d_topk_grouped_bf16) -- layer 1 is
-// 91 % of the head's flops and f32 MFMA runs at 1/16 of the bf16 rate.  Layers 2-3 stay exact f32.
+// 91 % of the head's flops and f32 MFMA runs at 1/16 of the bf16 rate.  Layer 2 takes the same form (its f32
+// MFMAs would otherwise cost as much as all of split-bf16 layer 1); layer 3 and the reference score stay f32.
 template <int KCH /* K / 64 */, bool X3>
 __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
 {
@@ -133,7 +151,7 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
             }
             return;
         }
-        const float *src = s < KCH ? p.w1 + (size_t)s * 64 * MH1 : p.w2;
+        const float *src = s < KCH ? p.w1 + (size_t)s * 64 * MH1 : X3 ? reinterpret_cast<const float *>(p.w2x3) : p.w2;
         for (int pc = wave; pc < 64; pc += MWAVES)
             __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + pc * 256 + lane * 4),
                                              (void __attribute__((address_space(3))) *)(dst + pc * 256), 16, 0, 0);
@@ -303,6 +321,28 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[mt][r] = sb2[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h];
+            if constexpr (X3) {
+                const unsigned char *img = reinterpret_cast<const unsigned char *>(ring + (size_t)buf * RING_FLOATS) + (h * 32 + pl) * 16;
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    bf16x8 bh, bl;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float hv = fmaxf(acc1[ks >> 1][8 * (ks & 1) + j], 0.f);
+                        const __bf16 hi = (__bf16)hv;
+                        bh[j] = hi;
+                        bl[j] = (__bf16)(hv - (float)hi);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const bf16x8 ah = *reinterpret_cast<const bf16x8 *>(img + (mt * 16 + ks) * 1024);
+                        const bf16x8 al = *reinterpret_cast<const bf16x8 *>(img + MH1 * MH2 * 2 + (mt * 16 + ks) * 1024);
+                        acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2[mt], 0, 0, 0);
+                        acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2[mt], 0, 0, 0);
+                        acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc2[mt], 0, 0, 0);
+                    }
+                }
+            } else
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
@@ -402,7 +442,7 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
     a.B = B; a.U = h->U; a.I = h->I; a.user_base = h->user_base;
     a.K = (h->C + 1) * h->E; a.H1 = h->mlp_h1; a.H2 = h->mlp_h2; a.err = h->err_dev;
     a.dbg = g_m2d_mlp_diag_buffer;
-    a.w1x3 = nullptr;
+    a.w1x3 = a.w2x3 = nullptr;
     const bool mfma_ok = a.H1 == MH1 && a.H2 == MH2 && a.K % 64 == 0 && h->opt_variant != 9;
     const int kch = a.K / 64;
     if (mfma_ok && (kch == 5 || kch == 10 || kch == 20 || kch == 3)) {
@@ -411,12 +451,15 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
         const unsigned grid = (unsigned)(ntiles < h->num_cu ? ntiles : h->num_cu);
         const bool x3 = h->opt_mlp_bf16x3 != 0;
         if (x3 && !h->mlp_w1x3) {          // built once per head (m2d_set_mlp_head resets it)
-            M2D_HIP_TRY(h, hipMalloc((void **)&h->mlp_w1x3, (size_t)a.K * MH1 * 4));
+            M2D_HIP_TRY(h, hipMalloc((void **)&h->mlp_w1x3, (size_t)a.K * MH1 * 4 + (size_t)MH1 * MH2 * 4));
             hipLaunchKernelGGL(m2d_mlp_split_w1, dim3((unsigned)(((int64_t)a.K * MH1 + 255) / 256)), dim3(256), 0, stream,
                                h->mlp_w1, a.K, reinterpret_cast<__bf16 *>(h->mlp_w1x3));
+            hipLaunchKernelGGL(m2d_mlp_split_w2, dim3(MH1 * MH2 / 256), dim3(256), 0, stream, h->mlp_w2,
+                               reinterpret_cast<__bf16 *>(h->mlp_w1x3) + (size_t)a.K * MH1 * 2);
             M2D_HIP_TRY(h, hipGetLastError());
         }
         a.w1x3 = reinterpret_cast<const __bf16 *>(h->mlp_w1x3);
+        a.w2x3 = a.w1x3 ? a.w1x3 + (size_t)a.K * MH1 * 2 : nullptr;
 #define M2D_MLP_CASE(N)                                                                                     \
     if (kch == N) {                                                                                         \
         if (x3) {                                                                                           \
