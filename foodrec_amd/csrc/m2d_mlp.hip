@@ -74,6 +74,27 @@ constexpr int RING_FLOATS = 64 * MH1;   // one stage: 64 k-rows of W1 (= all of 
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// vmcnt(0) twice over: the builtin is an s_waitcnt the compiler's own counter model sees (so it stops assuming that
+// loads from a previous loop trip are still in flight), the asm one cannot be optimised away on the grounds that
+// the compiler knows of nothing outstanding (the DMA ops below are hidden from it).
+__device__ __forceinline__ void wait_all_vmem()
+{
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0), expcnt / lgkmcnt untouched
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// LDS-DMA of 64 x 16 B: lane l's 16 bytes at `src` land at lds_base + 16 l.  Written as asm on purpose: after the
+// builtin the compiler puts s_waitcnt vmcnt(0) in front of the next ds_read (it must assume the read aliases the
+// DMA'd bytes), which serialises the NEXT stage's fill with the CURRENT stage's multiply.  Here a stage is
+// published by an explicit vmcnt(0) + barrier before anyone reads it, so that wait is never needed.  The hidden
+// VMEM op only makes the compiler's own vmcnt(N) waits more conservative (returns are in order), never less.
+__device__ __forceinline__ void lds_dma16(const void *src, const void *lds_base_uniform)
+{
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)lds_base_uniform);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+}
+
 // hidden unit held by accumulator tile nt, register r, lane half h (see the two layer-1 forms below)
 template <bool X3>
 __device__ __forceinline__ int hidden_unit(int nt, int r, int h)
@@ -146,25 +167,23 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
             for (int pc = wave; pc < 64; pc += MWAVES) {
                 const int rw = pc * 8 + (lane >> 3), sl = lane & 7;
                 const int q = sl ^ ((rw >> 1) & 7);
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + (size_t)rw * 128 + q * 16),
-                                                 (void __attribute__((address_space(3))) *)(dst + pc * 256), 16, 0, 0);
+                lds_dma16(src + (size_t)rw * 128 + q * 16, dst + pc * 256);
             }
             return;
         }
         const float *src = s < KCH ? p.w1 + (size_t)s * 64 * MH1 : X3 ? reinterpret_cast<const float *>(p.w2x3) : p.w2;
         for (int pc = wave; pc < 64; pc += MWAVES)
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src + pc * 256 + lane * 4),
-                                             (void __attribute__((address_space(3))) *)(dst + pc * 256), 16, 0, 0);
+            lds_dma16(src + pc * 256 + lane * 4, dst + pc * 256);
     };
 
     const int64_t ntiles = (p.B + 32 * MWAVES - 1) / (32 * MWAVES);
     int ringpos = 0;                          // parity of the stage being consumed
     if ((int64_t)blockIdx.x < ntiles) issue_stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_all_vmem();
     __syncthreads();
 
 #if M2D_MLP_DIAG
-    unsigned long long t_pro = 0, t_l1 = 0, t_bar = 0, t_l23 = 0, t_vm = 0, n_tiles = 0, t0_, t1_;
+    unsigned long long t_pro = 0, t_l1 = 0, t_bar = 0, t_l23 = 0, t_vm = 0, t_gw = 0, t_mz = 0, n_tiles = 0, t0_, t1_;
     MSTAMP(t0_);
 #endif
     // this lane's pair of a tile: ids -> the two row pointers (out-of-range ids are latched and clamped)
@@ -180,6 +199,7 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
         bad = false;
         if (ul < 0 || ul >= p.U) { latch(p.err, M2D_ERR_BAD_USER_ID, uid, pi); ul = 0; bad = true; }
         if (did < 0 || (int64_t)did >= p.I) { latch(p.err, M2D_ERR_BAD_ITEM_ID, did, pi); did = 0; bad = true; }
+        if (M2D_MLP_DIAG & 8) { ul = 0; did = 0; }          // diag bit 3: every pair reads row 0 (loads issue, no HBM traffic)
         // f32 form: the lane owns k = 64 kc + 32 h + t; bf16 form: k = 64 kc + 16 ks + 8 h + j (fragment order)
         pu = reinterpret_cast<const v4f *>(p.pm) + (size_t)ul * (K / 4) + (X3 ? 2 : 8) * h;
         pd = reinterpret_cast<const v4f *>(p.dt) + (size_t)did * (K / 4) + (X3 ? 2 : 8) * h;
@@ -267,7 +287,17 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
                         acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[it & 1], zh[ksl], acc1[nt], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
+#if M2D_MLP_DIAG
+                    asm volatile("" ::"v"(acc1[7][0]));
+                    MACC(t_l1);
+                    wait_all_vmem();
+                    MACC(t_gw);
+#endif
                     if (g + 1 < 2 * KCH) make_z();
+#if M2D_MLP_DIAG
+                    asm volatile("" ::"v"(zh[0][0]), "v"(zl[1][7]));
+                    MACC(t_mz);
+#endif
                     continue;
                 }
                 v4f a_cur[2], a_nxt[2];
@@ -296,7 +326,7 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
             for (int nt = 0; nt < 8; ++nt) asm volatile("" ::"v"(acc1[nt][0]));
             MACC(t_l1);
 #endif
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_all_vmem();
             MACC(t_vm);
             __syncthreads();
             MACC(t_bar);
@@ -366,7 +396,7 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
             base += __shfl_xor(base, 32, 64);
             if (h == 0 && cur_valid) p.out[cur_pi] = cur_bad ? __builtin_nanf("") : (base + (o + p.b3));
             MACC(t_l23);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_all_vmem();
             __syncthreads();
             MACC(t_bar);
             ++ringpos;
@@ -375,7 +405,7 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
 #if M2D_MLP_DIAG
     if (lane == 0 && p.dbg) {
         unsigned long long *d = p.dbg + ((size_t)blockIdx.x * MWAVES + wave) * 8;
-        d[0] = t_pro; d[1] = t_l1; d[2] = t_bar; d[3] = t_l23; d[4] = n_tiles; d[5] = t_vm;
+        d[0] = t_pro; d[1] = t_l1; d[2] = t_bar; d[3] = t_l23; d[4] = n_tiles; d[5] = t_vm; d[6] = t_gw; d[7] = t_mz;
     }
 #endif
 }

@@ -44,9 +44,9 @@ int main()
     {
         std::vector<unsigned long long> hd(2048 * 8);
         hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
-        double p = 0, l1 = 0, b = 0, l23 = 0, nt = 0, vm = 0;
-        for (int w = 0; w < 2048; ++w) { p += hd[w*8]; l1 += hd[w*8+1]; b += hd[w*8+2]; l23 += hd[w*8+3]; nt += hd[w*8+4]; vm += hd[w*8+5]; }
-        printf("per tile per wave (cycles): prologue %.0f  layer1 %.0f (10 chunks)  vmcnt-wait %.0f  barrier %.0f  layers2-3 %.0f\n", p / nt, l1 / nt, vm / nt, b / nt, l23 / nt);
+        double p = 0, l1 = 0, b = 0, l23 = 0, nt = 0, vm = 0, gw = 0, mz = 0;
+        for (int w = 0; w < 2048; ++w) { p += hd[w*8]; l1 += hd[w*8+1]; b += hd[w*8+2]; l23 += hd[w*8+3]; nt += hd[w*8+4]; vm += hd[w*8+5]; gw += hd[w*8+6]; mz += hd[w*8+7]; }
+        printf("per tile per wave (cycles): prologue %.0f  layer1 %.0f (10 chunks)  vmcnt-wait %.0f  barrier %.0f  layers2-3 %.0f  gather-wait %.0f  make_z %.0f\n", p / nt, l1 / nt, vm / nt, b / nt, l23 / nt, gw / nt, mz / nt);
     }
 #endif
     const double fl = 2.0 * (K * 256 + 256 * 64 + 64) * (double)B;
