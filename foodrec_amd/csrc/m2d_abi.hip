@@ -61,6 +61,7 @@ int adopt_table(m2d_engine *h, const float *src, size_t count, int flags, const 
 
 void release(m2d_engine *h)
 {
+    m2d_train_release(h);
     if (h->own_pm && h->pm) (void)hipFree((void *)h->pm);
     if (h->own_re && h->re) (void)hipFree((void *)h->re);
     if (h->own_ce && h->ce) (void)hipFree((void *)h->ce);
@@ -385,6 +386,50 @@ int m2d_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_t *item
     if (!h->dish_cats) return fail(h, M2D_ERR_NOT_CONFIGURED, "call m2d_set_dish_categories first");
     M2D_HIP_TRY(h, hipSetDevice(h->device));
     return m2d_launch_score_pairs_mlp(h, users, items, B, out, (hipStream_t)stream);
+}
+
+int m2d_train_begin(m2d_engine *h, int32_t learner, float lr, float clip_norm, void *stream)
+{
+    if (!h) return M2D_ERR_INVALID_ARG;
+    if (learner < M2D_LEARNER_SGD || learner > M2D_LEARNER_ADAM) return fail(h, M2D_ERR_INVALID_ARG, "m2d_train_begin: unknown learner");
+    if (!(clip_norm > 0.f)) return fail(h, M2D_ERR_INVALID_ARG, "m2d_train_begin: clip_norm must be positive");
+    if (h->ing) return fail(h, M2D_ERR_UNSUPPORTED, "m2d_train_begin: the ingredient extension has no training step");
+    M2D_HIP_TRY(h, hipSetDevice(h->device));
+    return m2d_train_setup(h, learner, lr, clip_norm, (hipStream_t)stream);
+}
+
+int m2d_train_step(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats, const float *labels,
+                   int64_t B, int32_t apply, float *out, void *stream)
+{
+    if (!h) return M2D_ERR_INVALID_ARG;
+    if (!h->train) return fail(h, M2D_ERR_NOT_CONFIGURED, "m2d_train_step: call m2d_train_begin first");
+    if (B <= 0) return fail(h, M2D_ERR_INVALID_ARG, "m2d_train_step: need B > 0 (the mean of an empty batch is NaN)");
+    if (!users || !items || !cats || !labels) return fail(h, M2D_ERR_INVALID_ARG, "m2d_train_step: null buffer");
+    M2D_HIP_TRY(h, hipSetDevice(h->device));
+    return m2d_launch_train_step(h, users, items, cats, labels, B, apply, out, (hipStream_t)stream);
+}
+
+int m2d_train_slot(m2d_engine *h, int32_t table, int32_t slot, float *buf, int32_t restore, void *stream)
+{
+    if (!h || !buf) return M2D_ERR_INVALID_ARG;
+    if (!h->train) return fail(h, M2D_ERR_NOT_CONFIGURED, "m2d_train_slot: call m2d_train_begin first");
+    if (table < 0 || table > 2 || slot < 0 || slot > 1) return fail(h, M2D_ERR_INVALID_ARG, "m2d_train_slot: table 0..2, slot 0..1");
+    float *dev = nullptr;
+    int64_t count = 0;
+    (void)m2d_train_get_slot(h, table, slot, &dev, &count);
+    if (!dev) return fail(h, M2D_ERR_INVALID_ARG, "m2d_train_slot: this learner has no such slot");
+    M2D_HIP_TRY(h, hipSetDevice(h->device));
+    M2D_HIP_TRY(h, hipMemcpyAsync(restore ? dev : buf, restore ? buf : dev, (size_t)count * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return M2D_OK;
+}
+
+int m2d_train_end(m2d_engine *h)
+{
+    if (!h) return M2D_ERR_INVALID_ARG;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    m2d_train_release(h);
+    return M2D_OK;
 }
 
 int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_index)

@@ -8,6 +8,8 @@
 
 #include "../../include/m2d.h"
 
+struct m2d_train_state;   // csrc/m2d_train.hip
+
 struct m2d_engine {
     // tables in HBM, row-major, float32 (Model_Recommender.py:45-53)
     const float *pm = nullptr;  // [U, C+1, E]
@@ -57,6 +59,9 @@ struct m2d_engine {
     int64_t grp_tiles = 0, grp_cap_rows = 0;
     bool grp_valid = false, grp_binary = false;
 
+    // training step: optimizer slots and gradient scratch, created by m2d_train_begin
+    m2d_train_state *train = nullptr;
+
     // scratch for rank_candidates
     float *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -92,6 +97,11 @@ int m2d_ensure_dish_vectors(m2d_engine *h, hipStream_t stream);
 int m2d_launch_write_memory(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
                             const float *sign, const float *labels, int64_t B, int32_t L, float *gm, float beta_1,
                             float beta_2, float alpha, double *out_sums, hipStream_t stream);
+int m2d_train_setup(m2d_engine *h, int32_t learner, float lr, float clip_norm, hipStream_t stream);
+void m2d_train_release(m2d_engine *h);
+int m2d_launch_train_step(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats, const float *labels,
+                          int64_t B, int32_t apply, float *out, hipStream_t stream);
+int m2d_train_get_slot(m2d_engine *h, int32_t table, int32_t slot, float **dev, int64_t *count);
 int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_t *items, int64_t B, float *out,
                                hipStream_t stream);
 int m2d_launch_rank_candidates(m2d_engine *h, const int32_t *users, const int32_t *items,

@@ -1,0 +1,443 @@
+// Training step: Model.loss + Model.train, Model_Recommender.py:99-104, :223-241,
+// as the call site runs it -- sess.run([model.loss_value, model.learning_rate, ..., model.train_op], feed_dict),
+// Train_recommender.py:180-199.
+//
+//   loss   = mean_b( max(s_b, 0) - s_b y_b + log(1 + exp(-|s_b|)) ),  s = Model.inference (:56-97)        :101-103
+//   grads  = d loss / d {Personal_Memory, Recipe_Embedding, Category_Embedding}   (General_Memory: none)    :236
+//            per-pair rows for the two gathered tables (TF: IndexedSlices), dense for Category_Embedding:
+//              q_h = g_b a / n_b,  q_l = g_b (1 - a) / n_b,  g_b = (sigmoid(s_b) - y_b) / B
+//              dPM[u_b][0]   += q_h sum_c m_bc CE_c          dPM[u_b][1 + c] += q_l m_bc RE[d_b]
+//              dRE[d_b]      += q_l sum_c m_bc PM[u_b][1+c]  dCE[c]          += q_h m_bc PM[u_b][0]
+//   clip   = tf.clip_by_global_norm(grads, 5.0): the norm runs over the PER-PAIR rows (duplicate ids not yet
+//            summed) and the dense dCE; scale = clip * min(1 / norm, 1 / clip)                              :237
+//   update = optimizer.apply_gradients: duplicate rows are summed, then adam / adagrad / rmsprop / sgd     :228-240
+//
+// The optimizer rules restate TF 1.x's published behaviour (oracle/train_oracle.py lists them; PARITY UNPINNED,
+// TensorFlow is not in the image).  The one that shapes the kernels: TF 1.x Adam's sparse path is not lazy -- it
+// decays m and v of EVERY row and moves EVERY row by lr_t m / (sqrt(v) + eps) each step -- so Adam is a dense
+// streaming pass over var / m / v (HBM-bound, 6 x table bytes per step) that picks a row's summed gradient out
+// of a compact buffer when the row was touched; adagrad / rmsprop / sgd touch only the batch's rows.
+//
+// Data flow of one step (all on the caller's stream, no host synchronisation):
+//   claim     one thread per pair: the first pair to see a user (dish) claims the next compact slot for it in a
+//             row -> slot map (atomicCAS), so duplicate ids share one gradient row;
+//   grad      one wave per pair: forward (two wave reductions), loss term, then the pair's gradient rows are
+//             float-atomic-added into the compact buffers; sum of squares of the per-pair values and the loss go
+//             to two double accumulators; dCE is reduced per wave in LDS first;
+//   finalize  one block: norm over dCE joins in, writes {loss, global norm, scale, lr};
+//   apply     rows (Adam: all rows; others: claimed rows) and the dense dCE;
+//   cleanup   claimed rows: map entry back to -1, compact gradient row back to zero.
+// Sums are float atomics: results are order-dependent in the last bits, like m2d_write_memory.
+#include "m2d_engine.h"
+
+namespace {
+
+struct TrainArgs {
+    float *pm, *re, *ce;
+    const int32_t *users, *items;
+    const float *cats;      // [B, C]
+    const float *labels;    // [B]
+    int64_t B, U, I, user_base;
+    int32_t C, E;
+    float a, b;
+    int32_t *map_u, *map_d;     // row -> compact slot, -1 = untouched
+    int32_t *slot_u, *slot_d;   // compact slot -> row
+    int32_t *cnt;               // [0] users claimed, [1] dishes claimed
+    float *gu, *gd;             // [cap, (C+1) E], [cap, E]
+    float *gce;                 // [C, E]
+    double *acc;                // [0] sum of loss terms, [1] sum of squares of the per-pair gradient values
+    float *scal;                // [0] loss, [1] global norm, [2] scale, [3] learning rate
+    int32_t *err;
+    int32_t accumulate;         // 0: loss + norm only (no slots are claimed, nothing is added to gu / gd)
+    float clip, lr;
+};
+
+__device__ __forceinline__ void train_latch(int32_t *err, int code, int64_t value, int64_t index)
+{
+    if (atomicCAS(&err[0], 0, code) == 0) {
+        err[1] = (int32_t)value;
+        err[2] = (int32_t)(index & 0xffffffff);
+        err[3] = (int32_t)(index >> 32);
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float x)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+__global__ __launch_bounds__(256) void m2d_train_claim(TrainArgs p)
+{
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= p.B) return;
+    const int32_t uid = p.users[b], did = p.items[b];
+    const int64_t ul = (int64_t)uid - p.user_base;
+    if (ul < 0 || ul >= p.U) { train_latch(p.err, M2D_ERR_BAD_USER_ID, uid, b); return; }
+    if (did < 0 || (int64_t)did >= p.I) { train_latch(p.err, M2D_ERR_BAD_ITEM_ID, did, b); return; }
+    if (atomicCAS(&p.map_u[ul], -1, -2) == -1) {
+        const int s = atomicAdd(&p.cnt[0], 1);
+        p.slot_u[s] = (int32_t)ul;
+        p.map_u[ul] = s;            // read by later launches only
+    }
+    if (atomicCAS(&p.map_d[did], -1, -2) == -1) {
+        const int s = atomicAdd(&p.cnt[1], 1);
+        p.slot_d[s] = did;
+        p.map_d[did] = s;
+    }
+}
+
+// One wave per pair.  LDS: this wave's partial dCE [C, E] when it fits (ce_lds != 0), else atomics to global.
+__global__ __launch_bounds__(256) void m2d_train_grad(TrainArgs p, int ce_lds)
+{
+    extern __shared__ float dce_all[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int C = p.C, E = p.E;
+    float *dce = dce_all + (size_t)wv * C * E;
+    if (ce_lds)
+        for (int i = lane; i < C * E; i += 64) dce[i] = 0.f;
+    __syncthreads();                                        // the zeroing lane is not the lane that owns column e below
+    double loss_acc = 0.0, sq_acc = 0.0;
+    const float invB = 1.0f / (float)p.B;
+    for (int64_t b = wave0; b < p.B; b += nwaves) {
+        const int32_t uid = p.users[b], did = p.items[b];
+        const int64_t ul = (int64_t)uid - p.user_base;
+        if (ul < 0 || ul >= p.U || did < 0 || (int64_t)did >= p.I) {      // latched by the claim pass / below
+            if (!p.accumulate && lane == 0)
+                train_latch(p.err, (ul < 0 || ul >= p.U) ? M2D_ERR_BAD_USER_ID : M2D_ERR_BAD_ITEM_ID,
+                            (ul < 0 || ul >= p.U) ? uid : did, b);
+            continue;
+        }
+        const float *m = p.cats + (size_t)b * C;
+        const float *urow = p.pm + (size_t)ul * (C + 1) * E;
+        const float *drow = p.re + (size_t)did * E;
+        float n = 0.f;
+        for (int c = 0; c < C; ++c) n += m[c];                                      // :77
+        float hi = 0.f, lo = 0.f;
+        for (int e = lane; e < E; e += 64) {
+            float H = 0.f, L = 0.f;
+            for (int c = 0; c < C; ++c) {
+                H = fmaf(m[c], p.ce[(size_t)c * E + e], H);                         // :67-75
+                L = fmaf(m[c], urow[(size_t)(1 + c) * E + e], L);                   // :82-90
+            }
+            hi = fmaf(urow[e], H, hi);
+            lo = fmaf(drow[e], L, lo);
+        }
+        hi = wave_sum(hi);
+        lo = wave_sum(lo);
+        const float s = __fadd_rn(__fmul_rn(p.a, hi / n), __fmul_rn(p.b, lo / n));  // :79, :93, :95-96
+        const float y = p.labels[b];
+        const float loss_b = fmaxf(s, 0.f) - s * y + log1pf(expf(-fabsf(s)));       // :101
+        const float gs = (1.0f / (1.0f + expf(-s)) - y) * invB;                     // d mean / d s_b
+        const float qh = gs * p.a / n, ql = gs * p.b / n;
+        const int su = p.accumulate ? p.map_u[ul] : 0, sd = p.accumulate ? p.map_d[did] : 0;
+        float *gu = p.gu + (size_t)su * (C + 1) * E;
+        float *gd = p.gd + (size_t)sd * E;
+        float sq = 0.f;
+        for (int e = lane; e < E; e += 64) {
+            float H = 0.f, L = 0.f;
+            for (int c = 0; c < C; ++c) {
+                H = fmaf(m[c], p.ce[(size_t)c * E + e], H);
+                L = fmaf(m[c], urow[(size_t)(1 + c) * E + e], L);
+            }
+            const float uh = urow[e], it = drow[e];
+            const float v0 = qh * H, vd = ql * L;
+            sq = fmaf(v0, v0, sq);
+            sq = fmaf(vd, vd, sq);
+            if (p.accumulate) {
+                atomicAdd(gu + e, v0);
+                atomicAdd(gd + e, vd);
+            }
+            for (int c = 0; c < C; ++c) {
+                const float vc = (ql * m[c]) * it;
+                sq = fmaf(vc, vc, sq);
+                // a zero mask entry contributes an exact zero (unless RE holds inf / NaN -- not reproduced)
+                if (p.accumulate && m[c] != 0.f) atomicAdd(gu + (size_t)(1 + c) * E + e, vc);
+                const float w = (qh * m[c]) * uh;
+                if (ce_lds) dce[c * E + e] += w;                                    // this lane owns column e
+                else if (m[c] != 0.f) atomicAdd(p.gce + (size_t)c * E + e, w);
+            }
+        }
+        sq_acc += (double)wave_sum(sq);
+        loss_acc += (double)loss_b;
+    }
+    __syncthreads();
+    if (ce_lds)
+        for (int i = lane; i < C * E; i += 64)
+            if (dce[i] != 0.f) atomicAdd(p.gce + i, dce[i]);
+    if (lane == 0) {
+        atomicAdd(p.acc + 0, loss_acc);
+        atomicAdd(p.acc + 1, sq_acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void m2d_train_finalize(TrainArgs p)
+{
+    __shared__ double part[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < p.C * p.E; i += 256) s += (double)p.gce[i] * (double)p.gce[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double n2 = p.acc[1] + part[0] + part[1] + part[2] + part[3];
+        const float norm = (float)sqrt(n2);
+        p.scal[0] = (float)(p.acc[0] / (double)p.B);                                // reduce_mean, :103
+        p.scal[1] = norm;
+        p.scal[2] = p.clip * fminf(1.0f / norm, 1.0f / p.clip);                     // clip_by_global_norm
+        p.scal[3] = p.lr;
+    }
+}
+
+struct RuleArgs {
+    int32_t rule;           // M2D_LEARNER_*
+    float lr;               // adam: lr sqrt(1 - b2^t) / (1 - b1^t)
+    float b1, b2, eps;      // adam: betas, epsilon; rmsprop: b1 = decay, b2 = momentum, eps
+};
+
+__device__ __forceinline__ void apply_one(const RuleArgs &r, float g, float &var, float &s0, float &s1)
+{
+    if (r.rule == M2D_LEARNER_ADAM) {
+        s0 = s0 * r.b1 + g * (1.0f - r.b1);
+        s1 = s1 * r.b2 + (g * g) * (1.0f - r.b2);
+        var -= r.lr * s0 / (sqrtf(s1) + r.eps);
+    } else if (r.rule == M2D_LEARNER_ADAGRAD) {
+        s0 += g * g;
+        var -= r.lr * g / sqrtf(s0);
+    } else if (r.rule == M2D_LEARNER_RMSPROP) {
+        s0 += (g * g - s0) * (1.0f - r.b1);
+        s1 = s1 * r.b2 + r.lr * g / sqrtf(s0 + r.eps);
+        var -= s1;
+    } else {
+        var -= r.lr * g;
+    }
+}
+
+// Rows of one table.  ALL = true (Adam): every row r < R, gradient row map[r] when >= 0, else zero.
+// ALL = false: claimed rows only, r = slot_row[s] for s < *count.  map == nullptr: dense gradient (row r of G).
+// W floats per row; a wave walks a row 64 (x4 when W % 4 == 0) floats at a time.
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int VEC> struct RowVec;
+template <> struct RowVec<1> { typedef float T; };
+template <> struct RowVec<4> { typedef v4f T; };
+__device__ __forceinline__ float &lane_of(float &v, int) { return v; }
+__device__ __forceinline__ float lane_get(const v4f &v, int j) { return v[j]; }
+__device__ __forceinline__ float lane_get(const float &v, int) { return v; }
+__device__ __forceinline__ void lane_set(v4f &v, int j, float x) { v[j] = x; }
+__device__ __forceinline__ void lane_set(float &v, int, float x) { v = x; }
+
+template <bool ALL, int VEC>
+__global__ __launch_bounds__(256) void m2d_train_apply(float *var, float *s0, float *s1, const float *G, const int32_t *map,
+                                                       const int32_t *slot_row, const int32_t *count, int64_t R, int32_t W,
+                                                       const float *scal, RuleArgs r)
+{
+    typedef typename RowVec<VEC>::T vf;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const float scale = scal[2];
+    const int64_t n = ALL ? R : (int64_t)*count;
+    const bool two = r.rule == M2D_LEARNER_ADAM || r.rule == M2D_LEARNER_RMSPROP, one = two || r.rule == M2D_LEARNER_ADAGRAD;
+    for (int64_t i = wave0; i < n; i += nwaves) {
+        int64_t row, grow;
+        if (ALL) { row = i; grow = map ? (int64_t)map[i] : i; }
+        else { row = slot_row[i]; grow = i; }
+        const size_t base = (size_t)row * W;
+        const float *g = grow >= 0 ? G + (size_t)grow * W : nullptr;
+        for (int e = lane * VEC; e < W; e += 64 * VEC) {
+            vf v = *reinterpret_cast<const vf *>(var + base + e);
+            vf a = vf(0.f), b = vf(0.f), gg = vf(0.f);
+            if (one) a = *reinterpret_cast<const vf *>(s0 + base + e);
+            if (two) b = *reinterpret_cast<const vf *>(s1 + base + e);
+            if (g) gg = *reinterpret_cast<const vf *>(g + e) * scale;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float vv = lane_get(v, j), aa = lane_get(a, j), bb = lane_get(b, j);
+                apply_one(r, lane_get(gg, j), vv, aa, bb);
+                lane_set(v, j, vv); lane_set(a, j, aa); lane_set(b, j, bb);
+            }
+            *reinterpret_cast<vf *>(var + base + e) = v;
+            if (one) *reinterpret_cast<vf *>(s0 + base + e) = a;
+            if (two) *reinterpret_cast<vf *>(s1 + base + e) = b;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void m2d_train_cleanup(int32_t *map, const int32_t *slot_row, const int32_t *count, float *G, int32_t W)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t n = *count;
+    for (int64_t s = wave0; s < n; s += (int64_t)gridDim.x * 4) {
+        if (lane == 0) map[slot_row[s]] = -1;
+        for (int e = lane; e < W; e += 64) G[(size_t)s * W + e] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void m2d_fill_kernel(float *x, int64_t n, float v)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = v;
+}
+
+__global__ __launch_bounds__(256) void m2d_fill_i32_kernel(int32_t *x, int64_t n, int32_t v)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = v;
+}
+
+unsigned blocks_for(const m2d_engine *h, int64_t waves)
+{
+    int64_t b = (waves + 3) / 4;
+    const int64_t cap = (int64_t)h->num_cu * 8;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+struct m2d_train_state {
+    int32_t learner = M2D_LEARNER_ADAM;
+    float lr = 0.001f, clip = 5.0f;
+    int64_t steps = 0;
+    float b1p = 0.9f, b2p = 0.999f;     // Adam's beta1_power / beta2_power variables (start at beta, times beta per step)
+    float *slot[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // [PM, RE, CE][slot]
+    int32_t *map_u = nullptr, *map_d = nullptr, *slot_u = nullptr, *slot_d = nullptr, *cnt = nullptr;
+    float *gu = nullptr, *gd = nullptr, *gce = nullptr, *scal = nullptr;
+    double *acc = nullptr;
+    int64_t cap = 0;                    // pairs the compact buffers hold
+};
+
+void m2d_train_release(m2d_engine *h)
+{
+    m2d_train_state *t = h->train;
+    if (!t) return;
+    for (auto &tb : t->slot)
+        for (float *q : tb)
+            if (q) (void)hipFree(q);
+    for (void *q : {(void *)t->map_u, (void *)t->map_d, (void *)t->slot_u, (void *)t->slot_d, (void *)t->cnt, (void *)t->gu,
+                    (void *)t->gd, (void *)t->gce, (void *)t->scal, (void *)t->acc})
+        if (q) (void)hipFree(q);
+    delete t;
+    h->train = nullptr;
+}
+
+int m2d_train_setup(m2d_engine *h, int32_t learner, float lr, float clip_norm, hipStream_t stream)
+{
+    m2d_train_release(h);
+    m2d_train_state *t = new m2d_train_state;
+    h->train = t;
+    t->learner = learner; t->lr = lr; t->clip = clip_norm;
+    const int64_t n[3] = {h->U * (int64_t)(h->C + 1) * h->E, h->I * (int64_t)h->E, (int64_t)h->C * h->E};
+    const int nslots = (learner == M2D_LEARNER_ADAM || learner == M2D_LEARNER_RMSPROP) ? 2 : learner == M2D_LEARNER_ADAGRAD ? 1 : 0;
+    for (int tb = 0; tb < 3; ++tb)
+        for (int s = 0; s < nslots; ++s) {
+            M2D_HIP_TRY(h, hipMalloc((void **)&t->slot[tb][s], (size_t)n[tb] * 4));
+            // slot initial values: adam m = v = 0; adagrad accumulator 0.1; rmsprop rms = 1, momentum = 0
+            const float v0 = learner == M2D_LEARNER_ADAGRAD ? 0.1f : (learner == M2D_LEARNER_RMSPROP && s == 0) ? 1.0f : 0.0f;
+            hipLaunchKernelGGL(m2d_fill_kernel, dim3(blocks_for(h, n[tb] / 64 + 1)), dim3(256), 0, stream, t->slot[tb][s], n[tb], v0);
+        }
+    M2D_HIP_TRY(h, hipMalloc((void **)&t->map_u, (size_t)h->U * 4));
+    M2D_HIP_TRY(h, hipMalloc((void **)&t->map_d, (size_t)h->I * 4));
+    hipLaunchKernelGGL(m2d_fill_i32_kernel, dim3(blocks_for(h, h->U / 64 + 1)), dim3(256), 0, stream, t->map_u, h->U, -1);
+    hipLaunchKernelGGL(m2d_fill_i32_kernel, dim3(blocks_for(h, h->I / 64 + 1)), dim3(256), 0, stream, t->map_d, h->I, -1);
+    M2D_HIP_TRY(h, hipMalloc((void **)&t->cnt, 2 * 4));
+    M2D_HIP_TRY(h, hipMalloc((void **)&t->gce, (size_t)n[2] * 4));
+    M2D_HIP_TRY(h, hipMalloc((void **)&t->scal, 4 * 4));
+    M2D_HIP_TRY(h, hipMalloc((void **)&t->acc, 2 * 8));
+    M2D_HIP_TRY(h, hipMemsetAsync(t->scal, 0, 16, stream));
+    M2D_HIP_TRY(h, hipGetLastError());
+    return M2D_OK;
+}
+
+int m2d_launch_train_step(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats, const float *labels,
+                          int64_t B, int32_t apply, float *out, hipStream_t stream)
+{
+    m2d_train_state *t = h->train;
+    const int C = h->C, E = h->E, W = (C + 1) * E;
+    if (apply && B > t->cap) {          // compact gradient rows: at most one per pair
+        M2D_HIP_TRY(h, hipStreamSynchronize(stream));
+        for (void *q : {(void *)t->slot_u, (void *)t->slot_d, (void *)t->gu, (void *)t->gd})
+            if (q) (void)hipFree(q);
+        t->slot_u = t->slot_d = nullptr; t->gu = t->gd = nullptr;
+        M2D_HIP_TRY(h, hipMalloc((void **)&t->slot_u, (size_t)B * 4));
+        M2D_HIP_TRY(h, hipMalloc((void **)&t->slot_d, (size_t)B * 4));
+        M2D_HIP_TRY(h, hipMalloc((void **)&t->gu, (size_t)B * W * 4));
+        M2D_HIP_TRY(h, hipMalloc((void **)&t->gd, (size_t)B * E * 4));
+        M2D_HIP_TRY(h, hipMemsetAsync(t->gu, 0, (size_t)B * W * 4, stream));
+        M2D_HIP_TRY(h, hipMemsetAsync(t->gd, 0, (size_t)B * E * 4, stream));
+        t->cap = B;
+    }
+    TrainArgs a;
+    a.pm = const_cast<float *>(h->pm); a.re = const_cast<float *>(h->re); a.ce = const_cast<float *>(h->ce);
+    a.users = users; a.items = items; a.cats = cats; a.labels = labels;
+    a.B = B; a.U = h->U; a.I = h->I; a.user_base = h->user_base; a.C = C; a.E = E; a.a = h->a; a.b = h->b;
+    a.map_u = t->map_u; a.map_d = t->map_d; a.slot_u = t->slot_u; a.slot_d = t->slot_d; a.cnt = t->cnt;
+    a.gu = t->gu; a.gd = t->gd; a.gce = t->gce; a.acc = t->acc; a.scal = t->scal; a.err = h->err_dev;
+    a.accumulate = apply ? 1 : 0; a.clip = t->clip; a.lr = t->lr;      // Global_Step never moves (:240): lr is constant
+    M2D_HIP_TRY(h, hipMemsetAsync(t->cnt, 0, 8, stream));
+    M2D_HIP_TRY(h, hipMemsetAsync(t->acc, 0, 16, stream));
+    M2D_HIP_TRY(h, hipMemsetAsync(t->gce, 0, (size_t)C * E * 4, stream));
+    if (apply) {
+        hipLaunchKernelGGL(m2d_train_claim, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, a);
+        M2D_HIP_TRY(h, hipGetLastError());
+    }
+    const size_t lds = (size_t)4 * C * E * 4;
+    const int ce_lds = lds <= 48 * 1024;
+    hipLaunchKernelGGL(m2d_train_grad, dim3(blocks_for(h, B)), dim3(256), ce_lds ? lds : 0, stream, a, ce_lds);
+    M2D_HIP_TRY(h, hipGetLastError());
+    hipLaunchKernelGGL(m2d_train_finalize, dim3(1), dim3(256), 0, stream, a);
+    M2D_HIP_TRY(h, hipGetLastError());
+    if (out) M2D_HIP_TRY(h, hipMemcpyAsync(out, t->scal, 16, hipMemcpyDeviceToDevice, stream));
+    h->last_kernel = "m2d_train_grad";
+    if (!apply) return M2D_OK;
+
+    RuleArgs r;
+    r.rule = t->learner; r.lr = t->lr; r.b1 = r.b2 = r.eps = 0.f;
+    if (t->learner == M2D_LEARNER_ADAM) {
+        r.b1 = 0.9f; r.b2 = 0.999f; r.eps = 1e-8f;
+        r.lr = t->lr * sqrtf(1.0f - t->b2p) / (1.0f - t->b1p);
+    } else if (t->learner == M2D_LEARNER_RMSPROP) {
+        r.b1 = 0.9f; r.b2 = 0.0f; r.eps = 1e-10f;
+    }
+    struct Tab { float *var; float *G; int32_t *map; int32_t *slot_row; int32_t *count; int64_t R; int32_t W; int idx; };
+    const Tab tabs[3] = {{a.pm, t->gu, t->map_u, t->slot_u, t->cnt + 0, h->U, W, 0},
+                         {a.re, t->gd, t->map_d, t->slot_d, t->cnt + 1, h->I, E, 1},
+                         {a.ce, t->gce, nullptr, nullptr, nullptr, C, E, 2}};
+    for (const Tab &tb : tabs) {
+        float *s0 = t->slot[tb.idx][0], *s1 = t->slot[tb.idx][1];
+        const bool all = t->learner == M2D_LEARNER_ADAM || !tb.map;       // dense gradient: every row
+        const int64_t rows = all ? tb.R : B;
+        const unsigned grid = blocks_for(h, rows);
+        const bool v4 = tb.W % 4 == 0;
+#define M2D_APPLY(ALL, VEC)                                                                                               \
+    hipLaunchKernelGGL((m2d_train_apply<ALL, VEC>), dim3(grid), dim3(256), 0, stream, tb.var, s0, s1, tb.G, tb.map, tb.slot_row, \
+                       tb.count, tb.R, tb.W, t->scal, r)
+        if (all) { if (v4) M2D_APPLY(true, 4); else M2D_APPLY(true, 1); }
+        else { if (v4) M2D_APPLY(false, 4); else M2D_APPLY(false, 1); }
+#undef M2D_APPLY
+        M2D_HIP_TRY(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(m2d_train_cleanup, dim3(blocks_for(h, B)), dim3(256), 0, stream, t->map_u, t->slot_u, t->cnt + 0, t->gu, W);
+    hipLaunchKernelGGL(m2d_train_cleanup, dim3(blocks_for(h, B)), dim3(256), 0, stream, t->map_d, t->slot_d, t->cnt + 1, t->gd, E);
+    M2D_HIP_TRY(h, hipGetLastError());
+    if (t->learner == M2D_LEARNER_ADAM) { t->b1p *= 0.9f; t->b2p *= 0.999f; }      // AdamOptimizer._finish
+    t->steps += 1;
+    // everything derived from Recipe_Embedding / Category_Embedding is stale now
+    h->dish_vec_valid = false;
+    h->grp_valid = false;
+    return M2D_OK;
+}
+
+int m2d_train_get_slot(m2d_engine *h, int32_t table, int32_t slot, float **dev, int64_t *count)
+{
+    m2d_train_state *t = h->train;
+    const int64_t n[3] = {h->U * (int64_t)(h->C + 1) * h->E, h->I * (int64_t)h->E, (int64_t)h->C * h->E};
+    *dev = t->slot[table][slot];
+    *count = *dev ? n[table] : 0;
+    return M2D_OK;
+}

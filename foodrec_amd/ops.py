@@ -176,6 +176,55 @@ class ScoringEngine:
             return float(s[0] / self.pm.numel()), float(s[1] / general_memory.numel())
         return None
 
+    # -- training step ----------------------------------------------------------
+    LEARNERS = {"sgd": 0, "adagrad": 1, "rmsprop": 2, "adam": 3}
+
+    def train_begin(self, learner: str = "adam", lr: float = 0.001, clip_norm: float = 5.0):
+        """Model.train's optimizer choice (Model_Recommender.py:228-235): anything but adagrad / rmsprop / adam is
+        gradient descent.  Allocates the optimizer slots; the three tables are updated in place from now on."""
+        code = self.LEARNERS.get(str(learner).lower(), 0)
+        with torch.cuda.device(self.device):
+            rc = _native.lib().m2d_train_begin(self._h, code, float(lr), float(clip_norm), _stream_ptr())
+        _native.raise_for(rc, self._h)
+        self._training = True
+
+    def train_step(self, users: torch.Tensor, items: torch.Tensor, cats: torch.Tensor, labels: torch.Tensor,
+                   apply: bool = True) -> torch.Tensor:
+        """One sess.run([loss_value, learning_rate, train_op]) (Train_recommender.py:189-199).  Returns a device
+        float32[4]: loss, global gradient norm, clip scale, learning rate.  apply=False: loss / norm only."""
+        self._check_ids(users, items)
+        B = users.numel()
+        f = lambda t, n: t.to(device=self.device, dtype=torch.float32).reshape(B, n).contiguous()
+        cats, labels = f(cats, self.C), f(labels, 1)
+        out = torch.empty(4, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = _native.lib().m2d_train_step(self._h, users.contiguous().data_ptr(), items.contiguous().data_ptr(),
+                                              cats.data_ptr(), labels.data_ptr(), B, 1 if apply else 0, out.data_ptr(),
+                                              _stream_ptr())
+        _native.raise_for(rc, self._h)
+        return out
+
+    def train_slot(self, table: int, slot: int, restore: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Optimizer slot `slot` of table 0 = PM, 1 = RE, 2 = CE (adam: m, v; adagrad: accumulator; rmsprop: rms,
+        momentum) as a tensor shaped like the table; with `restore`, that tensor is written INTO the slot instead
+        (checkpoint resume)."""
+        ref = (self.pm, self.re, self.ce)[table]
+        if restore is not None:
+            buf = restore.to(device=self.device, dtype=torch.float32).contiguous()
+            if buf.shape != ref.shape:
+                raise ValueError("slot must be shaped like its table %s" % (tuple(ref.shape),))
+        else:
+            buf = torch.empty_like(ref)
+        with torch.cuda.device(self.device):
+            rc = _native.lib().m2d_train_slot(self._h, int(table), int(slot), buf.data_ptr(), 0 if restore is None else 1,
+                                              _stream_ptr())
+        _native.raise_for(rc, self._h)
+        return buf
+
+    def train_end(self):
+        _native.raise_for(_native.lib().m2d_train_end(self._h), self._h)
+        self._training = False
+
     def set_option(self, name: str, value: int):
         _native.raise_for(_native.lib().m2d_set_option(self._h, name.encode(), int(value)), self._h)
 

@@ -5,8 +5,10 @@ and its one call site ``sess.run([model.logits], feed_dict)`` (``evaluate.py:55-
 constructor signature and attribute names are kept so reference-style driver code reads the same;
 the graph itself is replaced by one fused HIP kernel behind ``include/m2d.h``.
 
-Only the forward (scoring) path exists here.  ``loss`` / ``Write_Memory`` / ``train``
-(Model_Recommender.py:99-241) are out of scope.
+The forward (scoring) path is the product.  The training-side fetches of the
+reference's driver (Train_recommender.py:180-199) -- ``loss_value``, ``learning_rate``, ``train_op``
+(Model_Recommender.py:99-104, :223-241; section 8f row N4) and ``personal`` / ``general``
+(``Write_Memory``, :106-220; row N2) -- are served by the same engine through ``Session.run``.
 """
 from __future__ import annotations
 
@@ -27,6 +29,11 @@ class _Placeholder:
 
     def __repr__(self):
         return "<placeholder %s>" % self.name
+
+
+class _ScalarFetch(float):
+    """``model.learning_rate``: a number (args.lr) that can also be named in ``sess.run`` fetches
+    (Model_Recommender.py:11, :227; Train_recommender.py:190)."""
 
 
 class _Fetch:
@@ -93,6 +100,17 @@ class Model:
         self.dropout_keep_prob = _Placeholder("dropout_keep_prob", False)
         self.is_training_flag = _Placeholder("is_training_flag", False)
         self.logits = _Fetch("logits")
+        # training-side fetches (Model_Recommender.py:38-41, :13); Global_Step never moves in the reference
+        # (apply_gradients is called without it, :240), so learning_rate stays args.lr
+        self.loss_value = _Fetch("loss_value")
+        self.train_op = _Fetch("train_op")
+        self.personal = _Fetch("personal")
+        self.general = _Fetch("general")
+        self.learning_rate = _ScalarFetch(0.001 if self.learning_rate is None else self.learning_rate)   # --lr default
+        self.global_step = 0
+        self.epoch_step = 0
+        self.epoch_increment = _Fetch("epoch_increment")
+        self._train_started = False
 
         pm_shape = tuple(Personal_Memory.shape)
         if len(pm_shape) != 3 or pm_shape[1] != self.num_categories + 1 or pm_shape[2] != self.embed_size:
@@ -103,6 +121,7 @@ class Model:
         self.engine = ScoringEngine(Personal_Memory, Recipe_Embedding, Category_Embedding,
                                     coef=self.high_level_score_coefficient, device=device, user_base=user_base)
         self.device = self.engine.device
+        self._gm_dev = None             # General_Memory on the device, created by the first personal / general fetch
 
     # -- predict ------------------------------------------------------------------------------------
     def predict_device(self, user_input, item_input, categories) -> torch.Tensor:
@@ -127,6 +146,51 @@ class Model:
         out = self.predict_device(user_input, item_input, categories)
         self.engine.check()
         return out.cpu().numpy()
+
+    # -- training side -----------------------------------------------------
+    def _feeds(self, user_input, item_input, categories):
+        u, d = _ids(user_input, "user"), _ids(item_input, "item")
+        B = len(u)
+        if len(d) != B:
+            raise ValueError("user_input and item_input differ in length")
+        m = _mask(categories, self.num_categories, B)
+        dev = self.device
+        ut = u.to(dev, torch.int32) if isinstance(u, torch.Tensor) else torch.from_numpy(u).to(dev)
+        dt = d.to(dev, torch.int32) if isinstance(d, torch.Tensor) else torch.from_numpy(d).to(dev)
+        mt = m.to(dev) if isinstance(m, torch.Tensor) else torch.from_numpy(m).to(dev)
+        return ut, dt, mt
+
+    def train_step(self, user_input, item_input, categories, labels, apply: bool = True):
+        """``sess.run([model.loss_value, model.learning_rate, model.train_op], feed_dict)``
+        (Train_recommender.py:189-199): returns ``(loss, learning_rate)`` as Python floats; with ``apply=False``
+        only the loss is evaluated.  The optimizer is ``args.learner`` at ``args.lr`` (Model_Recommender.py:223-241)."""
+        if not self._train_started:
+            self.engine.train_begin(self.learner or "sgd", float(self.learning_rate), 5.0)
+            self._train_started = True
+        ut, dt, mt = self._feeds(user_input, item_input, categories)
+        y = torch.as_tensor(np.asarray(labels, dtype=np.float32) if not isinstance(labels, torch.Tensor) else labels)
+        out = self.engine.train_step(ut, dt, mt, y, apply=apply)
+        self.engine.check()
+        loss, _norm, _scale, lr = (float(v) for v in out.cpu().numpy())
+        return loss, lr
+
+    def write_memory(self, user_input, item_input, categories, write_sign, user_one_hot_label):
+        """The ``personal`` / ``general`` fetches (``Write_Memory``, Model_Recommender.py:106-220): updates
+        Personal_Memory and General_Memory in place, returns ``(mean(Personal_Memory), mean(General_Memory))``."""
+        if self._gm_dev is None:
+            if self.General_Memory is None:
+                raise ValueError("Model was built without General_Memory")
+            self._gm_dev = torch.as_tensor(np.asarray(self.General_Memory, dtype=np.float32)).to(self.device).contiguous()
+        ut, dt, mt = self._feeds(user_input, item_input, categories)
+        B = ut.numel()
+        sign = torch.as_tensor(np.asarray(write_sign, dtype=np.float32)).reshape(B)
+        y = torch.as_tensor(np.asarray(user_one_hot_label, dtype=np.float32)).reshape(B, -1)
+        return self.engine.write_memory(ut, dt, mt, sign, y, self._gm_dev, float(self.beta_1), float(self.beta_2),
+                                        float(self.alpha), want_means=True)
+
+    def general_memory(self) -> np.ndarray:
+        """General_Memory as it stands (host copy)."""
+        return np.asarray(self.General_Memory, dtype=np.float32) if self._gm_dev is None else self._gm_dev.cpu().numpy()
 
     # -- resident dish -> category table (dish_to_category.json) --------------------------------------
     def set_dish_categories(self, dish_to_category, num_dishes: Optional[int] = None):
@@ -191,17 +255,54 @@ class Session:
     def __init__(self, model: Model):
         self.model = model
 
-    def run(self, fetches, feed_dict):
+    def run(self, fetches, feed_dict=None):
+        """Fetches served: ``logits`` (evaluate.py:58); ``loss_value``, ``learning_rate``, ``train_op``, ``personal``,
+        ``general`` (Train_recommender.py:180-199); ``epoch_increment`` / ``epoch_step`` (:155, :204).
+
+        The reference fetches the memory write and ``train_op`` in one ``sess.run`` with no control dependency
+        between them, so TF may order them either way; here the optimizer step runs first and ``Write_Memory``
+        sees the updated tables."""
         as_list = isinstance(fetches, (list, tuple))
         fl: Sequence = fetches if as_list else [fetches]
         m = self.model
+        known = (m.logits, m.loss_value, m.train_op, m.personal, m.general, m.epoch_increment, m.learning_rate)
         for f in fl:
-            if f is not m.logits:
-                raise NotImplementedError("only model.logits can be fetched (forward path); got %r" % (f,))
-        try:
-            u, d, c = feed_dict[m.user_input], feed_dict[m.item_input], feed_dict[m.categories]
-        except KeyError as e:
-            raise ValueError("feed_dict is missing %r" % (e.args[0],)) from None
-        scores = m.predict(u, d, c)
-        out = [scores for _ in fl]
+            if not any(f is k for k in known) and f != "epoch_step":
+                raise NotImplementedError("fetch %r is not served" % (f,))
+        feed_dict = feed_dict or {}
+
+        def feed(key, what):
+            try:
+                return feed_dict[key]
+            except KeyError:
+                raise ValueError("feed_dict is missing %r" % (what,)) from None
+
+        has = lambda k: any(f is k for f in fl)
+        res = {}
+        if has(m.logits):
+            res[id(m.logits)] = m.predict(feed(m.user_input, m.user_input), feed(m.item_input, m.item_input),
+                                          feed(m.categories, m.categories))
+        if has(m.train_op) or has(m.loss_value):
+            loss, lr = m.train_step(feed(m.user_input, m.user_input), feed(m.item_input, m.item_input),
+                                    feed(m.categories, m.categories), feed(m.labels, m.labels), apply=has(m.train_op))
+            res[id(m.loss_value)] = np.float32(loss)
+            res[id(m.train_op)] = None
+            res["lr"] = np.float32(lr)
+        if has(m.personal) or has(m.general):
+            pmean, gmean = m.write_memory(feed(m.user_input, m.user_input), feed(m.item_input, m.item_input),
+                                          feed(m.categories, m.categories), feed(m.write_sign, m.write_sign),
+                                          feed(m.user_one_hot_label, m.user_one_hot_label))
+            res[id(m.personal)] = np.float32(pmean)
+            res[id(m.general)] = np.float32(gmean)
+        out = []
+        for f in fl:
+            if f is m.learning_rate:
+                out.append(res.get("lr", np.float32(m.learning_rate)))
+            elif f is m.epoch_increment:
+                m.epoch_step += 1
+                out.append(m.epoch_step)
+            elif isinstance(f, str) and f == "epoch_step":
+                out.append(m.epoch_step)
+            else:
+                out.append(res[id(f)])
         return out if as_list else out[0]

@@ -108,6 +108,33 @@ int m2d_write_memory(m2d_engine *h, const int32_t *users, const int32_t *items, 
                      const float *write_sign, const float *labels, int64_t B, int32_t L, float *general_memory,
                      float beta_1, float beta_2, float alpha, double *out_sums, void *stream);
 
+/* Training step.  Replaces Model.loss + Model.train (Model_Recommender.py:99-104,
+ * :223-241) as the driver runs them: sess.run([model.loss_value, model.learning_rate, ..., model.train_op], feed_dict)
+ * (Train_recommender.py:180-199).  All three tables given to m2d_create are updated IN PLACE and must be writable
+ * device memory (M2D_TABLES_DEVICE) or engine-owned; General_Memory gets no gradient and is not involved.
+ *   m2d_train_begin  `learner` as the reference's --learner flag (:228-235: adagrad / rmsprop / adam, anything else
+ *                    is gradient descent), `lr` = args.lr (the decayed rate equals it for ever: apply_gradients is
+ *                    called without global_step, :240), `clip_norm` = 5.0 in the reference (:237).  Allocates the
+ *                    optimizer slots (TF 1.x initial values) and scratch; calling it again resets the optimizer.
+ *   m2d_train_step   users/items i32[B], cats f32[B, C], labels f32[B].  apply = 1: loss, gradients, global-norm
+ *                    clip and the update; apply = 0: loss and gradient norm only (the loss_value fetch alone).
+ *                    out (device f32[4], may be NULL) receives {loss, global gradient norm, clip scale, lr}.
+ *   m2d_train_slot   copies optimizer slot `slot` of table 0 = Personal_Memory, 1 = Recipe_Embedding,
+ *                    2 = Category_Embedding (adam: m, v; adagrad: accumulator; rmsprop: rms, momentum) into `buf`
+ *                    (restore = 0) or from it (restore = 1); `buf` is device memory shaped like the table.  For
+ *                    checkpoint / resume (the reference's tf.train.Saver covers the slots too).
+ *                    M2D_ERR_INVALID_ARG when the learner has no such slot.
+ * The update rules restate TF 1.x's published behaviour (oracle/train_oracle.py); parity is unpinned. */
+#define M2D_LEARNER_SGD 0
+#define M2D_LEARNER_ADAGRAD 1
+#define M2D_LEARNER_RMSPROP 2
+#define M2D_LEARNER_ADAM 3
+int m2d_train_begin(m2d_engine *h, int32_t learner, float lr, float clip_norm, void *stream);
+int m2d_train_step(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats, const float *labels,
+                   int64_t B, int32_t apply, float *out, void *stream);
+int m2d_train_slot(m2d_engine *h, int32_t table, int32_t slot, float *buf, int32_t restore, void *stream);
+int m2d_train_end(m2d_engine *h);
+
 /* ---- build-defined extension, NO reference counterpart (BASELINE.json configs 2-5) ----
  * Multi-hot ingredient table for the high-level path:
  *     H[d]  = sum_j w_j ING[id_j] / sum_j w_j     over dish d's list ids[off[d] .. off[d+1])

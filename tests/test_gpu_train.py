@@ -1,0 +1,175 @@
+"""GPU parity of the training step (m2d_train_begin / m2d_train_step) against the build's
+restatement of the TF 1.x rules (oracle/train_oracle.py -- PARITY UNPINNED, see its header).
+
+Tolerances.  Loss and gradient norm: 1e-5 relative.  Tables after k steps: float32 arithmetic against a float64
+oracle; Adam divides by sqrt(v) + 1e-8, so an element whose gradient is ~0 in float32 but not in float64 may move
+by up to lr in one and not the other -- the bound on a table is therefore stated as a fraction of what the step
+moved (1e-3 of lr per step for adam / rmsprop, 1e-5 relative for sgd / adagrad)."""
+import types
+
+import numpy as np
+import pytest
+
+from helpers import random_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _batches(U, I, C, B, steps, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(steps):
+        users = rng.integers(0, U, B).astype(np.int32)
+        items = rng.integers(0, I, B).astype(np.int32)
+        users[: B // 4] = users[0]                          # duplicate ids: their rows must be summed
+        items[B // 8: B // 2] = items[B // 8]
+        cats = rng.integers(0, 2, (B, C)).astype(np.float32)
+        cats[cats.sum(1) == 0, rng.integers(0, C)] = 1.0
+        cats[B // 3] *= 0.5                                 # masks are weights
+        labels = rng.integers(0, 2, B).astype(np.float32)
+        out.append((users, items, cats, labels))
+    return out
+
+
+def _engine(PM, RE, CE):
+    from foodrec_amd import ScoringEngine
+    return ScoringEngine(PM.copy(), RE.copy(), CE.copy())
+
+
+@pytest.mark.parametrize("learner", ["adam", "sgd", "adagrad", "rmsprop"])
+@pytest.mark.parametrize("U,I,C,E,B", [(300, 100, 4, 32, 128), (64, 40, 4, 200, 8), (50, 30, 3, 6, 257), (2000, 500, 4, 64, 4096)])
+def test_train_steps_match_restatement(learner, U, I, C, E, B):
+    import torch
+    from oracle import train_oracle as T
+    PM, RE, CE, *_ = random_case(U, I, C, E, 1, seed=U + E)
+    PM, RE, CE = PM * 3, RE * 3, CE * 3
+    lr = 0.01
+    eng = _engine(PM, RE, CE)
+    eng.train_begin(learner, lr)
+    st = T.TrainState(PM, RE, CE, learner, lr)
+    steps = 3
+    for k, (users, items, cats, labels) in enumerate(_batches(U, I, C, B, steps, seed=B)):
+        ref_loss, ref_norm = st.step(users, items, cats, labels)
+        out = eng.train_step(torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda"),
+                             torch.as_tensor(cats, device="cuda"), torch.as_tensor(labels, device="cuda"))
+        eng.check()
+        loss, norm, scale, got_lr = out.cpu().numpy()
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (k, loss, ref_loss)
+        assert abs(norm - ref_norm) <= 1e-5 * max(1.0, ref_norm), (k, norm, ref_norm)
+        assert got_lr == np.float32(lr)
+        assert scale == pytest.approx(5.0 * min(1.0 / ref_norm, 0.2), rel=1e-5)
+    assert eng.last_kernel() == "m2d_train_grad"
+    tol = 1e-3 * lr * steps if learner in ("adam", "rmsprop") else 1e-5
+    for name, got, ref, ini in (("PM", eng.pm, st.PM, PM), ("RE", eng.re, st.RE, RE), ("CE", eng.ce, st.CE, CE)):
+        got = got.cpu().numpy().astype(np.float64)
+        assert np.abs(ref - ini).max() > 0, name            # the step did something
+        err = np.abs(got - ref)
+        bound = tol * np.maximum(1.0, np.abs(ref)) if learner in ("sgd", "adagrad") else tol
+        assert np.all(err <= bound), "%s %s: max err %.3e" % (learner, name, err.max())
+    # optimizer slots (what a checkpoint would hold)
+    if learner == "adam":
+        for tb, ref_t in enumerate(st.slots):
+            for sl in range(2):
+                got = eng.train_slot(tb, sl).cpu().numpy()
+                np.testing.assert_allclose(got, ref_t[sl], rtol=2e-4, atol=1e-9 if sl else 1e-7)
+    elif learner == "sgd":
+        with pytest.raises(ValueError):
+            eng.train_slot(0, 0)
+    eng.train_end()
+
+
+def test_clip_engages_and_loss_only_leaves_tables_alone():
+    import torch
+    from oracle import train_oracle as T
+    U, I, C, E, B = 200, 80, 4, 64, 512
+    PM, RE, CE, *_ = random_case(U, I, C, E, 1, seed=11)
+    PM, RE, CE = PM * 200, RE * 200, CE * 200               # huge logits -> gradient norm well above 5
+    (users, items, cats, labels), = _batches(U, I, C, B, 1, seed=5)
+    eng = _engine(PM, RE, CE)
+    eng.train_begin("sgd", 0.5)
+    dev = lambda a: torch.as_tensor(a, device="cuda")
+    out = eng.train_step(dev(users), dev(items), dev(cats), dev(labels), apply=False).cpu().numpy()
+    eng.check()
+    st = T.TrainState(PM, RE, CE, "sgd", 0.5)
+    ref_loss, ref_norm = st.step(users, items, cats, labels, apply=False)
+    assert ref_norm > 5.0
+    assert abs(out[0] - ref_loss) <= 1e-5 * abs(ref_loss) and abs(out[1] - ref_norm) <= 1e-5 * ref_norm
+    assert torch.equal(eng.pm.cpu(), torch.as_tensor(PM)) and torch.equal(eng.re.cpu(), torch.as_tensor(RE))
+    assert torch.equal(eng.ce.cpu(), torch.as_tensor(CE))
+    out = eng.train_step(dev(users), dev(items), dev(cats), dev(labels)).cpu().numpy()
+    eng.check()
+    st.step(users, items, cats, labels)
+    assert out[2] == pytest.approx(5.0 / ref_norm, rel=1e-5)
+    for got, ref in ((eng.pm, st.PM), (eng.re, st.RE), (eng.ce, st.CE)):
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-5, atol=1e-4)
+    # scoring after training reads the updated tables
+    from oracle import m2d_oracle as oracle
+    got = eng.score_pairs(dev(users), dev(items), dev(cats)).cpu().numpy(); eng.check()
+    ref = oracle.inference_f64(st.PM.astype(np.float32), st.RE.astype(np.float32), st.CE.astype(np.float32), users, items, cats)
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-2)
+
+
+def test_errors_and_slot_restore():
+    import torch
+    U, I, C, E, B = 100, 50, 4, 32, 64
+    PM, RE, CE, *_ = random_case(U, I, C, E, 1, seed=3)
+    (users, items, cats, labels), = _batches(U, I, C, B, 1, seed=1)
+    dev = lambda a: torch.as_tensor(a, device="cuda")
+    eng = _engine(PM, RE, CE)
+    with pytest.raises(ValueError, match="m2d_train_begin"):
+        eng.train_step(dev(users), dev(items), dev(cats), dev(labels))
+    eng.train_begin("adam", 0.001)
+    bad = users.copy(); bad[5] = U + 3
+    with pytest.raises(IndexError, match="user id %d at position 5" % (U + 3)):
+        eng.train_step(dev(bad), dev(items), dev(cats), dev(labels)); eng.check()
+    # resume: a second engine fed the first one's tables and slots continues identically
+    eng.train_begin("adam", 0.001)                                   # reset after the failed step
+    eng2 = _engine(PM, RE, CE)
+    eng2.train_begin("adam", 0.001)
+    eng.train_step(dev(users), dev(items), dev(cats), dev(labels)); eng.check()
+    eng2.train_step(dev(users), dev(items), dev(cats), dev(labels)); eng2.check()
+    for tb in range(3):
+        for sl in range(2):
+            np.testing.assert_allclose(eng.train_slot(tb, sl).cpu().numpy(), eng2.train_slot(tb, sl).cpu().numpy(), rtol=1e-5, atol=1e-9)
+            eng2.train_slot(tb, sl, restore=eng.train_slot(tb, sl))
+            assert torch.equal(eng.train_slot(tb, sl), eng2.train_slot(tb, sl))
+
+
+def test_session_serves_the_training_fetches():
+    """The two sess.run call shapes of Train_recommender.py:170-199."""
+    from foodrec_amd import Model, Session
+    from oracle import m2d_oracle as oracle
+    from oracle import train_oracle as T
+    U, I, C, E, L, B = 120, 60, 4, 32, 7, 16
+    PM, RE, CE, *_ = random_case(U, I, C, E, 1, seed=21)
+    rng = np.random.default_rng(0)
+    GM = (rng.standard_normal((L, C + 1, E)) / 8).astype(np.float32)
+    args = types.SimpleNamespace(learner="adam", num_categories=C, num_users=U, num_labels=L, embed_size=E, lr=0.002,
+                                 decay_steps=1000, decay_rate=1.0, high_level_score_coefficient=0.99, beta_1=0.01,
+                                 beta_2=0.01, alpha=0.01)
+    model = Model(args, PM.copy(), RE.copy(), CE.copy(), GM.copy())
+    sess = Session(model)
+    (users, items, cats, labels), = _batches(U, I, C, B, 1, seed=9)
+    sign = np.where(labels > 0, 1.0, -1.0).astype(np.float32)[:, None]
+    onehot = (rng.random((B, L)) < 0.3).astype(np.float32); onehot[:, 0] = 1
+    feed = {model.user_input: [str(u) for u in users], model.item_input: list(items), model.labels: list(labels),
+            model.categories: cats[:, :, None].tolist(), model.user_one_hot_label: onehot.tolist(),
+            model.write_sign: sign.tolist(), model.dropout_keep_prob: 0.8, model.is_training_flag: True}
+    st = T.TrainState(PM, RE, CE, "adam", 0.002)
+    ref_loss0, _ = st.step(users, items, cats, labels, apply=False)
+    assert sess.run(model.loss_value, feed) == pytest.approx(ref_loss0, rel=1e-5)          # loss only: no update
+    curr_loss, lr, general, _ = sess.run([model.loss_value, model.learning_rate, model.general, model.train_op], feed)
+    ref_loss, _ = st.step(users, items, cats, labels)
+    assert curr_loss == pytest.approx(ref_loss, rel=1e-5) and lr == np.float32(0.002)
+    # the memory write ran after the optimizer step, on the updated tables
+    pm32, re32, ce32 = (t.astype(np.float32) for t in (st.PM, st.RE, st.CE))
+    refPM, refGM, _, _ = oracle.write_memory(pm32, re32, ce32, GM, users, items, cats, sign, onehot, 0.01, 0.01, 0.01)
+    assert general == pytest.approx(refGM.mean(), rel=1e-4, abs=1e-7)
+    np.testing.assert_allclose(model.general_memory(), refGM, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(model.engine.pm.cpu().numpy(), refPM, rtol=1e-3, atol=2e-6)
+    loss2, lr2, personal, general2, _ = sess.run([model.loss_value, model.learning_rate, model.personal, model.general,
+                                                  model.train_op], feed)
+    assert np.isfinite(personal) and np.isfinite(general2) and loss2 < curr_loss + 1.0
+    assert sess.run(model.epoch_increment) == 1
+    with pytest.raises(ValueError, match="labels"):
+        sess.run([model.train_op], {k: v for k, v in feed.items() if k is not model.labels})
