@@ -27,6 +27,8 @@
 //   finalize  one block: norm over dCE joins in, writes {loss, global norm, scale, lr};
 //   apply     rows (Adam: all rows; others: claimed rows) and the dense dCE;
 //   cleanup   claimed rows: map entry back to -1, compact gradient row back to zero.
+// An out-of-range id is latched by the claim pass (m2d_check reports it) and the apply pass then leaves every
+// table and slot as it was -- TF raises InvalidArgumentError from the gather before anything is assigned.
 // Sums are float atomics: results are order-dependent in the last bits, like m2d_write_memory.
 #include "m2d_engine.h"
 
@@ -234,9 +236,10 @@ __device__ __forceinline__ void lane_set(float &v, int, float x) { v = x; }
 template <bool ALL, int VEC>
 __global__ __launch_bounds__(256) void m2d_train_apply(float *var, float *s0, float *s1, const float *G, const int32_t *map,
                                                        const int32_t *slot_row, const int32_t *count, int64_t R, int32_t W,
-                                                       const float *scal, RuleArgs r)
+                                                       const float *scal, RuleArgs r, const int32_t *err)
 {
     typedef typename RowVec<VEC>::T vf;
+    if (err[0] != 0) return;    // an id was out of range: like TF's InvalidArgumentError, the step applies nothing
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -416,7 +419,7 @@ int m2d_launch_train_step(m2d_engine *h, const int32_t *users, const int32_t *it
         const bool v4 = tb.W % 4 == 0;
 #define M2D_APPLY(ALL, VEC)                                                                                               \
     hipLaunchKernelGGL((m2d_train_apply<ALL, VEC>), dim3(grid), dim3(256), 0, stream, tb.var, s0, s1, tb.G, tb.map, tb.slot_row, \
-                       tb.count, tb.R, tb.W, t->scal, r)
+                       tb.count, tb.R, tb.W, t->scal, r, h->err_dev)
         if (all) { if (v4) M2D_APPLY(true, 4); else M2D_APPLY(true, 1); }
         else { if (v4) M2D_APPLY(false, 4); else M2D_APPLY(false, 1); }
 #undef M2D_APPLY

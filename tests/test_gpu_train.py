@@ -122,6 +122,8 @@ def test_errors_and_slot_restore():
     bad = users.copy(); bad[5] = U + 3
     with pytest.raises(IndexError, match="user id %d at position 5" % (U + 3)):
         eng.train_step(dev(bad), dev(items), dev(cats), dev(labels)); eng.check()
+    assert torch.equal(eng.pm.cpu(), torch.as_tensor(PM)) and torch.equal(eng.re.cpu(), torch.as_tensor(RE))   # nothing applied
+    assert float(eng.train_slot(0, 0).abs().max()) == 0.0
     # resume: a second engine fed the first one's tables and slots continues identically
     eng.train_begin("adam", 0.001)                                   # reset after the failed step
     eng2 = _engine(PM, RE, CE)
