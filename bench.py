@@ -44,11 +44,14 @@ def parse():
     p.add_argument("--dishes", type=int, default=100_000)
     p.add_argument("--embed", type=int, default=64)
     p.add_argument("--pairs", type=int, default=1 << 22, help="pairs per step per GPU")
-    p.add_argument("--workload", choices=["pairs", "ingredients", "mlp", "topk"], default="pairs",
+    p.add_argument("--learner", default="adam", help="workload train: adam / adagrad / rmsprop / sgd")
+    p.add_argument("--workload", choices=["pairs", "ingredients", "mlp", "topk", "train"], default="pairs",
                    help="pairs = BASELINE configs[1] (reference forward, HBM-bound); ingredients = configs[1] with the "
                         "build-defined 10k-row ingredient table on the high-level path; mlp = configs[2] (build-defined "
                         "3-layer head, MFMA-bound; pass --embed 128); topk = configs[3]/[4] retrieval: full-catalogue "
-                        "top-10 for --topk-users users per GPU + all-gather of the results (MFMA-bound)")
+                        "top-10 for --topk-users users per GPU + all-gather of the results (MFMA-bound); train = the reference's "
+                        "training step (SURVEY.md 8f N4) at its own default sizes unless --users/--dishes/--embed/--pairs "
+                        "are given: loss + gradients + clip + optimizer update per step, single GPU")
     p.add_argument("--ingredients", type=int, default=10_000, help="rows of the ingredient table (workload ingredients)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
@@ -296,6 +299,49 @@ def side_measurements(torch, eng, PM, U, I, C, E, dev, user_base):
     return nr, probe
 
 
+def train_workload(a, torch, foodrec_amd, dev):
+    """Single-GPU training-step throughput.  Default shape = the reference's flags
+    (Train_recommender.py:35, :51-58): 64 657 users, 4 548 dishes, E = 200, batch 128."""
+    import sys as _sys
+    given = lambda name: any(x == name or x.startswith(name + "=") for x in _sys.argv)
+    U = a.users if given("--users") else 64657
+    I = a.dishes if given("--dishes") else 4548
+    E = a.embed if given("--embed") else 200
+    B = a.pairs if given("--pairs") else 128
+    C = 4
+    PM, RE, CE, users, items, cats = make_inputs(torch, dev, U, I, C, E, B, 20260101 + 6, 0)
+    labels = (torch.rand(B, device=dev) < 0.5).float()
+    eng = foodrec_amd.ScoringEngine(PM, RE, CE, coef=0.99, device=dev)
+    eng.train_begin(a.learner, 0.001)
+    step = lambda: eng.train_step(users, items, cats, labels)
+    for _ in range(a.warmup):
+        step()
+    eng.check()
+    wall, per = time_steps(torch, eng, users, items, cats, None, a.steps, step)
+    eng.check()
+    avg_ms = sum(per) / len(per)
+    table_bytes = 4 * (PM.numel() + RE.numel() + CE.numel())
+    dense = a.learner.lower() == "adam"
+    # Adam (TF 1.x, not lazy): var, m, v of EVERY row read and written.  Others: the batch's rows only.
+    pair_bytes = (2 * (C + 2) * E * 4 + C * 4 + 12) * B          # forward gather + gradient rows out
+    alg = (6 * table_bytes if dense else 0) + pair_bytes
+    ach = alg / (avg_ms * 1e-3) / 1e9
+    line = {"metric": "trained (user,dish) pairs/sec", "value": B * a.steps / wall, "unit": "pairs/s", "n_gpus": 1,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "training step of Model_Recommender.py:99-104, :223-241 (sigmoid-CE loss, gradients, "
+                                   "global-norm clip 5.0, %s update as TF 1.x applies it) on %d users x %d dishes, C=4, "
+                                   "E=%d, batch %d; NOT the headline metric (SURVEY.md 8f row N4)" % (a.learner, U, I, E, B),
+                       "users": U, "dishes": I, "embed_size": E, "batch": B, "learner": a.learner},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None, "step_avg_ms": avg_ms, "algorithmic_bytes_per_step": alg,
+                         "note": ("whole step (claim + grad + finalize + 3 apply + 2 cleanup launches) over the bytes the "
+                                  "update rule must move: 6 x table bytes for TF 1.x Adam, which decays and moves every "
+                                  "row every step" if dense else
+                                  "whole step over the batch rows' bytes; launch-bound at this batch size")}}
+    print(json.dumps(line))
+
+
 def main():
     a = parse()
     import torch
@@ -321,6 +367,13 @@ def main():
         if use_dist:
             dist.barrier()
     import foodrec_amd
+    if a.workload == "train":
+        if rank == 0:
+            train_workload(a, torch, foodrec_amd, dev)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     C, E, U, I, B = 4, a.embed, a.users, a.dishes, a.pairs
     user_base = rank * U
     PM, RE, CE, users, items, cats = make_inputs(torch, dev, U, I, C, E, B, 20260101 + 2 + rank, user_base)
