@@ -16,6 +16,7 @@ sequence, since Python's ordering of NaN keys is whatever that sequence does.
 from __future__ import annotations
 
 import heapq
+import itertools
 import math
 from typing import Dict, List, Sequence, Tuple
 
@@ -71,19 +72,28 @@ def evaluate_model(sess, model: Model, testRatings: Dict[str, List[int]], testNe
             raise TypeError("cannot unpack non-iterable NoneType object (user %s has no test rating)" % u)
     if not users:
         return [], []
+    # evaluate.py:39-51 for every user at once: the positive first, then negatives 50..99.  One flat int array;
+    # the per-user Python work is one list concatenation.
     cand = [_candidates(u, testRatings, testNegatives) for u in users]
-    for items in cand:
-        for it in items:
-            if str(it) not in dish_to_category:
-                raise KeyError(str(it))                      # evaluate.py:43 / :50 would raise the same
-    lens = np.fromiter((len(c) for c in cand), dtype=np.int32, count=len(cand))
+    lens = np.fromiter(map(len, cand), dtype=np.int32, count=len(cand))
+    flat = np.fromiter(itertools.chain.from_iterable(cand), dtype=np.int64, count=int(lens.sum()))
+    for it in np.unique(flat).tolist():
+        if str(it) not in dish_to_category:
+            raise KeyError(str(it))                          # evaluate.py:43 / :50 would raise the same
     L = int(lens.max())
     if L > 1024 or K > 64:
         raise ValueError("evaluate_model: at most 1024 candidates per user and K <= 64 on the device path")
-    items_np = np.zeros((len(cand), L), dtype=np.int32)
-    for r, c in enumerate(cand):
-        items_np[r, :len(c)] = c
-    users_np = np.fromiter((int(u) for u in users), dtype=np.int32, count=len(users))
+    if flat.size and (flat.min() < -(2 ** 31) or flat.max() >= 2 ** 31):
+        raise IndexError("item id does not fit int32")
+    if int(lens.min()) == L:
+        items_np = flat.astype(np.int32).reshape(len(cand), L)
+    else:
+        items_np = np.zeros((len(cand), L), dtype=np.int32)
+        items_np[np.arange(L)[None, :] < lens[:, None]] = flat
+    users_np = np.fromiter(map(int, users), dtype=np.int64, count=len(users))
+    if users_np.min() < -(2 ** 31) or users_np.max() >= 2 ** 31:
+        raise IndexError("user id does not fit int32")
+    users_np = users_np.astype(np.int32)
 
     model.set_dish_categories(dish_to_category)
     eng = model.engine
@@ -94,14 +104,15 @@ def evaluate_model(sess, model: Model, testRatings: Dict[str, List[int]], testNe
     ids = ids.cpu().numpy()
     flags = flags.cpu().numpy()
 
-    hits: List[int] = []
-    ndcgs: List[float] = []
-    for r, u in enumerate(users):
-        if flags[r] & 1:
-            hr, ndcg = eval_one_rating(model, u, testRatings, testNegatives, K, dish_to_category)
-        else:
-            ranklist = [int(x) for x in ids[r] if x >= 0]
-            hr, ndcg = getHitRatio(ranklist, cand[r][0]), getNDCG(ranklist, cand[r][0])
-        hits.append(hr)
-        ndcgs.append(ndcg)
+    # getHitRatio / getNDCG (evaluate.py:69-81) for all users: 0-based rank of the held-out dish in its list.
+    # The list holds each dish once (dict collapse) and padding is -1, so the first match is the only one.
+    gt = items_np[:, 0]
+    match = ids == gt[:, None]
+    hit = match.any(axis=1)
+    rank = match.argmax(axis=1)
+    gain = [math.log(2) / math.log(r + 2) for r in range(ids.shape[1])]     # the reference's own expression
+    hits: List[int] = hit.astype(np.int64).tolist()
+    ndcgs: List[float] = [gain[r] if h else 0 for r, h in zip(rank.tolist(), hits)]
+    for r in np.flatnonzero(flags & 1).tolist():            # NaN among the scores: the reference's host sequence
+        hits[r], ndcgs[r] = eval_one_rating(model, users[r], testRatings, testNegatives, K, dish_to_category)
     return hits, ndcgs

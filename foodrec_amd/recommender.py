@@ -126,15 +126,7 @@ class Model:
     # -- predict ------------------------------------------------------------------------------------
     def predict_device(self, user_input, item_input, categories) -> torch.Tensor:
         """Scores as a device tensor, no synchronisation (stream-ordered)."""
-        u, d = _ids(user_input, "user"), _ids(item_input, "item")
-        B = len(u)
-        if len(d) != B:
-            raise ValueError("user_input and item_input differ in length")
-        m = _mask(categories, self.num_categories, B)
-        dev = self.device
-        ut = u.to(dev, torch.int32) if isinstance(u, torch.Tensor) else torch.from_numpy(u).to(dev)
-        dt = d.to(dev, torch.int32) if isinstance(d, torch.Tensor) else torch.from_numpy(d).to(dev)
-        mt = m.to(dev) if isinstance(m, torch.Tensor) else torch.from_numpy(m).to(dev)
+        ut, dt, mt = self._feeds(user_input, item_input, categories)
         return torch.ops.m2d.score_pairs(self.engine.id, ut, dt, mt)
 
     def predict(self, user_input, item_input, categories, **ignored) -> np.ndarray:
