@@ -159,7 +159,8 @@ int m2d_score_pairs_ingredients(m2d_engine *h, const int32_t *users, const int32
  * (sum_k z[k] is the reference score, Model_Recommender.py:67-96 in factored form):
  *     score = sum_k z[k] + w3 . relu(W2^T relu(W1^T z + b1) + b2) + b3
  * W1 f32[K, H1], b1 f32[H1], W2 f32[H1, H2], b2 f32[H2], w3 f32[H2].  H1 = 256, H2 = 64 with K % 64 == 0
- * run on the exact-f32 MFMA kernel; other sizes run a generic kernel.  Dish masks must be resident
+ * run on the MFMA kernel (split-bf16 layers 1-2 by default, exact f32 with option "mlp_bf16x3" = 0); other
+ * sizes run a generic kernel.  Dish masks must be resident
  * (m2d_set_dish_categories); the ingredient table, when set, feeds Dt's high-level part. */
 int m2d_set_mlp_head(m2d_engine *h, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *w3, float b3, int32_t H1, int32_t H2, int table_flags);
@@ -174,9 +175,10 @@ int m2d_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_t *item
 int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_index);
 
 /* Kernel-selection knobs for benchmarking ("prefetch", "nt_loads", "blocks_per_cu", "variant"): results
- * never depend on them.  One numerical switch: "topk_bf16x3" (default 1) lets m2d_topk_users contract on
- * split-bf16 MFMA (x = hi + lo, three bf16 products, fp32 accumulation; score error ~1e-5 relative, inside
- * the 1e-4 bar) where the mask table is 0/1 and E is 64 or 128; 0 forces the exact-f32 MFMA kernels.
+ * never depend on them.  Two numerical switches, both for build-defined paths: "topk_bf16x3" (default 1) lets
+ * m2d_topk_users contract on split-bf16 MFMA (x = hi + lo, three bf16 products, fp32 accumulation; score error
+ * ~1e-5 relative, inside the 1e-4 bar) where the mask table is 0/1 and E is 64 or 128; "mlp_bf16x3" (default 1)
+ * does the same for layers 1-2 of m2d_score_pairs_mlp; 0 forces the exact-f32 MFMA kernels.
  * m2d_score_pairs* (the reference path) is always exact float32.  Unknown names: M2D_ERR_INVALID_ARG. */
 int m2d_set_option(m2d_engine *h, const char *name, int64_t value);
 int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value);
