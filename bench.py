@@ -95,6 +95,26 @@ def time_steps(torch, eng, users, items, cats, out, steps, step=None):
     return wall, per
 
 
+def usable_cores():
+    """Host cores this process may actually run on: the affinity mask capped by the cgroup CPU quota.  (A GPU box
+    hands one GPU's job a share of a 256-thread host; 256 threads on that share run slower than 16.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            if parse:
+                quota, period = parse(open(path).read())
+            else:
+                quota = open(path).read().strip()
+                period = open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, -(-int(quota) // int(period))))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(torch, PM, RE, CE, users, items, cats, budget_s):
     """CPU restatement of the reference graph (oracle/torch_graph.py) on this box's host cores.
 
@@ -102,7 +122,7 @@ def cpu_baseline(torch, PM, RE, CE, users, items, cats, budget_s):
     (evaluate.py:39-58), 4096 and 65536 -- and reports the fastest as `value`, so the baseline is
     the most favourable batching of the op-for-op graph, not a strawman."""
     from oracle import c_oracle, torch_graph
-    ncores = os.cpu_count() or 1
+    ncores = usable_cores()
     torch.set_num_threads(ncores)
     Bc = min(1 << 18, users.numel())
     pm, re, ce = PM.cpu(), RE.cpu(), CE.cpu()
@@ -120,10 +140,11 @@ def cpu_baseline(torch, PM, RE, CE, users, items, cats, budget_s):
     # context: the fused scalar C port of the same formula (no temporaries), all OpenMP threads
     pmn, ren, cen = pm.numpy(), re.numpy(), ce.numpy()
     un, dn, mn = u.numpy(), d.numpy(), m.numpy()
-    c_oracle.score_pairs(pmn, ren, cen, un[:4096], dn[:4096], mn[:4096])
+    cthreads = min(ncores, c_oracle.max_threads())
+    c_oracle.score_pairs(pmn, ren, cen, un[:4096], dn[:4096], mn[:4096], nthreads=cthreads)
     reps, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < budget_s * 0.2:
-        c_oracle.score_pairs(pmn, ren, cen, un, dn, mn)
+        c_oracle.score_pairs(pmn, ren, cen, un, dn, mn, nthreads=cthreads)
         reps += 1
     c_rate = reps * Bc / (time.perf_counter() - t0)
     return {"value": rates[best], "unit": "pairs/s", "cores": int(torch.get_num_threads()), "kind": "port",
@@ -132,7 +153,8 @@ def cpu_baseline(torch, PM, RE, CE, users, items, cats, budget_s):
                       "51 / 4096 / 65536 pairs per call = %.3g / %.3g / %.3g (value = best, %d per call)"
                       % (Bc, budget_s * 0.22, rates[51], rates[4096], rates[65536], best),
             "value_51_pair_calls": rates[51],
-            "fused_c_port": {"value": c_rate, "unit": "pairs/s", "cores": c_oracle.max_threads(),
+            "host_cpu_count": os.cpu_count(),
+            "fused_c_port": {"value": c_rate, "unit": "pairs/s", "cores": cthreads,
                              "what": "oracle/m2d_oracle.c, fused scalar loop, OpenMP"}}, ref, Bc
 
 
