@@ -200,8 +200,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
             const int r = ps / S, sl = ps - r * S;
             const int q = sl ^ (r & (G - 1));          // logical slot that must land here
             const float *src = p.dt + ((size_t)(tile * 32 + r) * KP + (size_t)c * (KC8 * 8) + q * 4);
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)src,
-                                             (void __attribute__((address_space(3))) *)(dst + pc * 256), 16, 0, 0);
+            lds_dma16(src, dst + pc * 256);
         }
     };
 
@@ -210,7 +209,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
     v16f acc;
 
     if (nstages > 0) issue_stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_all_vmem();
     __syncthreads();
 
 #if M2D_DIAG & 16
@@ -313,7 +312,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
         STAMP(t1_); t_epi += t1_ - t0_; if (was_slow) { t_slow += t1_ - t0_; ++n_slow; } t0_ = t1_;
 #endif
         if (!(M2D_DIAG & 4)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_all_vmem();
             __syncthreads();
         }
 #if M2D_DIAG & 16
@@ -699,13 +698,12 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
             const int ps = pc * 64 + lane;
             const int r = ps / S, sl = ps - r * S;
             const int q = sl ^ (r & (SW - 1));
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src0 + (size_t)r * E + q * 4),
-                                             (void __attribute__((address_space(3))) *)(dst + pc * 256), 16, 0, 0);
+            lds_dma16(src0 + (size_t)r * E + q * 4, dst + pc * 256);
         }
     };
 
     if (nstages > 0) issue_stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_all_vmem();
     __syncthreads();
 
     v16f acc;
@@ -774,7 +772,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_all_vmem();
         __syncthreads();
     }
 
@@ -899,13 +897,12 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
             const int g = pc * 64 + lane;                  // physical 16-B slot in the stage image
             const int rw = g / S8, sl = g - rw * S8;       // stage row (hi and lo rows alike), slot in row
             const int q = sl ^ ((rw / RPB) & (S8 - 1));    // logical slot that must land here
-            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src0 + (size_t)rw * ROW_BYTES + q * 16),
-                                             (void __attribute__((address_space(3))) *)(dst + pc * 1024), 16, 0, 0);
+            lds_dma16(src0 + (size_t)rw * ROW_BYTES + q * 16, dst + pc * 1024);
         }
     };
 
     if (nstages > 0) issue_stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_all_vmem();
     __syncthreads();
 
     const int key = (j / RPB) & (S8 - 1);                  // this lane's row swizzle (same for hi and lo rows)
@@ -1008,7 +1005,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
             STAMP(t1_); t_slow += t1_ - t0_; ++n_slow; t0_ = t1_;
 #endif
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_all_vmem();
         __syncthreads();
 #if M2D_DIAG & 16
         STAMP(t1_); t_bar += t1_ - t0_; t0_ = t1_;

@@ -74,27 +74,6 @@ constexpr int RING_FLOATS = 64 * MH1;   // one stage: 64 k-rows of W1 (= all of 
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// vmcnt(0) twice over: the builtin is an s_waitcnt the compiler's own counter model sees (so it stops assuming that
-// loads from a previous loop trip are still in flight), the asm one cannot be optimised away on the grounds that
-// the compiler knows of nothing outstanding (the DMA ops below are hidden from it).
-__device__ __forceinline__ void wait_all_vmem()
-{
-    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0), expcnt / lgkmcnt untouched
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// LDS-DMA of 64 x 16 B: lane l's 16 bytes at `src` land at lds_base + 16 l.  Written as asm on purpose: after the
-// builtin the compiler puts s_waitcnt vmcnt(0) in front of the next ds_read (it must assume the read aliases the
-// DMA'd bytes), which serialises the NEXT stage's fill with the CURRENT stage's multiply.  Here a stage is
-// published by an explicit vmcnt(0) + barrier before anyone reads it, so that wait is never needed.  The hidden
-// VMEM op only makes the compiler's own vmcnt(N) waits more conservative (returns are in order), never less.
-__device__ __forceinline__ void lds_dma16(const void *src, const void *lds_base_uniform)
-{
-    const uint32_t m0v = __builtin_amdgcn_readfirstlane(
-        (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)lds_base_uniform);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
-}
-
 // hidden unit held by accumulator tile nt, register r, lane half h (see the two layer-1 forms below)
 template <bool X3>
 __device__ __forceinline__ int hidden_unit(int nt, int r, int h)
