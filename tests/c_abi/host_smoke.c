@@ -91,6 +91,35 @@ int main(void)
         const int rc = m2d_check(h, st, &bv, &bi);
         printf("bad id -> rc %d value %lld index %lld (%s)\n", rc, (long long)bv, (long long)bi, m2d_last_error(h));
         if (rc != M2D_ERR_BAD_USER_ID || bv != U || bi != 17) { printf("FAIL error path\n"); return 1; }
+        /* --- a training step from plain C (SGD, lr 0.5): loss = mean sigmoid-CE of the scores checked above
+         * (Model_Recommender.py:99-104), and one step along the clipped negative gradient lowers it --- */
+        HCHECK(hipMemcpy(du + 17, &us[17], 4, hipMemcpyHostToDevice));
+        float *y = malloc(4 * B), *dy, *dres, res[4];
+        double loss = 0;
+        for (int i = 0; i < B; ++i) {
+            y[i] = (float)(i & 1);
+            const double sc = ref_score(pm, re, ce, C, E, us[i], ds[i], m + i * C);
+            loss += (sc > 0 ? sc : 0) - sc * y[i] + log1p(exp(-fabs(sc)));
+        }
+        loss /= B;
+        HCHECK(hipMalloc((void **)&dy, 4 * B)); HCHECK(hipMalloc((void **)&dres, 16));
+        HCHECK(hipMemcpy(dy, y, 4 * B, hipMemcpyHostToDevice));
+        CHECK(m2d_train_begin(h, M2D_LEARNER_SGD, 0.5f, 5.0f, st));
+        CHECK(m2d_train_step(h, du, dd, dm, dy, B, 1, dres, st));
+        CHECK(m2d_check(h, st, NULL, NULL));
+        HCHECK(hipMemcpy(res, dres, 16, hipMemcpyDeviceToHost));
+        printf("train step: loss %.6f (host %.6f), gradient norm %.4g, clip scale %.3g, lr %.3g\n", res[0], loss, res[1], res[2], res[3]);
+        if (fabs(res[0] - loss) > 1e-5 || res[2] != 1.0f || res[3] != 0.5f) { printf("FAIL train loss\n"); return 1; }
+        /* the engine owns its copy of host tables; m2d_train_slot has nothing to copy for SGD */
+        if (m2d_train_slot(h, 2, 0, dres, 0, st) != M2D_ERR_INVALID_ARG) { printf("FAIL sgd slot\n"); return 1; }
+        /* apply = 0: the loss_value fetch alone, on the updated tables */
+        CHECK(m2d_train_step(h, du, dd, dm, dy, B, 0, dres, st));
+        CHECK(m2d_check(h, st, NULL, NULL));
+        float res2[4];
+        HCHECK(hipMemcpy(res2, dres, 16, hipMemcpyDeviceToHost));
+        printf("loss after the step: %.6f\n", res2[0]);
+        if (!(res2[0] < res[0])) { printf("FAIL loss did not decrease\n"); return 1; }
+        CHECK(m2d_train_end(h));
         CHECK(m2d_destroy(h));
     }
     printf("C ABI OK (version %d)\n", m2d_abi_version());
