@@ -321,6 +321,31 @@ def side_measurements(torch, eng, PM, U, I, C, E, dev, user_base):
     return nr, probe
 
 
+def ingredients_leg(torch, eng, users, items, cats, out, I, C, E, dev, R):
+    """Outside the timed region: the same batch with BASELINE configs[1]'s 10k-row ingredient table on the high-level
+    path (build-defined extension; --workload ingredients makes it the timed step)."""
+    g = torch.Generator(device=dev); g.manual_seed(20260101 + 3)
+    lens = torch.randint(1, 21, (I,), generator=g, device=dev)
+    off = torch.zeros(I + 1, dtype=torch.int32, device=dev)
+    off[1:] = torch.cumsum(lens, 0).to(torch.int32)
+    eng.set_ingredients(torch.randn((R, E), generator=g, device=dev) * E ** -0.5, off,
+                        torch.randint(0, R, (int(off[-1].item()),), generator=g, device=dev, dtype=torch.int32))
+    step = lambda: eng.score_pairs_ingredients(users, items, cats, out=out)
+    time_steps(torch, eng, users, items, cats, out, 3, step)
+    _, per = time_steps(torch, eng, users, items, cats, out, 10, step)
+    eng.check()
+    kern = eng.last_kernel()
+    eng.clear_ingredients()
+    ms = median(per)
+    B = users.numel()
+    bpp = (C + 3) * E * 4 + C * 4 + 12
+    return {"ingredient_rows": R, "ingredients_per_dish": "uniform 1..20", "kernel": kern, "kernel_median_ms": ms,
+            "pairs_per_s": B / ms * 1e3, "algorithmic_bytes_per_pair": bpp, "achieved": bpp * B / ms / 1e6, "unit": "GB/s",
+            "frac": bpp * B / ms / 1e6 / HBM_PEAK_GBS,
+            "what": "same pairs, high-level path from the per-dish multi-hot ingredient sum H[d] (segment-sum hoisted to a "
+                    "per-table kernel, DESIGN.md 8.1); no reference counterpart"}
+
+
 def train_workload(a, torch, foodrec_amd, dev):
     """Single-GPU training-step throughput.  Default shape = the reference's flags
     (Train_recommender.py:35, :51-58): 64 657 users, 4 548 dishes, E = 200, batch 128."""
@@ -578,6 +603,11 @@ def main():
                 line["evaluator"] = evaluator_leg(torch, dev)
             except Exception as e:                                     # noqa: BLE001
                 line["evaluator"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if not a.no_side and wl == "pairs":
+            try:
+                line["with_ingredient_table"] = ingredients_leg(torch, eng, users, items, cats, out, I, C, E, dev, a.ingredients)
+            except Exception as e:                                     # noqa: BLE001
+                line["with_ingredient_table"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if topk_ag is not None:
             line["sharded_topk_allgather"] = topk_ag
         if a.unique_users:
