@@ -41,6 +41,7 @@ SIGNATURES = {
     "m2d_set_user_base": (_c.c_int, [_vp, _i64]),
     "m2d_set_dish_categories": (_c.c_int, [_vp, _vp, _c.c_int]),
     "m2d_score_pairs": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "m2d_score_pairs_host": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "m2d_score_pairs_bydish": (_c.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "m2d_rank_candidates": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "m2d_topk_users": (_c.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),

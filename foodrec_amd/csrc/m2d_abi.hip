@@ -61,6 +61,8 @@ int adopt_table(m2d_engine *h, const float *src, size_t count, int flags, const 
 
 void release(m2d_engine *h)
 {
+    if (h->stage_host) (void)hipHostFree(h->stage_host);
+    if (h->stage_dev) (void)hipFree(h->stage_dev);
     m2d_train_release(h);
     if (h->own_pm && h->pm) (void)hipFree((void *)h->pm);
     if (h->own_re && h->re) (void)hipFree((void *)h->re);
@@ -194,6 +196,51 @@ int m2d_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *items, c
     if (h->C == 4 && !aligned16(cats)) return fail(h, M2D_ERR_INVALID_ARG, "m2d_score_pairs: cats must be 16-byte aligned");
     M2D_HIP_TRY(h, hipSetDevice(h->device));
     return m2d_launch_score_pairs(h, users, items, cats, false, B, out, (hipStream_t)stream);
+}
+
+// Host-buffer form of m2d_score_pairs: what the reference's own call site hands over (numpy / lists, 51 pairs per
+// sess.run, evaluate.py:55-59).  One pinned staging block [users | items | cats | out | err], one H2D copy, the
+// kernel, one D2H copy that brings the scores AND the id-error latch back, one synchronisation.
+int m2d_score_pairs_host(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats, int64_t B,
+                         float *out, void *stream)
+{
+    if (!h) return M2D_ERR_INVALID_ARG;
+    if (B < 0) return fail(h, M2D_ERR_INVALID_ARG, "m2d_score_pairs_host: negative batch");
+    if (B == 0) return M2D_OK;
+    if (!users || !items || !cats || !out) return fail(h, M2D_ERR_INVALID_ARG, "m2d_score_pairs_host: null buffer");
+    hipStream_t st = (hipStream_t)stream;
+    M2D_HIP_TRY(h, hipSetDevice(h->device));
+    const int C = h->C;
+    // layout (16-byte aligned sections): cats [B, C] | users [B] | items [B] || out [B] | err [4]
+    const size_t nb = ((size_t)B + 3) & ~(size_t)3;
+    const size_t in_bytes = nb * C * 4 + 2 * nb * 4, out_bytes = nb * 4 + 16, total = in_bytes + out_bytes;
+    if (total > h->stage_bytes) {
+        M2D_HIP_TRY(h, hipStreamSynchronize(st));
+        if (h->stage_host) (void)hipHostFree(h->stage_host);
+        if (h->stage_dev) (void)hipFree(h->stage_dev);
+        h->stage_host = h->stage_dev = nullptr; h->stage_bytes = 0;
+        const size_t cap = total * 2;
+        M2D_HIP_TRY(h, hipHostMalloc((void **)&h->stage_host, cap, hipHostMallocDefault));
+        M2D_HIP_TRY(h, hipMalloc((void **)&h->stage_dev, cap));
+        h->stage_bytes = cap;
+    }
+    unsigned char *hs = h->stage_host, *ds = h->stage_dev;
+    memcpy(hs, cats, (size_t)B * C * 4);
+    memcpy(hs + nb * C * 4, users, (size_t)B * 4);
+    memcpy(hs + nb * C * 4 + nb * 4, items, (size_t)B * 4);
+    M2D_HIP_TRY(h, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, st));
+    const int rc = m2d_launch_score_pairs(h, reinterpret_cast<const int32_t *>(ds + nb * C * 4),
+                                          reinterpret_cast<const int32_t *>(ds + nb * C * 4 + nb * 4),
+                                          reinterpret_cast<const float *>(ds), false, B, reinterpret_cast<float *>(ds + in_bytes), st);
+    if (rc != M2D_OK) return rc;
+    // the latch rides back behind the scores: copy it next to them on the device first (16 B, same stream)
+    M2D_HIP_TRY(h, hipMemcpyAsync(ds + in_bytes + nb * 4, h->err_dev, 16, hipMemcpyDeviceToDevice, st));
+    M2D_HIP_TRY(h, hipMemcpyAsync(hs + in_bytes, ds + in_bytes, out_bytes, hipMemcpyDeviceToHost, st));
+    M2D_HIP_TRY(h, hipStreamSynchronize(st));
+    const int32_t *err = reinterpret_cast<const int32_t *>(hs + in_bytes + nb * 4);
+    if (err[0] != 0) return m2d_check(h, stream, nullptr, nullptr);     // formats the message, clears the latch
+    memcpy(out, hs + in_bytes, (size_t)B * 4);
+    return M2D_OK;
 }
 
 int m2d_score_pairs_bydish(m2d_engine *h, const int32_t *users, const int32_t *items, int64_t B, float *out,

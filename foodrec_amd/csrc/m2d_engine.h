@@ -62,6 +62,10 @@ struct m2d_engine {
     // training step: optimizer slots and gradient scratch, created by m2d_train_begin
     m2d_train_state *train = nullptr;
 
+    // staging for m2d_score_pairs_host: one pinned block and its device twin
+    unsigned char *stage_host = nullptr, *stage_dev = nullptr;
+    size_t stage_bytes = 0;
+
     // scratch for rank_candidates
     float *scratch = nullptr;
     size_t scratch_bytes = 0;

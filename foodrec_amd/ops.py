@@ -261,6 +261,22 @@ class ScoringEngine:
         _native.raise_for(rc, self._h)
         return out
 
+    def score_pairs_host(self, users: np.ndarray, items: np.ndarray, cats: np.ndarray) -> np.ndarray:
+        """Host arrays in, host array out (int32 [B], int32 [B], float32 [B, C] -> float32 [B]): the latency path for
+        reference-shaped calls of a few dozen pairs.  Synchronous; raises IndexError for an out-of-range id."""
+        users = np.ascontiguousarray(users, dtype=np.int32)
+        items = np.ascontiguousarray(items, dtype=np.int32)
+        cats = np.ascontiguousarray(cats, dtype=np.float32)
+        B = users.shape[0]
+        if items.shape != (B,) or cats.shape != (B, self.C):
+            raise ValueError("users [B], items [B], cats [B, %d] expected" % self.C)
+        out = np.empty(B, dtype=np.float32)
+        with torch.cuda.device(self.device):
+            rc = _native.lib().m2d_score_pairs_host(self._h, users.ctypes.data, items.ctypes.data, cats.ctypes.data, B,
+                                                    out.ctypes.data, _stream_ptr())
+        _native.raise_for(rc, self._h)
+        return out
+
     def score_pairs_bydish(self, users: torch.Tensor, items: torch.Tensor,
                            out: Optional[torch.Tensor] = None) -> torch.Tensor:
         self._check_ids(users, items)

@@ -135,9 +135,15 @@ class Model:
         Extra reference feeds (``labels``, ``dropout_keep_prob``, ``is_training_flag`` ...) are accepted
         and ignored: no op in the reference's forward reads them.  An out-of-range id raises
         ``IndexError`` (TF-CPU ``GatherV2`` raises ``InvalidArgumentError``)."""
-        out = self.predict_device(user_input, item_input, categories)
-        self.engine.check()
-        return out.cpu().numpy()
+        if any(isinstance(x, torch.Tensor) for x in (user_input, item_input, categories)):
+            out = self.predict_device(user_input, item_input, categories)      # torch custom op, stream-ordered
+            self.engine.check()
+            return out.cpu().numpy()
+        # host data (the reference's own feeds): one staged copy in, one out (m2d_score_pairs_host)
+        u, d = _ids(user_input, "user"), _ids(item_input, "item")
+        if len(d) != len(u):
+            raise ValueError("user_input and item_input differ in length")
+        return self.engine.score_pairs_host(u, d, _mask(categories, self.num_categories, len(u)))
 
     # -- training side (SURVEY.md 8f rows N2, N4) -----------------------------------------------------
     def _feeds(self, user_input, item_input, categories):

@@ -71,6 +71,14 @@ int m2d_set_dish_categories(m2d_engine *h, const float *cats, int table_flags);
 int m2d_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
                     int64_t B, float *out, void *stream);
 
+/* m2d_score_pairs for HOST buffers -- what the reference's call site actually hands over (lists / numpy, 51 pairs
+ * per call, evaluate.py:39-59).  users, items, cats and out are host pointers; the call stages them through one
+ * pinned block (one copy in, one copy out), SYNCHRONISES `stream` and returns the scores in `out`.  An out-of-range
+ * id is returned directly as M2D_ERR_BAD_USER_ID / M2D_ERR_BAD_ITEM_ID (text in m2d_last_error), `out` untouched.
+ * This is the latency path; its rate includes PCIe and is never what bench.py reports as `value`. */
+int m2d_score_pairs_host(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
+                         int64_t B, float *out, void *stream);
+
 /* Same, with cats looked up from the resident dish table: cats[b] = dish_categories[items[b]]. */
 int m2d_score_pairs_bydish(m2d_engine *h, const int32_t *users, const int32_t *items, int64_t B,
                            float *out, void *stream);

@@ -214,3 +214,23 @@ def test_full_size_properties(torch_cuda):
     eng2 = ScoringEngine(PM * 2, RE, CE)
     out2 = eng2.score_pairs(users, items, cats); eng2.check()
     assert torch.equal(out2, out * 2)
+
+
+@pytest.mark.parametrize("B", [1, 51, 5000])
+def test_host_buffer_call_equals_the_device_op(torch_cuda, B):
+    """m2d_score_pairs_host (what Model.predict uses for host feeds) against the torch custom op: same kernel, same bits."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    PM, RE, CE, users, items, cats = random_case(400, 300, 4, 64, B, seed=B)
+    eng = ScoringEngine(PM, RE, CE)
+    dev = lambda a: torch.as_tensor(a, device="cuda")
+    ref = eng.score_pairs(dev(users), dev(items), dev(cats)).cpu().numpy(); eng.check()
+    got = eng.score_pairs_host(users, items, cats)
+    assert np.array_equal(got, ref, equal_nan=True)
+    assert eng.score_pairs_host(users[:0], items[:0], cats[:0]).shape == (0,)
+    bad = items.copy(); bad[B // 2] = 300
+    with pytest.raises(IndexError, match="item id 300 at position %d" % (B // 2)):
+        eng.score_pairs_host(users, bad, cats)
+    assert np.array_equal(eng.score_pairs_host(users, items, cats), ref, equal_nan=True)      # latch cleared, engine usable
+    with pytest.raises(ValueError):
+        eng.score_pairs_host(users, items[:-1] if B > 1 else np.zeros(2, np.int32), cats)
