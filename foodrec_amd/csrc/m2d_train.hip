@@ -227,7 +227,6 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 template <int VEC> struct RowVec;
 template <> struct RowVec<1> { typedef float T; };
 template <> struct RowVec<4> { typedef v4f T; };
-__device__ __forceinline__ float &lane_of(float &v, int) { return v; }
 __device__ __forceinline__ float lane_get(const v4f &v, int j) { return v[j]; }
 __device__ __forceinline__ float lane_get(const float &v, int) { return v; }
 __device__ __forceinline__ void lane_set(v4f &v, int j, float x) { v[j] = x; }
