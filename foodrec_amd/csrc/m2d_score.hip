@@ -197,6 +197,90 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
     }
 }
 
+// Latency form of the kernel above for small batches (serving calls, the reference's own 51 pairs per sess.run):
+// a group of LPP lanes takes ONE pair per pass instead of walking LPP pairs one after another, so a batch of B
+// pairs is spread over B * LPP / 64 waves and finishes in about one row-gather latency instead of up to 64 of
+// them in sequence.  Same per-lane arithmetic and the same group reduction: bit-identical scores.
+template <int LPP, bool BYDISH, bool FULL, bool HV>
+__global__ __launch_bounds__(256) void m2d_score_pairs_c4_small(ScoreArgs p)
+{
+    constexpr int C = 4, GPW = 64 / LPP;                    // pairs per wave per pass
+    const int lane = threadIdx.x & 63;
+    const int j = lane & (LPP - 1);
+    const int E4 = FULL ? LPP : (p.E >> 2);
+    const bool col_ok = FULL || (j < E4);
+    const int jc = col_ok ? j : 0;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const v4f *pm4 = reinterpret_cast<const v4f *>(p.pm);
+    const v4f *re4 = reinterpret_cast<const v4f *>(p.re);
+    const v4f *ce4 = reinterpret_cast<const v4f *>(p.ce);
+    const v4f *hv4 = reinterpret_cast<const v4f *>(p.hv);
+    const size_t urow4 = (size_t)(C + 1) * E4;
+    v4f cef[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        cef[c] = ce4[(size_t)c * E4 + jc];
+        if (!col_ok) cef[c] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int64_t base = wave0 * GPW; base < p.B; base += nwaves * GPW) {
+        const int64_t pi = base + lane / LPP;
+        const bool valid = pi < p.B;
+        int32_t uid = valid ? p.users[pi] : (int32_t)p.user_base;
+        int32_t did = valid ? p.items[pi] : 0;
+        int64_t ul = (int64_t)uid - p.user_base;
+        bool bad = false;
+        if (ul < 0 || ul >= p.U) {
+            if (j == 0) latch_error(p.err, M2D_ERR_BAD_USER_ID, uid, pi);
+            ul = 0;
+            bad = true;
+        }
+        if (did < 0 || (int64_t)did >= p.I) {
+            if (j == 0) latch_error(p.err, M2D_ERR_BAD_ITEM_ID, did, pi);
+            did = 0;
+            bad = true;
+        }
+        v4f m = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            const v4f *cp = reinterpret_cast<const v4f *>(p.cats);
+            m = BYDISH ? cp[did] : cp[pi];
+        }
+        const v4f *pu = pm4 + (size_t)ul * urow4 + jc;
+        v4f ub[C + 1];
+#pragma unroll
+        for (int r = 0; r <= C; ++r) ub[r] = pu[(size_t)r * E4];
+        const v4f ib = re4[(size_t)did * E4 + jc];
+        v4f hb = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (HV) hb = hv4[(size_t)did * E4 + jc];
+        const float mc[C] = {m.x, m.y, m.z, m.w};
+        float hs = 0.f, ls = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if constexpr (!HV) {
+                const v4f dish_category = scale4(mc[c], cef[c]);    // :67
+                hs = dot4(ub[0], dish_category, hs);                   // :71, :75
+            }
+            const v4f dish_memory = scale4(mc[c], ub[c + 1]);       // :82
+            ls = dot4(ib, dish_memory, ls);                            // :86, :90
+        }
+        if constexpr (HV) hs = dot4(ub[0], hb, hs);
+        if (!FULL && !col_ok) {
+            ls = 0.f;
+            if (HV) hs = 0.f;
+        }
+        hs = group_sum<LPP>(hs);
+        ls = group_sum<LPP>(ls);
+        if (valid && j == 0) {
+            const float n = (m.x + m.y) + (m.z + m.w);                         // :77
+            const float high = HV ? hs : hs / n;                               // :79
+            const float low = ls / n;                                          // :92
+            float score = __fadd_rn(__fmul_rn(p.a, high), __fmul_rn(p.b, low));     // :95-96
+            if (bad) score = __builtin_nanf("");
+            p.out[pi] = score;
+        }
+    }
+}
+
 // Any C (<= 64), any E: one wave per pair, lanes stride over e.  Slow path for shapes the
 // vectorised kernel does not cover (E % 4 != 0, E > 256, C != 4).
 template <bool BYDISH>
@@ -246,12 +330,18 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_generic(ScoreArgs p)
 }
 
 template <int LPP, bool FULL, bool BYDISH>
-void launch_c4(const ScoreArgs &a, int pf, bool nt, dim3 grid, hipStream_t st, const char **name)
+void launch_c4(const ScoreArgs &a, int pf, bool nt, bool small, dim3 grid, hipStream_t st, const char **name)
 {
 #define M2D_CASE(PFV, NTV)                                                                           \
     if (pf == PFV && nt == NTV) {                                                                    \
         hipLaunchKernelGGL((m2d_score_pairs_c4<LPP, PFV, BYDISH, NTV, FULL, false>), grid, dim3(256), 0, st, a); \
         return;                                                                                      \
+    }
+    if (small) {  // latency form: one pair per group per pass
+        *name = a.hv ? "m2d_score_pairs_c4_small_hv" : "m2d_score_pairs_c4_small";
+        if (a.hv) hipLaunchKernelGGL((m2d_score_pairs_c4_small<LPP, BYDISH, FULL, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((m2d_score_pairs_c4_small<LPP, BYDISH, FULL, false>), grid, dim3(256), 0, st, a);
+        return;
     }
     if (a.hv) {   // extension kernel: one configuration (PF 2, non-temporal user rows)
         *name = "m2d_score_pairs_c4_hv";
@@ -275,20 +365,23 @@ int launch_any(m2d_engine *h, const ScoreArgs &a, hipStream_t st)
     const bool vec_ok = (a.C == 4) && (a.E % 4 == 0) && E4 <= 64 && h->opt_variant != 9;
     int64_t blocks;
     const int64_t cap = (int64_t)h->num_cu * (h->opt_blocks_per_cu > 0 ? h->opt_blocks_per_cu : 8);
+    // up to 8192 pairs: the latency form (option "variant" = 11 forces the throughput form, 12 the latency form)
+    const bool small = vec_ok && ((a.B <= 8192 && h->opt_variant != 11) || h->opt_variant == 12);
     if (vec_ok) {
-        blocks = (nchunks + 3) / 4;
+        const int lpp = E4 <= 8 ? 8 : E4 <= 16 ? 16 : E4 <= 32 ? 32 : 64;
+        blocks = small ? (a.B * lpp / 64 + 3) / 4 + 1 : (nchunks + 3) / 4;
         if (blocks > cap) blocks = cap;
         if (blocks < 1) blocks = 1;
         dim3 grid((unsigned)blocks);
         const char **nm = &h->last_kernel;
-        if (E4 == 8) launch_c4<8, true, BYDISH>(a, pf, nt, grid, st, nm);
-        else if (E4 == 16) launch_c4<16, true, BYDISH>(a, pf, nt, grid, st, nm);
-        else if (E4 == 32) launch_c4<32, true, BYDISH>(a, pf, nt, grid, st, nm);
-        else if (E4 == 64) launch_c4<64, true, BYDISH>(a, pf, nt, grid, st, nm);
-        else if (E4 < 8) launch_c4<8, false, BYDISH>(a, pf, nt, grid, st, nm);
-        else if (E4 < 16) launch_c4<16, false, BYDISH>(a, pf, nt, grid, st, nm);
-        else if (E4 < 32) launch_c4<32, false, BYDISH>(a, pf, nt, grid, st, nm);
-        else launch_c4<64, false, BYDISH>(a, pf, nt, grid, st, nm);
+        if (E4 == 8) launch_c4<8, true, BYDISH>(a, pf, nt, small, grid, st, nm);
+        else if (E4 == 16) launch_c4<16, true, BYDISH>(a, pf, nt, small, grid, st, nm);
+        else if (E4 == 32) launch_c4<32, true, BYDISH>(a, pf, nt, small, grid, st, nm);
+        else if (E4 == 64) launch_c4<64, true, BYDISH>(a, pf, nt, small, grid, st, nm);
+        else if (E4 < 8) launch_c4<8, false, BYDISH>(a, pf, nt, small, grid, st, nm);
+        else if (E4 < 16) launch_c4<16, false, BYDISH>(a, pf, nt, small, grid, st, nm);
+        else if (E4 < 32) launch_c4<32, false, BYDISH>(a, pf, nt, small, grid, st, nm);
+        else launch_c4<64, false, BYDISH>(a, pf, nt, small, grid, st, nm);
     } else {
         if (a.C > 64) {
             h->last_error = "num_categories > 64 is not supported";

@@ -74,10 +74,21 @@ def test_seeded_shapes(torch_cuda, shape, B):
 def test_kernel_variants_agree(torch_cuda):
     from oracle import m2d_oracle as oracle
     for E in (32, 64, 128, 200):
-        PM, RE, CE, users, items, cats = random_case(500, 300, 4, E, 5000, seed=E)
+        PM, RE, CE, users, items, cats = random_case(500, 300, 4, E, 20000, seed=E)     # > 8192: the throughput form
         ref = oracle.inference_f64(PM, RE, CE, users, items, cats)
         eng = _engine(PM, RE, CE)
         outs = []
+        eng.set_option("variant", 12)                      # the latency form (default up to 8192 pairs), forced
+        outs.append(_run(eng, torch_cuda, users, items, cats))
+        assert eng.last_kernel() == "m2d_score_pairs_c4_small"
+        assert_scores_close(outs[0], ref, what="latency form E%d" % E)
+        eng.set_option("variant", 0)
+        assert np.array_equal(_run(eng, torch_cuda, users[:100], items[:100], cats[:100]), outs[0][:100], equal_nan=True)
+        assert eng.last_kernel() == "m2d_score_pairs_c4_small"
+        eng.set_option("variant", 11)                      # small batch through the throughput form
+        assert np.array_equal(_run(eng, torch_cuda, users[:100], items[:100], cats[:100]), outs[0][:100], equal_nan=True)
+        assert eng.last_kernel() == "m2d_score_pairs_c4"
+        eng.set_option("variant", 0)
         for pf in (1, 2, 4):
             for nt in (0, 1):
                 for bpc in (1, 8):
