@@ -227,7 +227,7 @@ def test_full_size_properties(torch_cuda):
     assert torch.equal(out2, out * 2)
 
 
-@pytest.mark.parametrize("B", [1, 51, 5000])
+@pytest.mark.parametrize("B", [1, 51, 5000, 20000])
 def test_host_buffer_call_equals_the_device_op(torch_cuda, B):
     """m2d_score_pairs_host (what Model.predict uses for host feeds) against the torch custom op: same kernel, same bits."""
     import torch
