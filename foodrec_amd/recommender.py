@@ -12,6 +12,7 @@ reference's driver (Train_recommender.py:180-199) -- ``loss_value``, ``learning_
 """
 from __future__ import annotations
 
+import itertools
 from typing import Optional, Sequence
 
 import numpy as np
@@ -51,7 +52,10 @@ def _ids(x, what: str) -> np.ndarray:
     if isinstance(x, np.ndarray) and x.dtype.kind in "iu":
         a = x.astype(np.int64, copy=False).reshape(-1)
     else:
-        a = np.fromiter((int(v) for v in x), dtype=np.int64, count=len(x))
+        try:
+            a = np.array(x, dtype=np.int64).reshape(-1)     # ints and decimal strings alike, one C loop
+        except (ValueError, TypeError, OverflowError):
+            a = np.fromiter((int(v) for v in x), dtype=np.int64, count=len(x))
     if a.size and (a.min() < -(2 ** 31) or a.max() >= 2 ** 31):
         raise IndexError("%s id does not fit int32" % what)
     return a.astype(np.int32)
@@ -61,6 +65,17 @@ def _mask(categories, C: int, B: int):
     """[B, C, 1] nested lists (dish_to_category.json values, evaluate.py:43) or [B, C] -> f32 [B, C]."""
     if isinstance(categories, torch.Tensor):
         m = categories.to(torch.float32)
+    elif (isinstance(categories, list) and len(categories) == B and B > 0 and isinstance(categories[0], list)
+          and len(categories[0]) == C and isinstance(categories[0][0], list)):
+        # the reference's own feed, [B][C][1] Python lists: flattening through iterators is ~5x faster than
+        # np.asarray on three levels of nesting (this conversion was half the cost of a 51-pair predict call)
+        it = itertools.chain.from_iterable(itertools.chain.from_iterable(categories))
+        try:
+            m = np.fromiter(it, dtype=np.float32, count=B * C).reshape(B, C)
+        except (ValueError, TypeError):
+            m = None
+        if m is None or next(it, None) is not None or sum(map(len, categories)) != B * C:
+            m = np.asarray(categories, dtype=np.float32)    # ragged or deeper than expected: let numpy say what is wrong
     else:
         m = np.asarray(categories, dtype=np.float32)
     if m.ndim == 3 and m.shape[2] == 1:
