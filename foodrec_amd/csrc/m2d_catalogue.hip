@@ -436,30 +436,45 @@ __global__ __launch_bounds__(256) void m2d_topk_generic(TopkArgs p, int K)
     }
 }
 
-// nsplit sorted partial lists per user -> final top-k
-__global__ void m2d_topk_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k,
-                                      float *out_scores, int32_t *out_ids)
+// nsplit sorted partial lists per user -> final top-k.  LPU lanes per user (LPU = nsplit rounded up to a power of two,
+// <= 64), lane w holding the head of split w's list; each of the k rounds is an argmax over the group by xor
+// shuffles and the winning lane steps to its next entry.  (The first form of this kernel walked all nsplit * k
+// entries from ONE thread through a scratch-memory pointer array: ~0.2 ms for a single user with 64 splits, most
+// of that call's latency.)  Splits cover increasing dish ranges, so on equal scores the lower split (= lower lane)
+// wins, which keeps ties in ascending-id order.
+template <int LPU>
+__global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k,
+                                                             float *out_scores, int32_t *out_ids)
 {
-    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= nU) return;
-    const float *s = ps + (size_t)u * nsplit * k;
-    const int32_t *id = pi + (size_t)u * nsplit * k;
-    // splits cover increasing dish ranges, so on equal scores the lower split wins (lower id)
-    int ptr[64];
-    for (int w = 0; w < nsplit; ++w) ptr[w] = 0;
-    for (int o = 0; o < k; ++o) {
-        int best = -1;
-        for (int w = 0; w < nsplit; ++w) {
-            if (ptr[w] >= k || id[w * k + ptr[w]] < 0) continue;
-            if (best < 0 || ahead(s[w * k + ptr[w]], s[best * k + ptr[best]])) best = w;
+    const int lane = threadIdx.x & 63, w = lane & (LPU - 1);
+    const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPU;
+    const bool live = u < nU && w < nsplit;
+    const float *s = ps + ((size_t)(live ? u : 0) * nsplit + (live ? w : 0)) * k;
+    const int32_t *id = pi + ((size_t)(live ? u : 0) * nsplit + (live ? w : 0)) * k;
+    int ptr = 0;
+    float hs = live ? s[0] : 0.f;
+    int32_t hi = live ? id[0] : -1;                          // -1: this list is exhausted (or the lane is idle)
+    for (int o = 0; o < k; ++o) {                           // wave-uniform trip count: the shuffles see a full EXEC
+        float bs = hs;
+        int32_t bi = hi;
+        int bw = w;
+#pragma unroll
+        for (int off = LPU / 2; off >= 1; off >>= 1) {
+            const float os = __shfl_xor(bs, off, 64);
+            const int32_t oi = __shfl_xor(bi, off, 64);
+            const int ow = __shfl_xor(bw, off, 64);
+            // the other candidate wins if this one is exhausted, or it ranks strictly ahead, or ties from a lower split
+            const bool take = oi >= 0 && (bi < 0 || ahead(os, bs) || (!ahead(bs, os) && ow < bw));
+            if (take) { bs = os; bi = oi; bw = ow; }
         }
-        if (best < 0) {
-            out_scores[u * k + o] = __builtin_nanf("");
-            out_ids[u * k + o] = -1;
-        } else {
-            out_scores[u * k + o] = s[best * k + ptr[best]];
-            out_ids[u * k + o] = id[best * k + ptr[best]];
-            ++ptr[best];
+        if (u < nU && w == 0) {
+            out_scores[u * k + o] = bi >= 0 ? bs : __builtin_nanf("");
+            out_ids[u * k + o] = bi;
+        }
+        if (live && bi >= 0 && bw == w) {                   // this lane's head was taken: step to its next entry
+            ++ptr;
+            hi = ptr < k ? id[ptr] : -1;
+            hs = ptr < k ? s[ptr] : 0.f;
         }
     }
 }
@@ -1093,6 +1108,17 @@ int ensure_grouped(m2d_engine *h, hipStream_t st)
     return M2D_OK;
 }
 
+void m2d_launch_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k, float *out_s, int32_t *out_i,
+                             hipStream_t st)
+{
+    int lpu = 1;
+    while (lpu < nsplit) lpu <<= 1;
+    const unsigned grid = (unsigned)((nU * lpu + 255) / 256);
+#define M2D_MERGE(L) if (lpu == L) hipLaunchKernelGGL(m2d_topk_merge_splits<L>, dim3(grid), dim3(256), 0, st, ps, pi, nU, nsplit, k, out_s, out_i);
+    M2D_MERGE(1) M2D_MERGE(2) M2D_MERGE(4) M2D_MERGE(8) M2D_MERGE(16) M2D_MERGE(32) M2D_MERGE(64)
+#undef M2D_MERGE
+}
+
 // shared tail of every MFMA retrieval launch: dish-range splits -> partial lists in scratch
 int pick_splits(m2d_engine *h, int64_t ublocks, int64_t tiles, int64_t min_tiles_per_split)
 {
@@ -1153,8 +1179,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     }
     M2D_HIP_TRY(h, hipGetLastError());
     if (nsplit > 1) {
-        hipLaunchKernelGGL(m2d_topk_merge_splits, dim3((unsigned)((nU + 127) / 128)), dim3(128), 0, st, a.out_scores,
-                           a.out_ids, nU, nsplit, k, final_s, final_i);
+        m2d_launch_merge_splits(a.out_scores, a.out_ids, nU, nsplit, k, final_s, final_i, st);
         M2D_HIP_TRY(h, hipGetLastError());
     }
     hipLaunchKernelGGL(m2d_topk_fill_absent, dim3((unsigned)((nU + 127) / 128)), dim3(128), 0, st, final_s, final_i, nU, k,
@@ -1206,8 +1231,7 @@ int launch_mfma(m2d_engine *h, TopkArgs &a, float *final_s, int32_t *final_i, hi
     hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(WAVES * 64), lds, st, a);
     M2D_HIP_TRY(h, hipGetLastError());
     if (nsplit > 1) {
-        hipLaunchKernelGGL(m2d_topk_merge_splits, dim3((unsigned)((a.nU + 127) / 128)), dim3(128), 0, st, a.out_scores,
-                           a.out_ids, a.nU, nsplit, a.k, final_s, final_i);
+        m2d_launch_merge_splits(a.out_scores, a.out_ids, a.nU, nsplit, a.k, final_s, final_i, st);
         M2D_HIP_TRY(h, hipGetLastError());
     }
     hipLaunchKernelGGL(m2d_topk_fill_absent, dim3((unsigned)((a.nU + 127) / 128)), dim3(128), 0, st, final_s, final_i,
