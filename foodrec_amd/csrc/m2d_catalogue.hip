@@ -1119,23 +1119,41 @@ void m2d_launch_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int
 #undef M2D_MERGE
 }
 
-// shared tail of every MFMA retrieval launch: dish-range splits -> partial lists in scratch
-int pick_splits(m2d_engine *h, int64_t ublocks, int64_t tiles, int64_t min_tiles_per_split)
+// More than 64 partial lists per user: two passes of the merge above -- groups of 64 consecutive splits first (a
+// "user" of that pass is one (user, group)), then the per-group winners.  nsplit must be a multiple of 64 then;
+// tmp_s / tmp_i hold nU * (nsplit / 64) * k entries.  Consecutive groups are consecutive dish ranges, so the
+// lower-split-wins tie rule carries through both passes.
+void m2d_launch_merge_splits2(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k, float *tmp_s, int32_t *tmp_i,
+                              float *out_s, int32_t *out_i, hipStream_t st)
+{
+    if (nsplit <= 64) {
+        m2d_launch_merge_splits(ps, pi, nU, nsplit, k, out_s, out_i, st);
+        return;
+    }
+    const int G = nsplit / 64;
+    m2d_launch_merge_splits(ps, pi, nU * G, 64, k, tmp_s, tmp_i, st);
+    m2d_launch_merge_splits(tmp_s, tmp_i, nU, G, k, out_s, out_i, st);
+}
+
+// shared tail of every MFMA retrieval launch: dish-range splits -> partial lists in scratch.  Few users: split the
+// dish range over up to max_splits blocks per user block so that a single query still uses the whole chip.
+int pick_splits(m2d_engine *h, int64_t ublocks, int64_t tiles, int64_t min_tiles_per_split, int max_splits = 64)
 {
     int nsplit = 1;
     const int64_t want = 2 * (int64_t)h->num_cu;
     if (ublocks < want) {
         int64_t ns = (want + ublocks - 1) / ublocks;
         const int64_t cap = tiles / min_tiles_per_split > 1 ? tiles / min_tiles_per_split : 1;
-        if (ns > 64) ns = 64;
+        if (ns > max_splits) ns = max_splits;
         if (ns > cap) ns = cap;
         nsplit = (int)ns;
     }
     if (h->opt_variant >= 100) {   // test hook: force the number of dish-range splits
         nsplit = h->opt_variant - 100;
         if (nsplit < 1) nsplit = 1;
-        if (nsplit > 64) nsplit = 64;
+        if (nsplit > max_splits) nsplit = max_splits;
     }
+    if (nsplit > 64) nsplit &= ~63;    // two-pass merge: whole groups of 64
     return nsplit;
 }
 
@@ -1152,10 +1170,11 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     a.users = users; a.nU = nU; a.U = h->U; a.user_base = h->user_base; a.k = k; a.tiles = h->grp_tiles;
     a.a = h->a; a.b = h->b; a.err = h->err_dev; a.dbg = g_m2d_diag_buffer;
     const int64_t ublocks = (nU + 32 * WAVES - 1) / (32 * WAVES);
-    const int nsplit = pick_splits(h, ublocks, a.tiles, 4 * TPS);
+    const int nsplit = pick_splits(h, ublocks, a.tiles, 2 * TPS, 512);
     a.nsplit = nsplit;
+    const size_t tmp_entries = nsplit > 64 ? (size_t)nU * (nsplit / 64) * k : 0;
     if (nsplit > 1) {
-        const size_t need = (size_t)nU * nsplit * k * 8 + 256;
+        const size_t need = ((size_t)nU * nsplit * k + tmp_entries) * 8 + 256;
         if (h->scratch_bytes < need) {
             if (h->scratch) M2D_HIP_TRY(h, hipFree(h->scratch));
             h->scratch = nullptr; h->scratch_bytes = 0;
@@ -1168,6 +1187,8 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         a.out_scores = final_s;
         a.out_ids = final_i;
     }
+    float *tmp_s = h->scratch ? h->scratch + (size_t)2 * nU * nsplit * k : nullptr;
+    int32_t *tmp_i = reinterpret_cast<int32_t *>(tmp_s ? tmp_s + tmp_entries : nullptr);
     if constexpr (BF16X3) {
         auto kern = m2d_topk_grouped_bf16<E, WAVES, KR>;
         M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1179,7 +1200,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     }
     M2D_HIP_TRY(h, hipGetLastError());
     if (nsplit > 1) {
-        m2d_launch_merge_splits(a.out_scores, a.out_ids, nU, nsplit, k, final_s, final_i, st);
+        m2d_launch_merge_splits2(a.out_scores, a.out_ids, nU, nsplit, k, tmp_s, tmp_i, final_s, final_i, st);
         M2D_HIP_TRY(h, hipGetLastError());
     }
     hipLaunchKernelGGL(m2d_topk_fill_absent, dim3((unsigned)((nU + 127) / 128)), dim3(128), 0, st, final_s, final_i, nU, k,

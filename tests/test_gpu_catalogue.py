@@ -83,9 +83,10 @@ def test_topk_dish_splits_and_tail_tiles():
     eng = ScoringEngine(PM, RE, CE)
     eng.set_dish_categories(cats)
     users = np.arange(0, 290, 3)
-    for forced in (101, 103, 108):                     # 1, 3, 8 dish-range splits
+    for forced in (101, 103, 108, 164, 228, 612):      # 1, 3, 8, 64 dish-range splits; 128 and 512 take the two-pass merge
         eng.set_option("variant", forced)
         _check(eng, PM, RE, CE, cats, users, 10)
+        _check(eng, PM, RE, CE, cats, users[:1], 10)   # a single query
     eng.set_option("variant", 0)
     _check(eng, PM, RE, CE, cats, users, 10)           # automatic split choice
     eng.set_option("variant", 9)                       # generic kernel on the same data
