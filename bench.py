@@ -38,8 +38,8 @@ def algorithmic_bytes_per_pair(C: int, E: int) -> int:
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=50)
-    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--users", type=int, default=1_000_000, help="users per GPU shard")
     p.add_argument("--dishes", type=int, default=100_000)
     p.add_argument("--embed", type=int, default=64)
