@@ -104,3 +104,29 @@ def test_float32_mode_tracks_float64():
         lb, _ = b.step(users, items, cats, labels)
         assert abs(la - lb) < 1e-5
     assert np.abs(a.PM - b.PM).max() < 2e-5
+
+
+@pytest.mark.parametrize("learner", ["sgd", "adagrad"])
+def test_two_steps_match_torch_optim_where_the_rules_coincide(learner):
+    """torch.optim.SGD and torch.optim.Adagrad(initial_accumulator_value=0.1, eps=0) apply the same formulas as the
+    TF 1.x optimizers for these two learners (dense autograd gradients sum duplicate rows, as TF's
+    _apply_sparse_duplicate_indices does; rows with a zero gradient do not move under either rule).  Adam and
+    RMSProp differ between the libraries (epsilon placement, slot initial values) and are not compared."""
+    PM, RE, CE, users, items, cats, labels = _batch(7)
+    lr = 0.05
+    st = T.TrainState(PM, RE, CE, learner, lr=lr)
+    tp, tr, tc = (torch.tensor(t, dtype=torch.float64, requires_grad=True) for t in (PM, RE, CE))
+    opt = (torch.optim.SGD([tp, tr, tc], lr=float(np.float32(lr))) if learner == "sgd" else
+           torch.optim.Adagrad([tp, tr, tc], lr=float(np.float32(lr)), initial_accumulator_value=0.1, eps=0.0))
+    for step in range(2):
+        u = np.roll(users, step * 3); d = np.roll(items, step * 5)
+        ref_loss, norm = st.step(u, d, cats, labels)
+        assert norm < 5.0                                   # no clipping in this case: torch has none here
+        opt.zero_grad()
+        logits = torch_graph.inference(tp, tr, tc, torch.tensor(u), torch.tensor(d), torch.tensor(cats, dtype=torch.float64))
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, torch.tensor(labels, dtype=torch.float64))
+        loss.backward()
+        opt.step()
+        assert abs(loss.item() - ref_loss) < 1e-12
+    for got, ref in ((st.PM, tp), (st.RE, tr), (st.CE, tc)):
+        np.testing.assert_allclose(got, ref.detach().numpy(), rtol=1e-9, atol=1e-12)
