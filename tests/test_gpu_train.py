@@ -78,6 +78,31 @@ def test_train_steps_match_restatement(learner, U, I, C, E, B):
     eng.train_end()
 
 
+def test_adam_at_the_reference_default_sizes():
+    """Train_recommender.py:35, :51-58: 64 657 users, 4 548 dishes, E = 200, batch 128, adam at lr 0.001 -- two steps
+    of the dense (every-row) update against the float32-mode restatement."""
+    import torch
+    from oracle import train_oracle as T
+    U, I, C, E, B = 64657, 4548, 4, 200, 128
+    PM, RE, CE, *_ = random_case(U, I, C, E, 1, seed=77)
+    PM, RE, CE = PM * 3, RE * 3, CE * 3
+    eng = _engine(PM, RE, CE)
+    eng.train_begin("adam", 0.001)
+    st = T.TrainState(PM, RE, CE, "adam", 0.001, dtype=np.float32)
+    for users, items, cats, labels in _batches(U, I, C, B, 2, seed=3):
+        ref_loss, _ = st.step(users, items, cats, labels)
+        out = eng.train_step(torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda"),
+                             torch.as_tensor(cats, device="cuda"), torch.as_tensor(labels, device="cuda")).cpu().numpy()
+        eng.check()
+        assert abs(out[0] - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    for got, ref, ini in ((eng.pm, st.PM, PM), (eng.re, st.RE, RE), (eng.ce, st.CE, CE)):
+        got = got.cpu().numpy()
+        moved = np.abs(ref - ini) > 0
+        assert moved.any() and not moved.all() or ref.size == C * E       # adam moved the touched rows only so far
+        assert np.abs(got - ref).max() <= 2e-6                           # 2 steps of lr 0.001; see the module docstring
+        assert np.array_equal(got[~moved], ini[~moved])                  # rows without history are bit-for-bit untouched
+
+
 def test_clip_engages_and_loss_only_leaves_tables_alone():
     import torch
     from oracle import train_oracle as T
