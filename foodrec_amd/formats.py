@@ -72,6 +72,34 @@ class Dataset:
         self.num_test = sum(len(v) for v in self.testRatings.values())
 
 
+def get_train_instances(train: Dict[str, List[int]], testNegatives: Dict[str, List[int]], dish_to_category: Dict[str, list],
+                        user_to_one_hot_label: Dict[str, list], rng=None):
+    """The training feeds the reference's driver builds once per run (``Train_recommender.py:69-93``): per user of
+    ``train`` (dict order), up to 200 of its positives drawn with ``random.sample`` (label 1, write_sign [1.0]), then
+    the first 50 of its test negatives (label 0, write_sign [-1.0]); ``categories`` and ``user_one_hot_label`` are
+    looked up per instance.  Returns the six parallel lists in the reference's order:
+    ``user_input_index, item_input_index, labels, categories, write_sign, user_one_hot_label``.
+
+    ``rng`` is a ``random.Random`` (default: the ``random`` module itself, as in the reference, so seeding
+    ``random`` reproduces its draw)."""
+    import random as _random
+    rng = rng or _random
+    users, items, labels, categories, write_sign, one_hot = [], [], [], [], [], []
+    for user in train:
+        positives = train[str(user)]
+        for dish in rng.sample(positives, min(len(positives), 200)):           # :72-73
+            users.append(user); items.append(dish); labels.append(1)
+            categories.append(dish_to_category[str(dish)])
+            write_sign.append([1.0])
+            one_hot.append(user_to_one_hot_label[str(user)])
+        for dish in testNegatives[str(user)][:50]:                                # :81-82
+            users.append(user); items.append(dish); labels.append(0)
+            categories.append(dish_to_category[str(dish)])
+            write_sign.append([-1.0])
+            one_hot.append(user_to_one_hot_label[str(user)])
+    return users, items, labels, categories, write_sign, one_hot
+
+
 def load_numpy_file(path: str) -> np.ndarray:
     return np.load(path)                      # Train_recommender.py:99-101
 

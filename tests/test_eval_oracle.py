@@ -76,3 +76,33 @@ def test_synthetic_split_roundtrip(tmp_path):
     d2c = formats.load_json_file(os.path.join(tmp_path, "dish_to_category.json"))
     assert len(d2c) == 40 and np.asarray(d2c["0"]).shape == (4, 1)
     assert all(sum(x[0] for x in v) >= 1 for v in d2c.values())
+
+
+def test_train_instances_follow_the_reference_driver():
+    """Train_recommender.py:69-93: per user, <= 200 positives drawn with random.sample, then its first 50 test
+    negatives; six parallel lists.  Checked against the rule spelled out again here, same `random` seed."""
+    import random
+    from foodrec_amd import formats
+    rs = np.random.default_rng(0)
+    train = {str(u): rs.integers(0, 30, n).tolist() for u, n in ((3, 5), (1, 260), (7, 1))}
+    negs = {u: rs.integers(0, 30, n).tolist() for u, n in (("3", 100), ("1", 100), ("7", 20))}
+    d2c = {str(d): [[float(d % 2)], [1.0], [0.0], [float(d % 3 == 0)]] for d in range(30)}
+    u2l = {u: [float(int(u) == k) for k in range(8)] for u in train}
+    random.seed(5)
+    got = formats.get_train_instances(train, negs, d2c, u2l)
+    random.seed(5)
+    want = [[], [], [], [], [], []]
+    for user in train:
+        pos = random.sample(train[user], min(len(train[user]), 200))
+        for dish, y, sgn in [(p, 1, [1.0]) for p in pos] + [(n, 0, [-1.0]) for n in negs[user][:50]]:
+            for lst, v in zip(want, (user, dish, y, d2c[str(dish)], sgn, u2l[user])):
+                lst.append(v)
+    assert [list(x) for x in got] == want
+    users, items, labels, cats, sign, onehot = got
+    assert len(users) == (5 + 50) + (200 + 50) + (1 + 20)
+    assert users[0] == "3" and users[55] == "1" and users[-1] == "7"          # dict order, user by user
+    assert sum(labels) == 5 + 200 + 1 and sign[0] == [1.0] and sign[5] == [-1.0]
+    # an explicit generator leaves the global `random` state alone
+    state = random.getstate()
+    formats.get_train_instances(train, negs, d2c, u2l, rng=random.Random(1))
+    assert random.getstate() == state
