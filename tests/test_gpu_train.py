@@ -5,6 +5,7 @@ Tolerances.  Loss and gradient norm: 1e-5 relative.  Tables after k steps: float
 oracle; Adam divides by sqrt(v) + 1e-8, so an element whose gradient is ~0 in float32 but not in float64 may move
 by up to lr in one and not the other -- the bound on a table is therefore stated as a fraction of what the step
 moved (1e-3 of lr per step for adam / rmsprop, 1e-5 relative for sgd / adagrad)."""
+import os
 import types
 
 import numpy as np
@@ -200,3 +201,55 @@ def test_session_serves_the_training_fetches():
     assert sess.run(model.epoch_increment) == 1
     with pytest.raises(ValueError, match="labels"):
         sess.run([model.train_op], {k: v for k, v in feed.items() if k is not model.labels})
+
+
+def test_driver_shaped_loop_end_to_end(tmp_path):
+    """The inner loop of Train_recommender.py:124-216 on files in the reference's formats: load, build the training
+    feeds, run batches through sess.run([loss_value, learning_rate, general, train_op]) (the first batch through the
+    8-pair memory-write branch, :169-186), evaluate.  Checks the plumbing and that training lowers the training loss;
+    the numbers themselves are pinned by the tests above."""
+    import random
+    from foodrec_amd import Model, Session, evaluate_model, formats
+    base = formats.write_synthetic_split(str(tmp_path), num_users=60, num_dishes=50, embed_size=32, num_labels=6,
+                                         train_per_user=4)
+    ds = formats.Dataset(base)
+    load = lambda n: formats.load_numpy_file(os.path.join(str(tmp_path), n))
+    d2c = formats.load_json_file(os.path.join(str(tmp_path), "dish_to_category.json"))
+    u2l = formats.load_json_file(os.path.join(str(tmp_path), "user_to_one_hot_label.json"))
+    args = types.SimpleNamespace(learner="adam", num_categories=4, num_users=60, num_labels=6, embed_size=32, lr=0.01,
+                                 decay_steps=1000, decay_rate=1.0, high_level_score_coefficient=0.99, beta_1=0.01,
+                                 beta_2=0.01, alpha=0.01)
+    model = Model(args, load("Personal_Memory.npy"), load("Recipe_Embedding.npy"), load("Category_Embedding.npy"),
+                  load("General_Memory.npy"))
+    sess = Session(model)
+    random.seed(1)
+    users, items, labels, cats, sign, onehot = formats.get_train_instances(ds.trainMatrix, ds.testNegatives, d2c, u2l)
+    n, bs = len(users), 128
+    assert n == 60 * (4 + 50)
+    hits0, _ = evaluate_model(sess, model, ds.testRatings, ds.testNegatives, 10, d2c)
+    losses = []
+    for epoch in range(3):
+        tot = 0.0
+        for start in range(0, n - bs + 1, bs):
+            sl = slice(start, start + bs)
+            feed = {model.user_input: users[sl], model.item_input: items[sl], model.labels: labels[sl],
+                    model.categories: cats[sl], model.user_one_hot_label: onehot[sl], model.write_sign: sign[sl],
+                    model.dropout_keep_prob: 0.8, model.is_training_flag: True}
+            if epoch == 0 and start == 0:                   # the memory-write branch: 16 mini-batches of 8
+                for mini in range(16):
+                    ms = slice(start + 8 * mini, start + 8 * (mini + 1))
+                    mfeed = {k: (v[ms] if isinstance(v, list) else v) for k, v in
+                             ((model.user_input, users), (model.item_input, items), (model.labels, labels),
+                              (model.categories, cats), (model.user_one_hot_label, onehot), (model.write_sign, sign))}
+                    curr_loss, lr, personal, general, _ = sess.run(
+                        [model.loss_value, model.learning_rate, model.personal, model.general, model.train_op], mfeed)
+            else:
+                curr_loss, lr, general, _ = sess.run([model.loss_value, model.learning_rate, model.general, model.train_op], feed)
+            assert np.isfinite(curr_loss) and lr == np.float32(0.01)
+            tot += float(curr_loss)
+        sess.run(model.epoch_increment)
+        losses.append(tot)
+    assert losses[-1] < losses[0]
+    hits, ndcgs = evaluate_model(sess, model, ds.testRatings, ds.testNegatives, 10, d2c)
+    assert len(hits) == len(ndcgs) == 60 and len(hits0) == 60
+    assert np.isfinite(model.engine.pm.cpu().numpy()).all() and np.isfinite(model.general_memory()).all()
