@@ -56,6 +56,8 @@ SIGNATURES = {
     "m2d_train_begin": (_c.c_int, [_vp, _i32, _c.c_float, _c.c_float, _vp]),
     "m2d_train_step": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "m2d_train_slot": (_c.c_int, [_vp, _i32, _i32, _vp, _i32, _vp]),
+    "m2d_tables_updated": (_c.c_int, [_vp]),
+    "m2d_train_steps": (_c.c_int, [_vp, _c.POINTER(_i64), _i32]),
     "m2d_train_end": (_c.c_int, [_vp]),
     "m2d_check": (_c.c_int, [_vp, _vp, _c.POINTER(_i64), _c.POINTER(_i64)]),
     "m2d_stream_read_probe": (_c.c_int, [_vp, _vp, _i64, _vp, _vp]),

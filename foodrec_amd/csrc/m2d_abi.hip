@@ -470,6 +470,22 @@ int m2d_train_slot(m2d_engine *h, int32_t table, int32_t slot, float *buf, int32
     return M2D_OK;
 }
 
+int m2d_tables_updated(m2d_engine *h)
+{
+    if (!h) return M2D_ERR_INVALID_ARG;
+    h->dish_vec_valid = false;      // factored dish vectors (Recipe_Embedding, Category_Embedding)
+    h->grp_valid = false;           // pattern-grouped retrieval tables (Recipe_Embedding)
+    return M2D_OK;
+}
+
+int m2d_train_steps(m2d_engine *h, int64_t *steps, int32_t set)
+{
+    if (!h || !steps) return M2D_ERR_INVALID_ARG;
+    if (!h->train) return fail(h, M2D_ERR_NOT_CONFIGURED, "m2d_train_steps: call m2d_train_begin first");
+    if (set && *steps < 0) return fail(h, M2D_ERR_INVALID_ARG, "m2d_train_steps: negative step count");
+    return m2d_train_step_count(h, steps, set);
+}
+
 int m2d_train_end(m2d_engine *h)
 {
     if (!h) return M2D_ERR_INVALID_ARG;

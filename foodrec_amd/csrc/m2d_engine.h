@@ -128,6 +128,7 @@ void m2d_train_release(m2d_engine *h);
 int m2d_launch_train_step(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats, const float *labels,
                           int64_t B, int32_t apply, float *out, hipStream_t stream);
 int m2d_train_get_slot(m2d_engine *h, int32_t table, int32_t slot, float **dev, int64_t *count);
+int m2d_train_step_count(m2d_engine *h, int64_t *steps, int32_t set);
 int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_t *items, int64_t B, float *out,
                                hipStream_t stream);
 int m2d_launch_rank_candidates(m2d_engine *h, const int32_t *users, const int32_t *items,

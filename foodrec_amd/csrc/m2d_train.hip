@@ -435,6 +435,21 @@ int m2d_launch_train_step(m2d_engine *h, const int32_t *users, const int32_t *it
     return M2D_OK;
 }
 
+// steps applied so far; setting it (checkpoint resume) also replays Adam's beta-power products, which TF keeps as
+// float32 variables multiplied by beta once per step
+int m2d_train_step_count(m2d_engine *h, int64_t *steps, int32_t set)
+{
+    m2d_train_state *t = h->train;
+    if (set) {
+        t->steps = *steps;
+        t->b1p = 0.9f; t->b2p = 0.999f;
+        for (int64_t i = 0; i < t->steps; ++i) { t->b1p *= 0.9f; t->b2p *= 0.999f; }
+    } else {
+        *steps = t->steps;
+    }
+    return M2D_OK;
+}
+
 int m2d_train_get_slot(m2d_engine *h, int32_t table, int32_t slot, float **dev, int64_t *count)
 {
     m2d_train_state *t = h->train;

@@ -221,6 +221,16 @@ class ScoringEngine:
         _native.raise_for(rc, self._h)
         return buf
 
+    def tables_updated(self):
+        """Call after writing to self.pm / self.re / self.ce directly (they are borrowed by the engine)."""
+        _native.raise_for(_native.lib().m2d_tables_updated(self._h), self._h)
+
+    def train_steps(self, restore: Optional[int] = None) -> int:
+        """Optimizer steps applied since train_begin; with `restore`, sets that count (checkpoint resume)."""
+        v = ctypes.c_int64(0 if restore is None else int(restore))
+        _native.raise_for(_native.lib().m2d_train_steps(self._h, ctypes.byref(v), 0 if restore is None else 1), self._h)
+        return int(v.value)
+
     def train_end(self):
         _native.raise_for(_native.lib().m2d_train_end(self._h), self._h)
         self._training = False

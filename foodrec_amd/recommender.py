@@ -201,6 +201,56 @@ class Model:
         return self.engine.write_memory(ut, dt, mt, sign, y, self._gm_dev, float(self.beta_1), float(self.beta_2),
                                         float(self.alpha), want_means=True)
 
+    # -- checkpoint (stands where the driver uses tf.train.Saver, Train_recommender.py:145-149, :218-222) ----------
+    _TABLE_FILES = ("Personal_Memory", "Recipe_Embedding", "Category_Embedding", "General_Memory")
+
+    def save(self, path: str):
+        """One ``.npz``: the four tables under the names of the reference's ``.npy`` files (so each can be re-saved
+        with ``np.save`` and fed back to the reference), plus the optimizer's slots and step count once training has
+        started."""
+        self.engine.check()
+        data = {"Personal_Memory": self.engine.pm.cpu().numpy(), "Recipe_Embedding": self.engine.re.cpu().numpy(),
+                "Category_Embedding": self.engine.ce.cpu().numpy(), "epoch_step": np.int64(self.epoch_step)}
+        if self.General_Memory is not None:
+            data["General_Memory"] = self.general_memory()
+        if self._train_started:
+            data["learner"] = np.str_(str(self.learner or "sgd").lower())
+            data["steps"] = np.int64(self.engine.train_steps())
+            for tb in range(3):
+                for sl in range(2):
+                    try:
+                        data["slot_%d_%d" % (tb, sl)] = self.engine.train_slot(tb, sl).cpu().numpy()
+                    except ValueError:                      # this learner has no such slot
+                        pass
+        np.savez(path, **data)
+
+    def restore(self, path: str):
+        """Load what `save` wrote INTO this model (same shapes): tables in place on the device, optimizer state if the
+        file has it and the learner matches."""
+        z = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+        for name, dst in (("Personal_Memory", self.engine.pm), ("Recipe_Embedding", self.engine.re),
+                          ("Category_Embedding", self.engine.ce)):
+            src = torch.from_numpy(z[name])
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError("%s in the checkpoint is %r, the model has %r" % (name, tuple(src.shape), tuple(dst.shape)))
+            dst.copy_(src)
+        self.engine.tables_updated()
+        if "General_Memory" in z.files:
+            self.General_Memory = z["General_Memory"]
+            self._gm_dev = None
+        self.epoch_step = int(z["epoch_step"]) if "epoch_step" in z.files else 0
+        if "steps" in z.files:
+            if str(z["learner"]) != str(self.learner or "sgd").lower():
+                raise ValueError("checkpoint was trained with %s, this model uses %s" % (z["learner"], self.learner))
+            self.engine.train_begin(self.learner or "sgd", float(self.learning_rate), 5.0)
+            self._train_started = True
+            self.engine.train_steps(restore=int(z["steps"]))
+            for key in z.files:
+                if key.startswith("slot_"):
+                    _, tb, sl = key.split("_")
+                    self.engine.train_slot(int(tb), int(sl), restore=torch.from_numpy(z[key]))
+        self.engine.check()
+
     def general_memory(self) -> np.ndarray:
         """General_Memory as it stands (host copy)."""
         return np.asarray(self.General_Memory, dtype=np.float32) if self._gm_dev is None else self._gm_dev.cpu().numpy()

@@ -141,6 +141,15 @@ int m2d_train_begin(m2d_engine *h, int32_t learner, float lr, float clip_norm, v
 int m2d_train_step(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats, const float *labels,
                    int64_t B, int32_t apply, float *out, void *stream);
 int m2d_train_slot(m2d_engine *h, int32_t table, int32_t slot, float *buf, int32_t restore, void *stream);
+/* Tell the engine that borrowed table memory (M2D_TABLES_DEVICE) was written from outside -- a checkpoint restore,
+ * an optimizer of the caller's own: everything the engine derives from Recipe_Embedding / Category_Embedding
+ * (retrieval's dish vectors and pattern-grouped tables) is rebuilt on next use.  m2d_train_step and
+ * m2d_write_memory do this themselves. */
+int m2d_tables_updated(m2d_engine *h);
+
+/* Optimizer steps applied since m2d_train_begin: read (*steps receives it, set = 0) or restored (set = 1, for a
+ * checkpoint resume; Adam's bias-correction powers are re-derived from it). */
+int m2d_train_steps(m2d_engine *h, int64_t *steps, int32_t set);
 int m2d_train_end(m2d_engine *h);
 
 /* ---- build-defined extension, NO reference counterpart (BASELINE.json configs 2-5) ----

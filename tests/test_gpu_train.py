@@ -253,3 +253,42 @@ def test_driver_shaped_loop_end_to_end(tmp_path):
     hits, ndcgs = evaluate_model(sess, model, ds.testRatings, ds.testNegatives, 10, d2c)
     assert len(hits) == len(ndcgs) == 60 and len(hits0) == 60
     assert np.isfinite(model.engine.pm.cpu().numpy()).all() and np.isfinite(model.general_memory()).all()
+
+
+def test_checkpoint_save_restore_resumes_training(tmp_path):
+    """Model.save / Model.restore stand where the driver uses tf.train.Saver: tables, optimizer slots and step count
+    come back, training continues as if uninterrupted, and retrieval sees the restored tables."""
+    import torch
+    from foodrec_amd import Model
+    U, I, C, E, B = 150, 90, 4, 64, 64
+    PM, RE, CE, *_ = random_case(U, I, C, E, 1, seed=31)
+    GM = np.zeros((5, C + 1, E), np.float32)
+    args = types.SimpleNamespace(learner="adam", num_categories=C, num_users=U, num_labels=5, embed_size=E, lr=0.01,
+                                 high_level_score_coefficient=0.99, beta_1=0.01, beta_2=0.01, alpha=0.01)
+    batches = _batches(U, I, C, B, 3, seed=8)
+    a = Model(args, PM.copy(), RE.copy(), CE.copy(), GM.copy())
+    for b in batches[:2]:
+        a.train_step(*b)
+    ck = os.path.join(str(tmp_path), "ck")
+    a.save(ck)
+    z = np.load(ck + ".npz")
+    assert z["Personal_Memory"].shape == PM.shape and int(z["steps"]) == 2 and str(z["learner"]) == "adam"
+    b_model = Model(args, PM.copy(), RE.copy(), CE.copy(), GM.copy())
+    dish_cats = np.ones((I, C), np.float32)
+    b_model.set_dish_categories(dish_cats)
+    before = b_model.topk(np.arange(8), 5)[1]              # builds the retrieval tables from the UNtrained RE
+    b_model.restore(ck)
+    assert torch.equal(b_model.engine.pm, a.engine.pm) and torch.equal(b_model.engine.re, a.engine.re)
+    assert b_model.engine.train_steps() == 2
+    la, _ = a.train_step(*batches[2])
+    lb, _ = b_model.train_step(*batches[2])
+    assert la == pytest.approx(lb, rel=1e-6)
+    for x, y in ((a.engine.pm, b_model.engine.pm), (a.engine.re, b_model.engine.re), (a.engine.ce, b_model.engine.ce)):
+        assert (x - y).abs().max().item() <= 1e-6           # float-atomic order is the only difference
+    a.set_dish_categories(dish_cats)
+    sa, ia = a.topk(np.arange(8), 5)
+    sb, ib = b_model.topk(np.arange(8), 5)                  # stale tables would still rank with the untrained RE
+    np.testing.assert_allclose(sa, sb, rtol=1e-4, atol=1e-5)
+    wrong = types.SimpleNamespace(**{**vars(args), "learner": "sgd"})
+    with pytest.raises(ValueError, match="trained with adam"):
+        Model(wrong, PM.copy(), RE.copy(), CE.copy(), GM.copy()).restore(ck)
