@@ -22,9 +22,11 @@
 //   claim     one thread per pair: the first pair to see a user (dish) claims the next compact slot for it in a
 //             row -> slot map (atomicCAS), so duplicate ids share one gradient row;
 //   grad      one wave per pair: forward (two wave reductions), loss term, then the pair's gradient rows are
-//             float-atomic-added into the compact buffers; sum of squares of the per-pair values and the loss go
-//             to two double accumulators; dCE is reduced per wave in LDS first;
-//   finalize  one block: norm over dCE joins in, writes {loss, global norm, scale, lr};
+//             float-atomic-added into the compact buffers; dCE (reduced per wave in LDS), the loss sum and the sum
+//             of squares of the per-pair values leave each block as plain per-block partials;
+//   reduce    the per-block dCE partials -> dCE;
+//   finalize  one block: per-block loss / square sums in a fixed order, norm over dCE joins in, writes
+//             {loss, global norm, scale, lr};
 //   apply     rows (Adam: all rows; others: claimed rows) and the dense dCE;
 //   cleanup   claimed rows: map entry back to -1, compact gradient row back to zero.
 // An out-of-range id is latched by the claim pass (m2d_check reports it) and the apply pass then leaves every
@@ -47,7 +49,9 @@ struct TrainArgs {
     int32_t *cnt;               // [0] users claimed, [1] dishes claimed
     float *gu, *gd;             // [cap, (C+1) E], [cap, E]
     float *gce;                 // [C, E]
-    double *acc;                // [0] sum of loss terms, [1] sum of squares of the per-pair gradient values
+    float *part_ce;             // [grid, C, E] per-block partial dCE (summed by the finalize kernel), or null
+    double *part_acc;           // [grid, 2]    per-block partial {loss sum, square sum}
+    int32_t nblocks;            // grid of the grad kernel
     float *scal;                // [0] loss, [1] global norm, [2] scale, [3] learning rate
     int32_t *err;
     int32_t accumulate;         // 0: loss + norm only (no slots are claimed, nothing is added to gu / gd)
@@ -91,6 +95,9 @@ __global__ __launch_bounds__(256) void m2d_train_claim(TrainArgs p)
 }
 
 // One wave per pair.  LDS: this wave's partial dCE [C, E] when it fits (ce_lds != 0), else atomics to global.
+// Nothing every wave would add to the same few addresses goes through atomics: dCE (C*E floats), the loss sum and
+// the square sum leave a block as plain stores into per-block partial rows that the finalize kernel adds up in a
+// fixed order (8192 waves each adding 256 floats into one 1-KiB dCE was 250 us of a 330-us kernel).
 __global__ __launch_bounds__(256) void m2d_train_grad(TrainArgs p, int ce_lds)
 {
     extern __shared__ float dce_all[];
@@ -167,19 +174,58 @@ __global__ __launch_bounds__(256) void m2d_train_grad(TrainArgs p, int ce_lds)
         sq_acc += (double)wave_sum(sq);
         loss_acc += (double)loss_b;
     }
+    __shared__ double wave_acc[4][2];
+    if (lane == 0) { wave_acc[wv][0] = loss_acc; wave_acc[wv][1] = sq_acc; }
     __syncthreads();
-    if (ce_lds)
-        for (int i = lane; i < C * E; i += 64)
-            if (dce[i] != 0.f) atomicAdd(p.gce + i, dce[i]);
-    if (lane == 0) {
-        atomicAdd(p.acc + 0, loss_acc);
-        atomicAdd(p.acc + 1, sq_acc);
+    if (ce_lds) {
+        float *row = p.part_ce + (size_t)blockIdx.x * C * E;
+        for (int i = threadIdx.x; i < C * E; i += 256)
+            row[i] = (dce_all[i] + dce_all[C * E + i]) + (dce_all[2 * C * E + i] + dce_all[3 * C * E + i]);
+    }
+    if (threadIdx.x < 2)
+        p.part_acc[(size_t)blockIdx.x * 2 + threadIdx.x] =
+            (wave_acc[0][threadIdx.x] + wave_acc[1][threadIdx.x]) + (wave_acc[2][threadIdx.x] + wave_acc[3][threadIdx.x]);
+}
+
+// dCE[i] = sum over the grad kernel's blocks of their partial rows.  A block owns 64 columns and every gridDim.y-th
+// slice of the rows; its 16 waves split those, lane l reads column l of each (256-B coalesced); the gridDim.y
+// block sums meet in dCE through one float atomic each (dCE is zeroed at the start of the step).
+__global__ __launch_bounds__(1024) void m2d_train_reduce_ce(TrainArgs p)
+{
+    __shared__ float wsum[16][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = p.C * p.E, i = blockIdx.x * 64 + lane;
+    float a = 0.f;
+    if (i < n)
+        for (int b = blockIdx.y * 16 + wv; b < p.nblocks; b += 16 * gridDim.y) a += p.part_ce[(size_t)b * n + i];
+    wsum[wv][lane] = a;
+    __syncthreads();
+    if (wv == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += wsum[w][lane];
+        atomicAdd(p.gce + i, t);
     }
 }
 
 __global__ __launch_bounds__(256) void m2d_train_finalize(TrainArgs p)
 {
     __shared__ double part[4];
+    __shared__ double tot[2][4];
+    {   // per-block partial loss / square sums, fixed order
+        double l = 0.0, q = 0.0;
+        for (int b = threadIdx.x; b < p.nblocks; b += 256) {
+            l += p.part_acc[(size_t)b * 2];
+            q += p.part_acc[(size_t)b * 2 + 1];
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            l += __shfl_xor(l, off, 64);
+            q += __shfl_xor(q, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { tot[0][threadIdx.x >> 6] = l; tot[1][threadIdx.x >> 6] = q; }
+    }
+    __syncthreads();
     double s = 0.0;
     for (int i = threadIdx.x; i < p.C * p.E; i += 256) s += (double)p.gce[i] * (double)p.gce[i];
 #pragma unroll
@@ -187,9 +233,9 @@ __global__ __launch_bounds__(256) void m2d_train_finalize(TrainArgs p)
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double n2 = p.acc[1] + part[0] + part[1] + part[2] + part[3];
+        const double n2 = ((tot[1][0] + tot[1][1]) + (tot[1][2] + tot[1][3])) + part[0] + part[1] + part[2] + part[3];
         const float norm = (float)sqrt(n2);
-        p.scal[0] = (float)(p.acc[0] / (double)p.B);                                // reduce_mean, :103
+        p.scal[0] = (float)(((tot[0][0] + tot[0][1]) + (tot[0][2] + tot[0][3])) / (double)p.B);   // reduce_mean, :103
         p.scal[1] = norm;
         p.scal[2] = p.clip * fminf(1.0f / norm, 1.0f / p.clip);                     // clip_by_global_norm
         p.scal[3] = p.lr;
@@ -310,7 +356,8 @@ struct m2d_train_state {
     float *slot[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // [PM, RE, CE][slot]
     int32_t *map_u = nullptr, *map_d = nullptr, *slot_u = nullptr, *slot_d = nullptr, *cnt = nullptr;
     float *gu = nullptr, *gd = nullptr, *gce = nullptr, *scal = nullptr;
-    double *acc = nullptr;
+    float *part_ce = nullptr;           // [num_cu * 8, C, E]
+    double *part_acc = nullptr;         // [num_cu * 8, 2]
     int64_t cap = 0;                    // pairs the compact buffers hold
 };
 
@@ -322,7 +369,7 @@ void m2d_train_release(m2d_engine *h)
         for (float *q : tb)
             if (q) (void)hipFree(q);
     for (void *q : {(void *)t->map_u, (void *)t->map_d, (void *)t->slot_u, (void *)t->slot_d, (void *)t->cnt, (void *)t->gu,
-                    (void *)t->gd, (void *)t->gce, (void *)t->scal, (void *)t->acc})
+                    (void *)t->gd, (void *)t->gce, (void *)t->scal, (void *)t->part_ce, (void *)t->part_acc})
         if (q) (void)hipFree(q);
     delete t;
     h->train = nullptr;
@@ -350,7 +397,8 @@ int m2d_train_setup(m2d_engine *h, int32_t learner, float lr, float clip_norm, h
     M2D_HIP_TRY(h, hipMalloc((void **)&t->cnt, 2 * 4));
     M2D_HIP_TRY(h, hipMalloc((void **)&t->gce, (size_t)n[2] * 4));
     M2D_HIP_TRY(h, hipMalloc((void **)&t->scal, 4 * 4));
-    M2D_HIP_TRY(h, hipMalloc((void **)&t->acc, 2 * 8));
+    M2D_HIP_TRY(h, hipMalloc((void **)&t->part_ce, (size_t)h->num_cu * 8 * n[2] * 4));
+    M2D_HIP_TRY(h, hipMalloc((void **)&t->part_acc, (size_t)h->num_cu * 8 * 2 * 8));
     M2D_HIP_TRY(h, hipMemsetAsync(t->scal, 0, 16, stream));
     M2D_HIP_TRY(h, hipGetLastError());
     return M2D_OK;
@@ -379,10 +427,9 @@ int m2d_launch_train_step(m2d_engine *h, const int32_t *users, const int32_t *it
     a.users = users; a.items = items; a.cats = cats; a.labels = labels;
     a.B = B; a.U = h->U; a.I = h->I; a.user_base = h->user_base; a.C = C; a.E = E; a.a = h->a; a.b = h->b;
     a.map_u = t->map_u; a.map_d = t->map_d; a.slot_u = t->slot_u; a.slot_d = t->slot_d; a.cnt = t->cnt;
-    a.gu = t->gu; a.gd = t->gd; a.gce = t->gce; a.acc = t->acc; a.scal = t->scal; a.err = h->err_dev;
+    a.gu = t->gu; a.gd = t->gd; a.gce = t->gce; a.scal = t->scal; a.err = h->err_dev;
     a.accumulate = apply ? 1 : 0; a.clip = t->clip; a.lr = t->lr;      // Global_Step never moves (:240): lr is constant
     M2D_HIP_TRY(h, hipMemsetAsync(t->cnt, 0, 8, stream));
-    M2D_HIP_TRY(h, hipMemsetAsync(t->acc, 0, 16, stream));
     M2D_HIP_TRY(h, hipMemsetAsync(t->gce, 0, (size_t)C * E * 4, stream));
     if (apply) {
         hipLaunchKernelGGL(m2d_train_claim, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, a);
@@ -390,8 +437,15 @@ int m2d_launch_train_step(m2d_engine *h, const int32_t *users, const int32_t *it
     }
     const size_t lds = (size_t)4 * C * E * 4;
     const int ce_lds = lds <= 48 * 1024;
-    hipLaunchKernelGGL(m2d_train_grad, dim3(blocks_for(h, B)), dim3(256), ce_lds ? lds : 0, stream, a, ce_lds);
+    a.part_ce = t->part_ce; a.part_acc = t->part_acc;
+    a.nblocks = (int32_t)blocks_for(h, B);
+    hipLaunchKernelGGL(m2d_train_grad, dim3((unsigned)a.nblocks), dim3(256), ce_lds ? lds : 0, stream, a, ce_lds);
     M2D_HIP_TRY(h, hipGetLastError());
+    if (ce_lds) {
+        const unsigned ry = a.nblocks >= 512 ? 8 : 1;
+        hipLaunchKernelGGL(m2d_train_reduce_ce, dim3((unsigned)((C * E + 63) / 64), ry), dim3(1024), 0, stream, a);
+        M2D_HIP_TRY(h, hipGetLastError());
+    }
     hipLaunchKernelGGL(m2d_train_finalize, dim3(1), dim3(256), 0, stream, a);
     M2D_HIP_TRY(h, hipGetLastError());
     if (out) M2D_HIP_TRY(h, hipMemcpyAsync(out, t->scal, 16, hipMemcpyDeviceToDevice, stream));
