@@ -382,7 +382,7 @@ def train_workload(a, torch, foodrec_amd, dev):
                        "users": U, "dishes": I, "embed_size": E, "batch": B, "learner": a.learner},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": None, "step_avg_ms": avg_ms, "algorithmic_bytes_per_step": alg,
-                         "note": ("whole step (claim + grad + finalize + 3 apply + 2 cleanup launches) over the bytes the "
+                         "note": ("whole step (claim + grad + reduce + finalize + 3 apply + 2 cleanup launches) over the bytes the "
                                   "update rule must move: 6 x table bytes for TF 1.x Adam, which decays and moves every "
                                   "row every step" if dense else
                                   "whole step over the batch rows' bytes; launch-bound at this batch size")}}
