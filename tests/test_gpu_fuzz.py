@@ -1,0 +1,57 @@
+"""Property-based parity of the pair-score path on arbitrary shapes (hypothesis): any embed size (the vectorised kernels
+need E % 4 == 0 and C == 4, everything else takes the generic kernel), any batch length, masks as arbitrary
+non-negative weights with zero rows (0/0 -> NaN, Model_Recommender.py:79), against the float64 restatement; and the
+latency / throughput forms of the kernel against each other, bit for bit."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from helpers import assert_scores_close
+
+pytestmark = pytest.mark.gpu
+
+
+@st.composite
+def cases(draw):
+    C = draw(st.sampled_from([4, 4, 4, 1, 2, 3, 5, 6]))
+    E = draw(st.one_of(st.integers(1, 64).map(lambda x: 4 * x), st.integers(1, 300)))
+    U = draw(st.integers(1, 40))
+    I = draw(st.integers(1, 40))
+    B = draw(st.integers(1, 300))
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    weights = draw(st.booleans())
+    return C, E, U, I, B, seed, weights
+
+
+@settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+@given(cases())
+def test_any_shape_matches_the_restatement(case):
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    C, E, U, I, B, seed, weights = case
+    rng = np.random.default_rng(seed)
+    s = 1.0 / np.sqrt(E)
+    PM = (rng.standard_normal((U, C + 1, E)) * s).astype(np.float32)
+    RE = (rng.standard_normal((I, E)) * s).astype(np.float32)
+    CE = (rng.standard_normal((C, E)) * s).astype(np.float32)
+    users = rng.integers(0, U, B).astype(np.int32)
+    items = rng.integers(0, I, B).astype(np.int32)
+    cats = rng.integers(0, 2, (B, C)).astype(np.float32)            # zero rows included: NaN scores
+    if weights:
+        cats *= rng.choice([0.25, 1.0, 3.0], size=cats.shape).astype(np.float32)
+    eng = ScoringEngine(PM, RE, CE)
+    dev = lambda a: torch.as_tensor(a, device="cuda")
+    got = eng.score_pairs(dev(users), dev(items), dev(cats)).cpu().numpy(); eng.check()
+    ref = oracle.inference_f64(PM, RE, CE, users, items, cats)
+    assert_scores_close(got, ref, what="C%d E%d B%d %s" % (C, E, B, eng.last_kernel()))
+    vec = C == 4 and E % 4 == 0 and E <= 256
+    assert eng.last_kernel() == ("m2d_score_pairs_c4_small" if vec else "m2d_score_pairs_generic")
+    host = eng.score_pairs_host(users, items, cats)                  # the host-buffer entry point, same bits
+    assert np.array_equal(host, got, equal_nan=True)
+    if vec:
+        eng.set_option("variant", 11)                                # the throughput form on the same batch
+        big = eng.score_pairs(dev(users), dev(items), dev(cats)).cpu().numpy(); eng.check()
+        assert eng.last_kernel() == "m2d_score_pairs_c4"
+        assert np.array_equal(big, got, equal_nan=True)
+    eng.close()
