@@ -55,3 +55,37 @@ def test_any_shape_matches_the_restatement(case):
         assert eng.last_kernel() == "m2d_score_pairs_c4"
         assert np.array_equal(big, got, equal_nan=True)
     eng.close()
+
+
+@st.composite
+def retrieval_cases(draw):
+    E = draw(st.sampled_from([32, 64, 128, 64, 128, 48, 200]))
+    U = draw(st.integers(1, 70))
+    I = draw(st.integers(1, 400))
+    k = draw(st.sampled_from([1, 3, 10, 16, 17, 40]))
+    n_users = draw(st.integers(1, min(U, 40)))
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    n_nan = draw(st.integers(0, min(I, 4)))
+    dup = draw(st.integers(0, I // 3))
+    x3 = draw(st.booleans())
+    splits = draw(st.sampled_from([0, 0, 102, 107, 164]))
+    return E, U, I, k, n_users, seed, n_nan, dup, x3, splits
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+@given(retrieval_cases())
+def test_retrieval_any_catalogue(case):
+    """m2d_topk_users on arbitrary catalogue sizes (fewer dishes than k, a single tile, ragged tails), with NaN dishes,
+    exactly tied dishes, forced dish-range splits and both arithmetic forms: the checks of test_gpu_catalogue._check."""
+    from foodrec_amd import ScoringEngine
+    from test_gpu_catalogue import _check, _tables
+    E, U, I, k, n_users, seed, n_nan, dup, x3, splits = case
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=seed, n_nan=n_nan, dup=dup)
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    eng.set_option("topk_bf16x3", int(x3))
+    if splits:
+        eng.set_option("variant", splits)
+    users = np.random.default_rng(seed).choice(U, n_users, replace=False)
+    _check(eng, PM, RE, CE, cats, users, k)
+    eng.close()
