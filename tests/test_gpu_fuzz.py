@@ -89,3 +89,39 @@ def test_retrieval_any_catalogue(case):
     users = np.random.default_rng(seed).choice(U, n_users, replace=False)
     _check(eng, PM, RE, CE, cats, users, k)
     eng.close()
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+@given(st.integers(0, 2 ** 31 - 1), st.integers(1, 40), st.integers(1, 70), st.sampled_from([1, 5, 10, 20]),
+       st.sampled_from([32, 64, 200]))
+def test_segment_ranking_any_candidates(seed, nseg, L, K, E):
+    """m2d_rank_candidates against the reference's dict + heapq.nlargest sequence (evaluate.py:53-63, restated in
+    oracle.rank_candidates) on candidate lists full of repeated dishes and exactly tied scores, ragged lengths."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    rng = np.random.default_rng(seed)
+    U, I, C = 30, 25, 4
+    s = 1.0 / np.sqrt(E)
+    PM = (rng.standard_normal((U, C + 1, E)) * s).astype(np.float32)
+    RE = (rng.standard_normal((I, E)) * s).astype(np.float32)
+    CE = (rng.standard_normal((C, E)) * s).astype(np.float32)
+    cats = rng.integers(0, 2, (I, C)).astype(np.float32)
+    cats[cats.sum(1) == 0, 0] = 1
+    RE[I - 6:] = RE[:6]; cats[I - 6:] = cats[:6]                       # six pairs of dishes with bit-equal scores
+    eng = ScoringEngine(PM, RE, CE); eng.set_dish_categories(cats)
+    users = rng.integers(0, U, nseg).astype(np.int32)
+    lens = rng.integers(1, L + 1, nseg).astype(np.int32)
+    items = rng.integers(0, I, (nseg, L)).astype(np.int32)              # 25 dishes in up to 70 slots: many repeats
+    dev = lambda a: torch.as_tensor(a, device="cuda")
+    sc, ids, flags = eng.rank_candidates(dev(users), dev(items), K, lens=dev(lens)); eng.check()
+    sc, ids, flags = sc.cpu().numpy(), ids.cpu().numpy(), flags.cpu().numpy()
+    assert not flags.any()                                              # no NaN dish in this catalogue
+    for r in range(nseg):
+        cand = items[r, :lens[r]]
+        scores = eng.score_pairs_bydish(dev(np.full(len(cand), users[r], np.int32)), dev(cand)).cpu().numpy()
+        want = oracle.rank_candidates(cand.tolist(), scores.tolist(), K)
+        got = [int(x) for x in ids[r] if x >= 0]
+        assert got == want, (r, got, want)
+        assert np.array_equal(sc[r, :len(want)], np.array([scores[np.where(cand == w)[0][-1]] for w in want], np.float32))
+    eng.close()
