@@ -125,3 +125,40 @@ def test_segment_ranking_any_candidates(seed, nseg, L, K, E):
         assert got == want, (r, got, want)
         assert np.array_equal(sc[r, :len(want)], np.array([scores[np.where(cand == w)[0][-1]] for w in want], np.float32))
     eng.close()
+
+
+@settings(max_examples=30, deadline=None, suppress_health_check=list(HealthCheck))
+@given(st.integers(0, 2 ** 31 - 1), st.sampled_from(["adam", "sgd", "adagrad", "rmsprop"]), st.integers(1, 6),
+       st.one_of(st.integers(1, 40).map(lambda x: 4 * x), st.integers(1, 90)), st.integers(1, 200))
+def test_training_step_any_shape(seed, learner, C, E, B):
+    """One m2d_train_step on arbitrary (C, E, B) -- row widths that are not multiples of 4, batches smaller than a
+    wave, every id repeated -- against the restatement (oracle/train_oracle.py, PARITY UNPINNED)."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import train_oracle as T
+    rng = np.random.default_rng(seed)
+    U, I = int(rng.integers(1, 30)), int(rng.integers(1, 30))
+    s = 3.0 / np.sqrt(E)
+    PM = (rng.standard_normal((U, C + 1, E)) * s).astype(np.float32)
+    RE = (rng.standard_normal((I, E)) * s).astype(np.float32)
+    CE = (rng.standard_normal((C, E)) * s).astype(np.float32)
+    users = rng.integers(0, U, B).astype(np.int32)
+    items = rng.integers(0, I, B).astype(np.int32)
+    cats = rng.integers(0, 2, (B, C)).astype(np.float32)
+    cats[cats.sum(1) == 0, 0] = 1.0
+    labels = rng.integers(0, 2, B).astype(np.float32)
+    lr = 0.01
+    eng = ScoringEngine(PM.copy(), RE.copy(), CE.copy())
+    eng.train_begin(learner, lr)
+    st_ = T.TrainState(PM, RE, CE, learner, lr)
+    ref_loss, ref_norm = st_.step(users, items, cats, labels)
+    dev = lambda a: torch.as_tensor(a, device="cuda")
+    out = eng.train_step(dev(users), dev(items), dev(cats), dev(labels)).cpu().numpy(); eng.check()
+    assert abs(out[0] - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    assert abs(out[1] - ref_norm) <= 1e-5 * max(1.0, ref_norm)
+    tol = 1e-3 * lr if learner in ("adam", "rmsprop") else None
+    for got, ref in ((eng.pm, st_.PM), (eng.re, st_.RE), (eng.ce, st_.CE)):
+        err = np.abs(got.cpu().numpy().astype(np.float64) - ref)
+        bound = tol if tol is not None else 1e-5 * np.maximum(1.0, np.abs(ref))
+        assert np.all(err <= bound), (learner, C, E, B, err.max())
+    eng.close()
