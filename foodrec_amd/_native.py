@@ -24,6 +24,9 @@ M2D_ERR_NO_DEVICE = -7
 M2D_ERR_BAD_INGREDIENT = -8
 M2D_TABLES_HOST = 0
 M2D_TABLES_DEVICE = 1
+M2D_WRITE_PERSONAL = 1
+M2D_WRITE_GENERAL = 2
+ABI_VERSION = 2
 
 _c = ctypes
 _vp = _c.c_void_p
@@ -52,7 +55,7 @@ SIGNATURES = {
     "m2d_clear_mlp_head": (_c.c_int, [_vp]),
     "m2d_score_pairs_mlp": (_c.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "m2d_write_memory": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _c.c_float, _c.c_float,
-                                    _c.c_float, _vp, _vp]),
+                                    _c.c_float, _i32, _vp, _vp]),
     "m2d_train_begin": (_c.c_int, [_vp, _i32, _c.c_float, _c.c_float, _vp]),
     "m2d_train_step": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "m2d_train_slot": (_c.c_int, [_vp, _i32, _i32, _vp, _i32, _vp]),

@@ -95,7 +95,7 @@ void release(m2d_engine *h)
 
 extern "C" {
 
-int m2d_abi_version(void) { return 1; }
+int m2d_abi_version(void) { return 2; }
 
 int m2d_create(const float *pm, const float *re, const float *ce, int64_t U, int64_t I, int32_t C, int32_t E,
                float coef, int device, int table_flags, m2d_engine **out)
@@ -309,8 +309,10 @@ int m2d_set_ingredients(m2d_engine *h, const float *ing, int64_t R, const int32_
         return fail(h, M2D_ERR_INVALID_ARG, "m2d_set_ingredients: bad argument");
     if (table_flags != M2D_TABLES_HOST && table_flags != M2D_TABLES_DEVICE)
         return fail(h, M2D_ERR_INVALID_ARG, "m2d_set_ingredients: bad table_flags");
-    int rc = m2d_clear_ingredients(h);
+    // an id error latched by an earlier launch is reported as what it is, before the CSR check can mislabel it
+    int rc = m2d_check(h, nullptr, nullptr, nullptr);
     if (rc != M2D_OK) return rc;
+    if ((rc = m2d_clear_ingredients(h)) != M2D_OK) return rc;
     M2D_HIP_TRY(h, hipSetDevice(h->device));
     if (table_flags == M2D_TABLES_DEVICE) {
         h->ing = ing; h->ing_off = off; h->ing_ids = ids; h->ing_w = w; h->own_ing = false;
@@ -369,15 +371,17 @@ int m2d_score_pairs_ingredients(m2d_engine *h, const int32_t *users, const int32
 
 int m2d_write_memory(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
                      const float *write_sign, const float *labels, int64_t B, int32_t L, float *general_memory,
-                     float beta_1, float beta_2, float alpha, double *out_sums, void *stream)
+                     float beta_1, float beta_2, float alpha, int32_t which, double *out_sums, void *stream)
 {
     if (!h) return M2D_ERR_INVALID_ARG;
     if (B < 0 || L <= 0) return fail(h, M2D_ERR_INVALID_ARG, "m2d_write_memory: need B >= 0 and L > 0");
+    if (which <= 0 || (which & ~(M2D_WRITE_PERSONAL | M2D_WRITE_GENERAL)))
+        return fail(h, M2D_ERR_INVALID_ARG, "m2d_write_memory: which must be M2D_WRITE_PERSONAL, M2D_WRITE_GENERAL or both");
     if (!general_memory || (B > 0 && (!users || !items || !cats || !write_sign || !labels)))
         return fail(h, M2D_ERR_INVALID_ARG, "m2d_write_memory: null buffer");
     M2D_HIP_TRY(h, hipSetDevice(h->device));
     return m2d_launch_write_memory(h, users, items, cats, write_sign, labels, B, L, general_memory, beta_1, beta_2,
-                                   alpha, out_sums, (hipStream_t)stream);
+                                   alpha, which, out_sums, (hipStream_t)stream);
 }
 
 int m2d_clear_mlp_head(m2d_engine *h)

@@ -122,7 +122,7 @@ int m2d_launch_check_csr(m2d_engine *h, hipStream_t stream);
 int m2d_ensure_dish_vectors(m2d_engine *h, hipStream_t stream);
 int m2d_launch_write_memory(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
                             const float *sign, const float *labels, int64_t B, int32_t L, float *gm, float beta_1,
-                            float beta_2, float alpha, double *out_sums, hipStream_t stream);
+                            float beta_2, float alpha, int32_t which, double *out_sums, hipStream_t stream);
 int m2d_train_setup(m2d_engine *h, int32_t learner, float lr, float clip_norm, hipStream_t stream);
 void m2d_train_release(m2d_engine *h);
 int m2d_launch_train_step(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats, const float *labels,

@@ -242,9 +242,17 @@ __global__ __launch_bounds__(256) void m2d_train_finalize(TrainArgs p)
     }
 }
 
+// Optimizer state that must move only when a step really applied: kept on the device and advanced by the step's last
+// kernel under the same `err[0] == 0` condition as the apply kernels, so a step refused for an out-of-range id leaves
+// the step count and Adam's beta powers where they were (TF raises before any assign, the beta-power assigns included).
+struct OptState {
+    float b1p, b2p;         // Adam's beta1_power / beta2_power variables: start at beta, times beta per applied step
+    int64_t steps;          // optimizer steps applied since m2d_train_begin
+};
+
 struct RuleArgs {
     int32_t rule;           // M2D_LEARNER_*
-    float lr;               // adam: lr sqrt(1 - b2^t) / (1 - b1^t)
+    float lr;               // args.lr; adam scales it by sqrt(1 - b2^t) / (1 - b1^t) from the device-side powers
     float b1, b2, eps;      // adam: betas, epsilon; rmsprop: b1 = decay, b2 = momentum, eps
 };
 
@@ -281,10 +289,11 @@ __device__ __forceinline__ void lane_set(float &v, int, float x) { v = x; }
 template <bool ALL, int VEC>
 __global__ __launch_bounds__(256) void m2d_train_apply(float *var, float *s0, float *s1, const float *G, const int32_t *map,
                                                        const int32_t *slot_row, const int32_t *count, int64_t R, int32_t W,
-                                                       const float *scal, RuleArgs r, const int32_t *err)
+                                                       const float *scal, RuleArgs r, const int32_t *err, const OptState *st)
 {
     typedef typename RowVec<VEC>::T vf;
     if (err[0] != 0) return;    // an id was out of range: like TF's InvalidArgumentError, the step applies nothing
+    if (r.rule == M2D_LEARNER_ADAM) r.lr = r.lr * sqrtf(1.0f - st->b2p) / (1.0f - st->b1p);   // AdamOptimizer._apply_dense
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -316,8 +325,14 @@ __global__ __launch_bounds__(256) void m2d_train_apply(float *var, float *s0, fl
     }
 }
 
-__global__ __launch_bounds__(256) void m2d_train_cleanup(int32_t *map, const int32_t *slot_row, const int32_t *count, float *G, int32_t W)
+__global__ __launch_bounds__(256) void m2d_train_cleanup(int32_t *map, const int32_t *slot_row, const int32_t *count, float *G, int32_t W,
+                                                         const int32_t *err, OptState *advance)
 {
+    if (advance && blockIdx.x == 0 && threadIdx.x == 0 && err[0] == 0) {     // the step applied: AdamOptimizer._finish
+        advance->b1p *= 0.9f;
+        advance->b2p *= 0.999f;
+        advance->steps += 1;
+    }
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t n = *count;
@@ -351,8 +366,7 @@ unsigned blocks_for(const m2d_engine *h, int64_t waves)
 struct m2d_train_state {
     int32_t learner = M2D_LEARNER_ADAM;
     float lr = 0.001f, clip = 5.0f;
-    int64_t steps = 0;
-    float b1p = 0.9f, b2p = 0.999f;     // Adam's beta1_power / beta2_power variables (start at beta, times beta per step)
+    OptState *opt = nullptr;            // device: step count and Adam's beta powers (see OptState)
     float *slot[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // [PM, RE, CE][slot]
     int32_t *map_u = nullptr, *map_d = nullptr, *slot_u = nullptr, *slot_d = nullptr, *cnt = nullptr;
     float *gu = nullptr, *gd = nullptr, *gce = nullptr, *scal = nullptr;
@@ -369,7 +383,7 @@ void m2d_train_release(m2d_engine *h)
         for (float *q : tb)
             if (q) (void)hipFree(q);
     for (void *q : {(void *)t->map_u, (void *)t->map_d, (void *)t->slot_u, (void *)t->slot_d, (void *)t->cnt, (void *)t->gu,
-                    (void *)t->gd, (void *)t->gce, (void *)t->scal, (void *)t->part_ce, (void *)t->part_acc})
+                    (void *)t->gd, (void *)t->gce, (void *)t->scal, (void *)t->part_ce, (void *)t->part_acc, (void *)t->opt})
         if (q) (void)hipFree(q);
     delete t;
     h->train = nullptr;
@@ -400,6 +414,10 @@ int m2d_train_setup(m2d_engine *h, int32_t learner, float lr, float clip_norm, h
     M2D_HIP_TRY(h, hipMalloc((void **)&t->part_ce, (size_t)h->num_cu * 8 * n[2] * 4));
     M2D_HIP_TRY(h, hipMalloc((void **)&t->part_acc, (size_t)h->num_cu * 8 * 2 * 8));
     M2D_HIP_TRY(h, hipMemsetAsync(t->scal, 0, 16, stream));
+    M2D_HIP_TRY(h, hipMalloc((void **)&t->opt, sizeof(OptState)));
+    const OptState st0 = {0.9f, 0.999f, 0};
+    M2D_HIP_TRY(h, hipMemcpyAsync(t->opt, &st0, sizeof st0, hipMemcpyHostToDevice, stream));
+    M2D_HIP_TRY(h, hipStreamSynchronize(stream));      // st0 is on this frame
     M2D_HIP_TRY(h, hipGetLastError());
     return M2D_OK;
 }
@@ -456,7 +474,6 @@ int m2d_launch_train_step(m2d_engine *h, const int32_t *users, const int32_t *it
     r.rule = t->learner; r.lr = t->lr; r.b1 = r.b2 = r.eps = 0.f;
     if (t->learner == M2D_LEARNER_ADAM) {
         r.b1 = 0.9f; r.b2 = 0.999f; r.eps = 1e-8f;
-        r.lr = t->lr * sqrtf(1.0f - t->b2p) / (1.0f - t->b1p);
     } else if (t->learner == M2D_LEARNER_RMSPROP) {
         r.b1 = 0.9f; r.b2 = 0.0f; r.eps = 1e-10f;
     }
@@ -472,17 +489,17 @@ int m2d_launch_train_step(m2d_engine *h, const int32_t *users, const int32_t *it
         const bool v4 = tb.W % 4 == 0;
 #define M2D_APPLY(ALL, VEC)                                                                                               \
     hipLaunchKernelGGL((m2d_train_apply<ALL, VEC>), dim3(grid), dim3(256), 0, stream, tb.var, s0, s1, tb.G, tb.map, tb.slot_row, \
-                       tb.count, tb.R, tb.W, t->scal, r, h->err_dev)
+                       tb.count, tb.R, tb.W, t->scal, r, h->err_dev, t->opt)
         if (all) { if (v4) M2D_APPLY(true, 4); else M2D_APPLY(true, 1); }
         else { if (v4) M2D_APPLY(false, 4); else M2D_APPLY(false, 1); }
 #undef M2D_APPLY
         M2D_HIP_TRY(h, hipGetLastError());
     }
-    hipLaunchKernelGGL(m2d_train_cleanup, dim3(blocks_for(h, B)), dim3(256), 0, stream, t->map_u, t->slot_u, t->cnt + 0, t->gu, W);
-    hipLaunchKernelGGL(m2d_train_cleanup, dim3(blocks_for(h, B)), dim3(256), 0, stream, t->map_d, t->slot_d, t->cnt + 1, t->gd, E);
+    hipLaunchKernelGGL(m2d_train_cleanup, dim3(blocks_for(h, B)), dim3(256), 0, stream, t->map_u, t->slot_u, t->cnt + 0, t->gu, W,
+                       h->err_dev, (OptState *)nullptr);
+    hipLaunchKernelGGL(m2d_train_cleanup, dim3(blocks_for(h, B)), dim3(256), 0, stream, t->map_d, t->slot_d, t->cnt + 1, t->gd, E,
+                       h->err_dev, t->opt);               // also advances the step count / beta powers if the step applied
     M2D_HIP_TRY(h, hipGetLastError());
-    if (t->learner == M2D_LEARNER_ADAM) { t->b1p *= 0.9f; t->b2p *= 0.999f; }      // AdamOptimizer._finish
-    t->steps += 1;
     // everything derived from Recipe_Embedding / Category_Embedding is stale now
     h->dish_vec_valid = false;
     h->grp_valid = false;
@@ -494,12 +511,16 @@ int m2d_launch_train_step(m2d_engine *h, const int32_t *users, const int32_t *it
 int m2d_train_step_count(m2d_engine *h, int64_t *steps, int32_t set)
 {
     m2d_train_state *t = h->train;
+    M2D_HIP_TRY(h, hipSetDevice(h->device));
+    M2D_HIP_TRY(h, hipDeviceSynchronize());            // the count lives on the device; steps in flight finish first
+    OptState st = {0.9f, 0.999f, 0};
     if (set) {
-        t->steps = *steps;
-        t->b1p = 0.9f; t->b2p = 0.999f;
-        for (int64_t i = 0; i < t->steps; ++i) { t->b1p *= 0.9f; t->b2p *= 0.999f; }
+        st.steps = *steps;
+        for (int64_t i = 0; i < st.steps; ++i) { st.b1p *= 0.9f; st.b2p *= 0.999f; }
+        M2D_HIP_TRY(h, hipMemcpy(t->opt, &st, sizeof st, hipMemcpyHostToDevice));
     } else {
-        *steps = t->steps;
+        M2D_HIP_TRY(h, hipMemcpy(&st, t->opt, sizeof st, hipMemcpyDeviceToHost));
+        *steps = st.steps;
     }
     return M2D_OK;
 }

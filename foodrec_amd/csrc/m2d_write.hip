@@ -46,7 +46,8 @@ __device__ __forceinline__ void latch(int32_t *err, int code, int64_t value, int
     }
 }
 
-// PASS 0: PM[u_b] += v_b + alpha g_b.   PASS 1: GM[l] += y_bl v_b.
+// PASS 0: PM[u_b] += v_b + alpha g_b.   PASS 1: GM[l] += y_bl v_b (after pass 0, which latched any id error).
+// PASS 2: the GM pass on its own (the `general`-only fetch): latches id errors itself.
 template <int PASS>
 __global__ __launch_bounds__(256) void m2d_write_memory_kernel(WriteArgs p)
 {
@@ -58,11 +59,11 @@ __global__ __launch_bounds__(256) void m2d_write_memory_kernel(WriteArgs p)
         const int32_t uid = p.users[b], did = p.items[b];
         const int64_t ul = (int64_t)uid - p.user_base;
         if (ul < 0 || ul >= p.U) {
-            if (PASS == 0 && lane == 0) latch(p.err, M2D_ERR_BAD_USER_ID, uid, b);
+            if (PASS != 1 && lane == 0) latch(p.err, M2D_ERR_BAD_USER_ID, uid, b);
             continue;   // wave-uniform: nothing is written for a bad pair
         }
         if (did < 0 || (int64_t)did >= p.I) {
-            if (PASS == 0 && lane == 0) latch(p.err, M2D_ERR_BAD_ITEM_ID, did, b);
+            if (PASS != 1 && lane == 0) latch(p.err, M2D_ERR_BAD_ITEM_ID, did, b);
             continue;
         }
         const float s = p.sign[b];
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void m2d_sum_kernel(const float *x, int64_t n,
 
 int m2d_launch_write_memory(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
                             const float *sign, const float *labels, int64_t B, int32_t L, float *gm, float beta_1,
-                            float beta_2, float alpha, double *out_sums, hipStream_t stream)
+                            float beta_2, float alpha, int32_t which, double *out_sums, hipStream_t stream)
 {
     WriteArgs a;
     a.pm = const_cast<float *>(h->pm); a.re = h->re; a.ce = h->ce; a.gm = gm;
@@ -127,17 +128,28 @@ int m2d_launch_write_memory(m2d_engine *h, const int32_t *users, const int32_t *
     if (B > 0) {
         int64_t blocks = (B + 3) / 4;
         if (blocks > (int64_t)h->num_cu * 8) blocks = (int64_t)h->num_cu * 8;
-        hipLaunchKernelGGL(m2d_write_memory_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-        M2D_HIP_TRY(h, hipGetLastError());
-        hipLaunchKernelGGL(m2d_write_memory_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
-        M2D_HIP_TRY(h, hipGetLastError());
+        // each pass runs only when its assign is fetched (`personal` -> :167/:198, `general` -> :215); a GM-only call
+        // still validates the ids (the gathers at :107 / one_hot at :149 are shared by both branches)
+        if (which & M2D_WRITE_PERSONAL) {
+            hipLaunchKernelGGL(m2d_write_memory_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+            M2D_HIP_TRY(h, hipGetLastError());
+        }
+        if (which & M2D_WRITE_GENERAL) {
+            if (which & M2D_WRITE_PERSONAL)
+                hipLaunchKernelGGL(m2d_write_memory_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+            else
+                hipLaunchKernelGGL(m2d_write_memory_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+            M2D_HIP_TRY(h, hipGetLastError());
+        }
     }
     if (out_sums) {
         M2D_HIP_TRY(h, hipMemsetAsync(out_sums, 0, 2 * sizeof(double), stream));
-        hipLaunchKernelGGL(m2d_sum_kernel, dim3((unsigned)(h->num_cu * 4)), dim3(256), 0, stream, h->pm,
-                           (int64_t)h->U * (h->C + 1) * h->E, out_sums);
-        hipLaunchKernelGGL(m2d_sum_kernel, dim3(64), dim3(256), 0, stream, gm, (int64_t)L * (h->C + 1) * h->E,
-                           out_sums + 1);
+        if (which & M2D_WRITE_PERSONAL)
+            hipLaunchKernelGGL(m2d_sum_kernel, dim3((unsigned)(h->num_cu * 4)), dim3(256), 0, stream, h->pm,
+                               (int64_t)h->U * (h->C + 1) * h->E, out_sums);
+        if (which & M2D_WRITE_GENERAL)
+            hipLaunchKernelGGL(m2d_sum_kernel, dim3(64), dim3(256), 0, stream, gm, (int64_t)L * (h->C + 1) * h->E,
+                               out_sums + 1);
         M2D_HIP_TRY(h, hipGetLastError());
     }
     return M2D_OK;

@@ -151,9 +151,13 @@ class ScoringEngine:
 
     def write_memory(self, users: torch.Tensor, items: torch.Tensor, cats: torch.Tensor, write_sign: torch.Tensor,
                      labels: torch.Tensor, general_memory: torch.Tensor, beta_1: float, beta_2: float, alpha: float,
-                     want_means: bool = False):
-        """Model.Write_Memory (Model_Recommender.py:106-220) as a scatter-add: updates self.pm and
-        `general_memory` ([L, C+1, E], device float32) IN PLACE.  Returns (mean(PM), mean(GM)) when asked."""
+                     want_means: bool = False, write_pm: bool = True, write_gm: bool = True):
+        """Model.Write_Memory (Model_Recommender.py:106-220) as a scatter-add: updates self.pm (`write_pm`: the two
+        chained Personal_Memory assigns the `personal` fetch depends on, :167 / :198) and `general_memory`
+        ([L, C+1, E], device float32; `write_gm`: the assign the `general` fetch depends on, :215) IN PLACE.
+        Returns (mean(PM), mean(GM)) when asked; the mean of a table that was not written is None."""
+        if not (write_pm or write_gm):
+            raise ValueError("write_memory: nothing to write")
         self._check_ids(users, items)
         B = users.numel()
         L = labels.shape[-1]
@@ -168,12 +172,15 @@ class ScoringEngine:
             rc = _native.lib().m2d_write_memory(self._h, users.contiguous().data_ptr(), items.contiguous().data_ptr(),
                                                 cats.data_ptr(), write_sign.data_ptr(), labels.data_ptr(), B, L,
                                                 general_memory.data_ptr(), float(beta_1), float(beta_2), float(alpha),
+                                                (_native.M2D_WRITE_PERSONAL if write_pm else 0) |
+                                                (_native.M2D_WRITE_GENERAL if write_gm else 0),
                                                 sums.data_ptr() if want_means else None, _stream_ptr())
         _native.raise_for(rc, self._h)
         if want_means:
             self.check()
             s = sums.cpu().numpy()
-            return float(s[0] / self.pm.numel()), float(s[1] / general_memory.numel())
+            return (float(s[0] / self.pm.numel()) if write_pm else None,
+                    float(s[1] / general_memory.numel()) if write_gm else None)
         return None
 
     # -- training step ----------------------------------------------------------

@@ -187,9 +187,12 @@ class Model:
         loss, _norm, _scale, lr = (float(v) for v in out.cpu().numpy())
         return loss, lr
 
-    def write_memory(self, user_input, item_input, categories, write_sign, user_one_hot_label):
-        """The ``personal`` / ``general`` fetches (``Write_Memory``, Model_Recommender.py:106-220): updates
-        Personal_Memory and General_Memory in place, returns ``(mean(Personal_Memory), mean(General_Memory))``."""
+    def write_memory(self, user_input, item_input, categories, write_sign, user_one_hot_label,
+                     personal: bool = True, general: bool = True):
+        """The ``personal`` / ``general`` fetches (``Write_Memory``, Model_Recommender.py:106-220).  As in the reference
+        graph each fetch pulls in only the assigns it depends on: ``personal`` the two chained Personal_Memory assigns
+        (:167, :198), ``general`` the General_Memory assign (:215).  Updates those tables in place and returns
+        ``(mean(Personal_Memory), mean(General_Memory))`` with ``None`` for a table that was not fetched."""
         if self._gm_dev is None:
             if self.General_Memory is None:
                 raise ValueError("Model was built without General_Memory")
@@ -199,7 +202,7 @@ class Model:
         sign = torch.as_tensor(np.asarray(write_sign, dtype=np.float32)).reshape(B)
         y = torch.as_tensor(np.asarray(user_one_hot_label, dtype=np.float32)).reshape(B, -1)
         return self.engine.write_memory(ut, dt, mt, sign, y, self._gm_dev, float(self.beta_1), float(self.beta_2),
-                                        float(self.alpha), want_means=True)
+                                        float(self.alpha), want_means=True, write_pm=personal, write_gm=general)
 
     # -- checkpoint (stands where the driver uses tf.train.Saver, Train_recommender.py:145-149, :218-222) ----------
     _TABLE_FILES = ("Personal_Memory", "Recipe_Embedding", "Category_Embedding", "General_Memory")
@@ -324,7 +327,8 @@ class Session:
 
         The reference fetches the memory write and ``train_op`` in one ``sess.run`` with no control dependency
         between them, so TF may order them either way; here the optimizer step runs first and ``Write_Memory``
-        sees the updated tables."""
+        sees the updated tables.  ``general`` alone (the driver's ordinary batch, Train_recommender.py:195-199) writes
+        General_Memory only; Personal_Memory is written only when ``personal`` is fetched (:180-184)."""
         as_list = isinstance(fetches, (list, tuple))
         fl: Sequence = fetches if as_list else [fetches]
         m = self.model
@@ -354,9 +358,10 @@ class Session:
         if has(m.personal) or has(m.general):
             pmean, gmean = m.write_memory(feed(m.user_input, m.user_input), feed(m.item_input, m.item_input),
                                           feed(m.categories, m.categories), feed(m.write_sign, m.write_sign),
-                                          feed(m.user_one_hot_label, m.user_one_hot_label))
-            res[id(m.personal)] = np.float32(pmean)
-            res[id(m.general)] = np.float32(gmean)
+                                          feed(m.user_one_hot_label, m.user_one_hot_label),
+                                          personal=has(m.personal), general=has(m.general))
+            res[id(m.personal)] = None if pmean is None else np.float32(pmean)
+            res[id(m.general)] = None if gmean is None else np.float32(gmean)
         out = []
         for f in fl:
             if f is m.learning_rate:

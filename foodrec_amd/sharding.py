@@ -8,16 +8,28 @@ by independent units:
   gather bytes and is the only table too large to replicate);
 * ``Recipe_Embedding``, ``Category_Embedding`` and the dish masks are replicated;
 * one process per GPU, ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI; ``gloo`` in the CPU
-  tests).  Pair scoring needs no data-path collective beyond returning ``f32[B]``; retrieval
-  all-gathers each shard's *final* per-user top-k (dishes are replicated, so no merge is needed).
+  tests).
 
-The scorer is any object with ``score_pairs(users, items, cats)`` and ``topk_users(users, k)`` working on
-tensors of its own device -- in production a ``foodrec_amd.ScoringEngine`` created with
-``user_base=base``.
+Pair scoring routes every pair to the rank that owns its user (``user // users_per_shard``): pairs are
+bucketed by owner with one stable sort, only the owner gathers and scores them, and the only traffic is
+ids in / ``f32`` scores out --
+
+* ``score_pairs``        every rank holds the SAME batch (a replicated request): each rank scores its own
+                         bucket and one ``all_gather`` of the per-rank score pieces rebuilds ``f32[B]``;
+* ``score_pairs_routed`` every rank holds its OWN batch (the serving shape): one ``all_to_all`` carries
+                         ``(user, dish, mask)`` records to their owners, one carries the scores back.
+
+Neither masks the full batch on every rank, and the only host round trip per call is the bucket-size vector
+(``world`` integers) that sizes the launch and the collective.  Retrieval all-gathers each shard's *final*
+per-user top-k (dishes are replicated, so no merge is needed).
+
+The scorer is any object with ``score_pairs(users, items, cats)``, ``topk_users(users, k)`` and ``check()``
+working on tensors of its own device -- in production a ``foodrec_amd.ScoringEngine`` created with
+``user_base=base`` (``None`` on a rank whose shard is empty).
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -38,35 +50,119 @@ class UserShardedScorer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.num_users_total = int(num_users_total)
+        if self.num_users_total < 1:
+            raise ValueError("num_users_total must be positive")
         self.base, self.count = shard_range(self.num_users_total, self.world, self.rank)
         self.per = -(-self.num_users_total // self.world)
         self.device = torch.device(device) if device is not None else getattr(scorer, "device", torch.device("cpu"))
+        if self.count > 0 and scorer is None:
+            raise ValueError("rank %d owns users [%d, %d) and needs a scorer" % (self.rank, self.base, self.base + self.count))
+        self._bad_local = False        # an id no shard owns was seen by this rank's routing (reported by check())
 
     # -- routing ------------------------------------------------------------------------------------
     def owner_of(self, users: torch.Tensor) -> torch.Tensor:
-        return torch.div(users.to(torch.int64), self.per, rounding_mode="floor")
-
-    def local_mask(self, users: torch.Tensor) -> torch.Tensor:
+        """Owning rank of each user id (int64).  An id outside ``[0, num_users_total)`` has no owner: it is sent to
+        rank 0, whose engine refuses it (the id error is latched there and raised by ``check()`` on every rank)."""
         u = users.to(torch.int64)
-        return (u >= self.base) & (u < self.base + self.count)
+        own = torch.div(u, self.per, rounding_mode="floor")
+        return torch.where((u < 0) | (u >= self.num_users_total), torch.zeros_like(own), own)
+
+    def _bucket(self, users: torch.Tensor):
+        """Stable bucketing by owner: ``order`` (positions grouped by owner, original order kept inside a bucket),
+        ``owner[order]`` and the bucket sizes ``int64[world]`` -- all on the device, no synchronisation."""
+        owner = self.owner_of(users)
+        owner_sorted, order = torch.sort(owner, stable=True)
+        counts = torch.bincount(owner, minlength=self.world)
+        return order, owner_sorted, counts
+
+    def _score_local(self, users, items, cats) -> torch.Tensor:
+        if users.numel() == 0:
+            return torch.empty(0, dtype=torch.float32, device=self.device)
+        if self.scorer is None:                     # empty shard: only ownerless ids can land here (rank 0 never is empty)
+            return torch.full((users.numel(),), float("nan"), dtype=torch.float32, device=self.device)
+        return self.scorer.score_pairs(users.contiguous(), items.contiguous(), cats.contiguous())
 
     # -- pair scoring ---------------------------------------------------------------------------------
-    def score_pairs(self, users: torch.Tensor, items: torch.Tensor, cats: torch.Tensor) -> torch.Tensor:
-        """Every rank passes the SAME batch (global user ids); every rank gets all B scores back.
-        Each pair is scored by the one rank that owns its user; the pieces are combined by a sum
-        all-reduce over a zero-filled vector (each slot is written by exactly one rank)."""
+    def score_pairs(self, users: torch.Tensor, items: torch.Tensor, cats: torch.Tensor, check: bool = True) -> torch.Tensor:
+        """Every rank passes the SAME batch (global user ids) and gets all B scores back.  Each rank scores only the
+        pairs whose user it owns; the per-rank pieces, padded to the largest bucket, travel in one all-gather."""
         B = users.numel()
-        if users.numel() and (int(users.min()) < 0 or int(users.max()) >= self.num_users_total):
-            raise IndexError("user id out of range [0, %d)" % self.num_users_total)
-        mask = self.local_mask(users)
-        out = torch.zeros(B, dtype=torch.float32, device=self.device)
-        if bool(mask.any()):
-            idx = mask.nonzero(as_tuple=True)[0]
-            out[idx] = self.scorer.score_pairs(users[idx].contiguous(), items[idx].contiguous(),
-                                               cats[idx].contiguous())
-        if self.world > 1:
-            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
+        C = cats.numel() // max(B, 1)
+        out = torch.empty(B, dtype=torch.float32, device=self.device)
+        if B == 0:
+            return out
+        order, owner_sorted, counts = self._bucket(users)
+        counts_h: List[int] = counts.tolist()                         # the one host round trip: sizes the launch
+        off_h = [0]
+        for c in counts_h:
+            off_h.append(off_h[-1] + c)
+        lo, n = off_h[self.rank], counts_h[self.rank]
+        idx = order[lo:lo + n]
+        local = self._score_local(users[idx], items[idx], cats.reshape(B, C)[idx])
+        if self.world == 1:
+            out[idx] = local
+        else:
+            cmax = max(counts_h)
+            piece = torch.zeros(cmax, dtype=torch.float32, device=self.device)
+            piece[:n] = local
+            gathered = torch.empty(self.world * cmax, dtype=torch.float32, device=self.device)
+            dist.all_gather_into_tensor(gathered, piece, group=self.group)
+            # sorted position p of bucket r sits at gathered[r * cmax + (p - off[r])]
+            off = torch.cumsum(counts, 0) - counts
+            sel = owner_sorted * cmax + (torch.arange(B, device=self.device) - off[owner_sorted])
+            out[order] = gathered[sel]
+        if check:
+            self.check()
         return out
+
+    def score_pairs_routed(self, users: torch.Tensor, items: torch.Tensor, cats: torch.Tensor,
+                           check: bool = True) -> torch.Tensor:
+        """Every rank passes its OWN batch (global user ids, any owners) and gets its own scores back: one all-to-all
+        of ``[user, dish, mask bits]`` int32 records to the owners, the owners score, one all-to-all of ``f32`` back."""
+        B = users.numel()
+        C = cats.shape[-1] if cats.dim() > 1 else (cats.numel() // max(B, 1))
+        if self.world == 1:
+            out = self._score_local(users, items, cats.reshape(B, C))
+            if check:
+                self.check()
+            return out
+        order, _, send_counts = self._bucket(users)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+        sc: List[int] = send_counts.tolist()                          # the one host round trip (two small vectors)
+        rc: List[int] = recv_counts.tolist()
+        rec = torch.empty((B, 2 + C), dtype=torch.int32, device=self.device)
+        rec[:, 0] = users[order]
+        rec[:, 1] = items[order]
+        rec[:, 2:] = cats.reshape(B, C).to(torch.float32)[order].view(torch.int32)
+        got = torch.empty((sum(rc), 2 + C), dtype=torch.int32, device=self.device)
+        dist.all_to_all_single(got, rec, rc, sc, group=self.group)
+        scores = self._score_local(got[:, 0].contiguous(), got[:, 1].contiguous(),
+                                   got[:, 2:].contiguous().view(torch.float32))
+        back = torch.empty(B, dtype=torch.float32, device=self.device)
+        dist.all_to_all_single(back, scores, sc, rc, group=self.group)
+        out = torch.empty(B, dtype=torch.float32, device=self.device)
+        out[order] = back
+        if check:
+            self.check()
+        return out
+
+    def check(self):
+        """Collective: synchronise, and raise ``IndexError`` on EVERY rank when any rank's engine latched an
+        out-of-range id (TF-CPU's GatherV2 would have raised for the whole call)."""
+        msg = ""
+        if self.scorer is not None and hasattr(self.scorer, "check"):
+            try:
+                self.scorer.check()
+            except IndexError as e:
+                msg = str(e) or "id out of range"
+        if self.world > 1:
+            flag = torch.tensor([1 if msg else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            if int(flag.item()) and not msg:
+                msg = "an id was out of range on another rank"
+        if msg:
+            raise IndexError(msg)
 
     # -- retrieval ------------------------------------------------------------------------------------
     def topk_local(self, k: int, users: Optional[torch.Tensor] = None):
@@ -79,17 +175,18 @@ class UserShardedScorer:
         return self.scorer.topk_users(users, k)
 
     def topk_all_users(self, k: int):
-        """Per-user top-k for EVERY user, on every rank: one all-gather of ``[shard, k] x (f32, i32)``.
-        Shards are padded to the common size ``per`` for the collective and trimmed afterwards."""
+        """Per-user top-k for EVERY user, on every rank: one all-gather of ``[shard, k] x (f32, i32)`` (scores and
+        ids travel in one buffer).  Shards are padded to the common size ``per`` for the collective and trimmed."""
         s, ids = self.topk_local(k)
         if self.world == 1:
             return s, ids
-        ps = torch.full((self.per, k), float("nan"), dtype=torch.float32, device=self.device)
-        pi = torch.full((self.per, k), -1, dtype=torch.int32, device=self.device)
-        ps[: self.count] = s
-        pi[: self.count] = ids
-        gs = torch.empty((self.world * self.per, k), dtype=torch.float32, device=self.device)
-        gi = torch.empty((self.world * self.per, k), dtype=torch.int32, device=self.device)
-        dist.all_gather_into_tensor(gs, ps, group=self.group)
-        dist.all_gather_into_tensor(gi, pi, group=self.group)
+        piece = torch.empty((2, self.per, k), dtype=torch.int32, device=self.device)
+        piece[0].view(torch.float32).fill_(float("nan"))
+        piece[1].fill_(-1)
+        piece[0, : self.count] = s.view(torch.int32)
+        piece[1, : self.count] = ids
+        gathered = torch.empty((self.world, 2, self.per, k), dtype=torch.int32, device=self.device)
+        dist.all_gather_into_tensor(gathered, piece, group=self.group)
+        gs = gathered[:, 0].reshape(self.world * self.per, k).view(torch.float32)
+        gi = gathered[:, 1].reshape(self.world * self.per, k)
         return gs[: self.num_users_total], gi[: self.num_users_total]

@@ -110,11 +110,19 @@ int m2d_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
  *   users/items i32[B], cats f32[B, C], write_sign f32[B] (the [B, 1] placeholder flattened),
  *   labels f32[B, L] (user_one_hot_label), general_memory f32[L, C+1, E] (device, updated in place).
  * Personal_Memory is updated IN PLACE in the buffer given to m2d_create, which must therefore be
- * writable device memory (M2D_TABLES_DEVICE) or engine-owned (M2D_TABLES_HOST).  out_sums (device
- * f64[2], may be NULL) receives sum(PM) and sum(GM) after the write (the reference returns their means). */
+ * writable device memory (M2D_TABLES_DEVICE) or engine-owned (M2D_TABLES_HOST).
+ * `which` selects the assigns that run, as the fetch list does in the reference graph: `personal` depends on the two
+ * chained Personal_Memory assigns only (:167, :198), `general` on the General_Memory assign only (:215) -- the
+ * driver's ordinary batch fetches `general` alone (Train_recommender.py:195-199), so it never writes Personal_Memory.
+ *   M2D_WRITE_PERSONAL  PM[u_b] += v_b + alpha * g_b      (g_b reads General_Memory as it stands before this call)
+ *   M2D_WRITE_GENERAL   GM[l]   += sum_b y_bl v_b
+ * out_sums (device f64[2], may be NULL) receives sum(PM) in [0] when M2D_WRITE_PERSONAL is set and sum(GM) in [1]
+ * when M2D_WRITE_GENERAL is set, after the write (the reference returns their means); the other entry is 0. */
+#define M2D_WRITE_PERSONAL 1
+#define M2D_WRITE_GENERAL 2
 int m2d_write_memory(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
                      const float *write_sign, const float *labels, int64_t B, int32_t L, float *general_memory,
-                     float beta_1, float beta_2, float alpha, double *out_sums, void *stream);
+                     float beta_1, float beta_2, float alpha, int32_t which, double *out_sums, void *stream);
 
 /* Training step.  Replaces Model.loss + Model.train (Model_Recommender.py:99-104,
  * :223-241) as the driver runs them: sess.run([model.loss_value, model.learning_rate, ..., model.train_op], feed_dict)
@@ -127,6 +135,10 @@ int m2d_write_memory(m2d_engine *h, const int32_t *users, const int32_t *items, 
  *   m2d_train_step   users/items i32[B], cats f32[B, C], labels f32[B].  apply = 1: loss, gradients, global-norm
  *                    clip and the update; apply = 0: loss and gradient norm only (the loss_value fetch alone).
  *                    out (device f32[4], may be NULL) receives {loss, global gradient norm, clip scale, lr}.
+ *                    An out-of-range id blocks the whole update (TF raises from the gather before any assign): the
+ *                    tables, the slots, the step count and Adam's beta powers all stay as they were.  The id error
+ *                    stays latched until m2d_check reports it, and while it is latched every later step is blocked
+ *                    too -- call m2d_check after a step whose ids are not known to be valid.
  *   m2d_train_slot   copies optimizer slot `slot` of table 0 = Personal_Memory, 1 = Recipe_Embedding,
  *                    2 = Category_Embedding (adam: m, v; adagrad: accumulator; rmsprop: rms, momentum) into `buf`
  *                    (restore = 0) or from it (restore = 1); `buf` is device memory shaped like the table.  For
@@ -160,7 +172,8 @@ int m2d_train_end(m2d_engine *h);
  * With ING = Category_Embedding, ids = 0..C-1 and w = the dish's category mask this is the reference's
  * formula.  ing f32[R, E]; off i32[I+1] (CSR, off[0] = 0); ids i32[nnz]; w f32[nnz] or NULL (all 1).
  * The call gathers and segment-sums the rows into H once (it synchronises and reports a malformed CSR /
- * bad id as M2D_ERR_BAD_INGREDIENT); all four arrays use `table_flags`.  A dish with an empty list
+ * bad id as M2D_ERR_BAD_INGREDIENT; an id error still latched from an earlier launch is returned first, under its own
+ * code, exactly as m2d_check would); all four arrays use `table_flags`.  A dish with an empty list
  * scores NaN, like an empty category mask. */
 int m2d_set_ingredients(m2d_engine *h, const float *ing, int64_t R, const int32_t *off, const int32_t *ids,
                         const float *w, int64_t nnz, int table_flags);

@@ -157,8 +157,12 @@ def inference_factored(PM, RE, CE, users, items, dish_categories, coef: float = 
 # ----------------------------------------------------------------------------------------------
 
 def write_memory(PM, RE, CE, GM, users, items, categories, write_sign, user_one_hot_label,
-                 beta_1=0.01, beta_2=0.01, alpha=0.01, dtype=np.float64):
-    """Returns (Personal_Memory', General_Memory', mean(PM'), mean(GM'))."""
+                 beta_1=0.01, beta_2=0.01, alpha=0.01, dtype=np.float64, personal=True, general=True):
+    """Returns (Personal_Memory', General_Memory', mean(PM'), mean(GM')).
+
+    `personal` / `general` say which of the two fetches is in the sess.run list: TF executes only the assigns a fetch
+    depends on -- `personal` = reduce_mean of the second Personal_Memory assign (:198, chained on :167), `general` =
+    reduce_mean of the General_Memory assign (:215).  A table whose fetch is absent comes back unchanged."""
     PM = np.asarray(PM, dtype=dtype); RE = np.asarray(RE, dtype=dtype); CE = np.asarray(CE, dtype=dtype)
     GM = np.asarray(GM, dtype=dtype)
     U, C1, E = PM.shape
@@ -190,6 +194,10 @@ def write_memory(PM, RE, CE, GM, users, items, categories, write_sign, user_one_
         dgb = (ylab @ dish_memory).sum(axis=0).reshape(-1, C, E)                  # :200-205
         cgb = (ylab @ dish_category).sum(axis=0)[:, None, :]                      # :207-212
         GM2 = GM + np.concatenate([cgb, dgb], axis=1)                             # :213-215
+    if not personal:
+        PM2 = PM
+    if not general:
+        GM2 = GM
     return PM2, GM2, PM2.mean(), GM2.mean()
 
 

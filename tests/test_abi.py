@@ -25,7 +25,7 @@ def test_header_symbols_exported(native_lib):
     for s in syms:
         assert hasattr(native_lib, s), "libm2d.so does not export %s" % s
     assert sorted(_native.SIGNATURES) == syms, "ctypes table and include/m2d.h disagree"
-    assert native_lib.m2d_abi_version() == 1
+    assert native_lib.m2d_abi_version() == 2
 
 
 def test_no_cpu_fallback(native_lib):

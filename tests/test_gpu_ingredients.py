@@ -109,3 +109,32 @@ def test_ingredient_errors_and_topk():
         ref = oracle.inference_ingredients(PM, RE, ING, off, ids, None, np.full(I, u), np.arange(I), dish_cats)
         assert_scores_close(s[u], ref[idx[u]])
         assert np.sort(ref)[-10] <= s[u].min() + 1e-4
+
+
+def test_abort_shape_from_round_1_repeated_in_one_process():
+    """Round 1 recorded one process abort inside m2d_set_ingredients (gpurun_out/pytest_ing.log: E = 200, unweighted,
+    empty dishes 7 and 149, reached after four other engines had been built and destroyed in the same process; the
+    kernel source of that run predates the first commit of m2d_ingredients.hip -- DESIGN.md 8.1).  This pins that
+    exact sequence on the shipped kernel: engines of E = 6 / 32 / 64 / 128 built, used and destroyed first, then the
+    E = 200 table set twice on one engine (second call replaces the first table), H checked row by row."""
+    import gc
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    U, I, R = 200, 150, 300
+    for E in (6, 32, 64, 128, 200):
+        PM, RE, CE, users, items, cats = random_case(U, I, 4, E, 500, seed=E, zero_rows=False)
+        rng = np.random.default_rng(E + 1)
+        ING = (rng.standard_normal((R, E)) / np.sqrt(E)).astype(np.float32)
+        off, ids = _csr(I, R, rng, empty=(7, 149))
+        eng = ScoringEngine(PM, RE, CE)
+        for _ in range(2 if E == 200 else 1):
+            eng.set_ingredients(ING, off, ids, None)
+        ut, it = torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda")
+        got = eng.score_pairs_ingredients(ut, it, torch.as_tensor(cats, device="cuda")).cpu().numpy()
+        eng.check()
+        ref = oracle.inference_ingredients(PM, RE, ING, off, ids, None, users, items, cats)
+        assert np.isnan(ref[(items == 7) | (items == 149)]).all()
+        assert_scores_close(got, ref, what="E%d" % E)
+        del eng
+        gc.collect()

@@ -38,7 +38,7 @@ def test_native_library_is_what_runs(torch_cuda):
     import foodrec_amd
     maps = open("/proc/self/maps").read()
     assert "libm2d.so" in maps
-    assert "libm2d_oracle" not in maps or True     # the oracle may be loaded by the TEST, never by the package
+
 
 
 @pytest.mark.parametrize("path", score_cases(), ids=lambda p: p.split("score_")[-1][:-4])

@@ -150,8 +150,10 @@ def test_errors_and_slot_restore():
         eng.train_step(dev(bad), dev(items), dev(cats), dev(labels)); eng.check()
     assert torch.equal(eng.pm.cpu(), torch.as_tensor(PM)) and torch.equal(eng.re.cpu(), torch.as_tensor(RE))   # nothing applied
     assert float(eng.train_slot(0, 0).abs().max()) == 0.0
+    # ... the step count and Adam's beta powers included (TF raises before the beta-power assigns): the engine goes on
+    # WITHOUT a reset exactly like one that never saw the bad batch
+    assert eng.train_steps() == 0
     # resume: a second engine fed the first one's tables and slots continues identically
-    eng.train_begin("adam", 0.001)                                   # reset after the failed step
     eng2 = _engine(PM, RE, CE)
     eng2.train_begin("adam", 0.001)
     eng.train_step(dev(users), dev(items), dev(cats), dev(labels)); eng.check()
@@ -161,6 +163,21 @@ def test_errors_and_slot_restore():
             np.testing.assert_allclose(eng.train_slot(tb, sl).cpu().numpy(), eng2.train_slot(tb, sl).cpu().numpy(), rtol=1e-5, atol=1e-9)
             eng2.train_slot(tb, sl, restore=eng.train_slot(tb, sl))
             assert torch.equal(eng.train_slot(tb, sl), eng2.train_slot(tb, sl))
+    assert eng.train_steps() == 1 and eng2.train_steps() == 1
+    for a, b in ((eng.pm, eng2.pm), (eng.re, eng2.re), (eng.ce, eng2.ce)):      # float atomics: equal to the last bits only
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-8)
+    snap = eng.pm.clone()
+    # a raw-ABI caller that does not check: the latch blocks the following steps too, and none of them counts
+    eng.train_step(dev(bad), dev(items), dev(cats), dev(labels))
+    eng.train_step(dev(users), dev(items), dev(cats), dev(labels))
+    with pytest.raises(IndexError):
+        eng.check()
+    assert eng.train_steps() == 1 and torch.equal(eng.pm, snap)
+    # a pending id error is reported as such by m2d_set_ingredients, not as a malformed CSR
+    eng.train_end()
+    eng.score_pairs(dev(bad), dev(items), dev(cats))
+    with pytest.raises(IndexError, match="user id"):
+        eng.set_ingredients(np.zeros((3, E), np.float32), np.zeros(I + 1, np.int32), np.zeros(0, np.int32))
 
 
 def test_session_serves_the_training_fetches():
@@ -189,12 +206,27 @@ def test_session_serves_the_training_fetches():
     curr_loss, lr, general, _ = sess.run([model.loss_value, model.learning_rate, model.general, model.train_op], feed)
     ref_loss, _ = st.step(users, items, cats, labels)
     assert curr_loss == pytest.approx(ref_loss, rel=1e-5) and lr == np.float32(0.002)
-    # the memory write ran after the optimizer step, on the updated tables
+    # the driver's ordinary batch (Train_recommender.py:195-199) fetches `general` only: the General_Memory assign
+    # (Model_Recommender.py:215) runs -- after the optimizer step, on the updated tables -- and the two
+    # Personal_Memory assigns (:167, :198) do NOT: Personal_Memory is exactly what the optimizer left
     pm32, re32, ce32 = (t.astype(np.float32) for t in (st.PM, st.RE, st.CE))
-    refPM, refGM, _, _ = oracle.write_memory(pm32, re32, ce32, GM, users, items, cats, sign, onehot, 0.01, 0.01, 0.01)
+    refPM, refGM, _, _ = oracle.write_memory(pm32, re32, ce32, GM, users, items, cats, sign, onehot, 0.01, 0.01, 0.01,
+                                             personal=False)
+    assert refPM is pm32
     assert general == pytest.approx(refGM.mean(), rel=1e-4, abs=1e-7)
     np.testing.assert_allclose(model.general_memory(), refGM, rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(model.engine.pm.cpu().numpy(), refPM, rtol=1e-3, atol=2e-6)
+    np.testing.assert_allclose(model.engine.pm.cpu().numpy(), pm32, rtol=1e-3, atol=2e-6)
+    written, _, _, _ = oracle.write_memory(pm32, re32, ce32, GM, users, items, cats, sign, onehot, 0.01, 0.01, 0.01)
+    assert np.abs(written - pm32).max() > 1e-4          # the write would have been visible at this tolerance
+    # `personal` alone: both Personal_Memory assigns, General_Memory untouched (g_b reads it as it stands)
+    pm_before, gm_before = model.engine.pm.cpu().numpy().copy(), model.general_memory().copy()
+    personal = sess.run(model.personal, feed)
+    refPM2, refGM2, mp, _ = oracle.write_memory(pm_before, re32, ce32, gm_before, users, items, cats, sign, onehot,
+                                                0.01, 0.01, 0.01, general=False)
+    assert personal == pytest.approx(mp, rel=1e-4, abs=1e-7)
+    np.testing.assert_allclose(model.engine.pm.cpu().numpy(), refPM2, rtol=1e-4, atol=2e-6)
+    np.testing.assert_array_equal(model.general_memory(), gm_before)
+    # the rare 'Write Personal Memory' branch (:180-184) fetches both
     loss2, lr2, personal, general2, _ = sess.run([model.loss_value, model.learning_rate, model.personal, model.general,
                                                   model.train_op], feed)
     assert np.isfinite(personal) and np.isfinite(general2) and loss2 < curr_loss + 1.0

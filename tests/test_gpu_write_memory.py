@@ -76,3 +76,39 @@ def test_write_memory_edge_cases():
     with pytest.raises(IndexError):
         eng.write_memory(t(bad), t(items), t(cats), t(sign), t(y), gm, 0.01, 0.01, 0.01); eng.check()
     eng.write_memory(t(users[:0]), t(items[:0]), t(cats[:0]), t(sign[:0]), t(y[:0]), gm, 0.01, 0.01, 0.01); eng.check()
+
+
+@pytest.mark.parametrize("personal,general", [(True, False), (False, True)])
+def test_write_memory_runs_only_the_fetched_assigns(personal, general):
+    """`personal` depends on the two Personal_Memory assigns only (Model_Recommender.py:167, :198), `general` on the
+    General_Memory assign only (:215); the driver's ordinary batch fetches `general` alone
+    (Train_recommender.py:195-199) and must leave Personal_Memory bit for bit as it was."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    U, I, C, E, L, B = 40, 20, 4, 64, 9, 50
+    PM, RE, CE, users, items, cats = random_case(U, I, C, E, B, seed=77, zero_rows=False)
+    rng = np.random.default_rng(5)
+    GM = (rng.standard_normal((L, C + 1, E)) / 4).astype(np.float32)
+    sign = np.where(rng.random(B) < 0.5, 1.0, -1.0).astype(np.float32)
+    y = (rng.random((B, L)) < 0.3).astype(np.float32); y[:, 1] = 1
+    eng = ScoringEngine(PM, RE, CE)
+    gm = torch.as_tensor(GM, device="cuda").clone()
+    t = lambda a: torch.as_tensor(a, device="cuda")
+    means = eng.write_memory(t(users), t(items), t(cats), t(sign), t(y), gm, 0.01, 0.02, 0.03, want_means=True,
+                             write_pm=personal, write_gm=general)
+    PM2, GM2, mp, mg = oracle.write_memory(PM, RE, CE, GM, users, items, cats, sign, y, 0.01, 0.02, 0.03,
+                                           personal=personal, general=general)
+    if personal:
+        _close(eng.pm.cpu().numpy(), PM2)
+        assert np.array_equal(gm.cpu().numpy(), GM) and means[1] is None and abs(means[0] - mp) < 1e-6
+    else:
+        _close(gm.cpu().numpy(), GM2)
+        assert np.array_equal(eng.pm.cpu().numpy(), PM) and means[0] is None and abs(means[1] - mg) < 1e-6
+    # a general-only call still refuses a bad id (the gathers are shared by both branches)
+    bad = items.copy(); bad[3] = I
+    with pytest.raises(IndexError):
+        eng.write_memory(t(users), t(bad), t(cats), t(sign), t(y), gm, 0.01, 0.02, 0.03, write_pm=personal, write_gm=general)
+        eng.check()
+    with pytest.raises(ValueError):
+        eng.write_memory(t(users), t(items), t(cats), t(sign), t(y), gm, 0.01, 0.02, 0.03, write_pm=False, write_gm=False)
