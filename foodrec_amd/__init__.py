@@ -11,8 +11,8 @@ _native.lib()          # fail loudly, at import, if the HIP library has not been
 
 from .ops import ScoringEngine                                  # noqa: E402
 from .recommender import Model, Session                         # noqa: E402
-from .evaluator import evaluate_model, eval_one_rating, getHitRatio, getNDCG   # noqa: E402
+from .evaluator import clear_eval_plans, evaluate_model, eval_one_rating, getHitRatio, getNDCG   # noqa: E402
 from .formats import Dataset                                    # noqa: E402
 
 __all__ = ["ScoringEngine", "Model", "Session", "evaluate_model", "eval_one_rating", "getHitRatio", "getNDCG",
-           "Dataset"]
+           "Dataset", "clear_eval_plans"]

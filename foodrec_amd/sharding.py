@@ -44,7 +44,9 @@ def shard_range(num_users: int, world: int, rank: int) -> Tuple[int, int]:
 
 class UserShardedScorer:
     def __init__(self, scorer, num_users_total: int, group: Optional[dist.ProcessGroup] = None,
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, always_collective: bool = False):
+        """`always_collective`: issue the collectives even at world size 1 (where they are identities) -- lets a
+        one-GPU box run the very code path the 8-GPU job runs (tests/test_gpu_sharding.py)."""
         self.scorer = scorer
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -57,7 +59,7 @@ class UserShardedScorer:
         self.device = torch.device(device) if device is not None else getattr(scorer, "device", torch.device("cpu"))
         if self.count > 0 and scorer is None:
             raise ValueError("rank %d owns users [%d, %d) and needs a scorer" % (self.rank, self.base, self.base + self.count))
-        self._bad_local = False        # an id no shard owns was seen by this rank's routing (reported by check())
+        self._solo = self.world == 1 and not always_collective
 
     # -- routing ------------------------------------------------------------------------------------
     def owner_of(self, users: torch.Tensor) -> torch.Tensor:
@@ -99,7 +101,7 @@ class UserShardedScorer:
         lo, n = off_h[self.rank], counts_h[self.rank]
         idx = order[lo:lo + n]
         local = self._score_local(users[idx], items[idx], cats.reshape(B, C)[idx])
-        if self.world == 1:
+        if self._solo:
             out[idx] = local
         else:
             cmax = max(counts_h)
@@ -121,7 +123,7 @@ class UserShardedScorer:
         of ``[user, dish, mask bits]`` int32 records to the owners, the owners score, one all-to-all of ``f32`` back."""
         B = users.numel()
         C = cats.shape[-1] if cats.dim() > 1 else (cats.numel() // max(B, 1))
-        if self.world == 1:
+        if self._solo:
             out = self._score_local(users, items, cats.reshape(B, C))
             if check:
                 self.check()
@@ -156,7 +158,7 @@ class UserShardedScorer:
                 self.scorer.check()
             except IndexError as e:
                 msg = str(e) or "id out of range"
-        if self.world > 1:
+        if not self._solo:
             flag = torch.tensor([1 if msg else 0], dtype=torch.int32, device=self.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
             if int(flag.item()) and not msg:
@@ -174,19 +176,34 @@ class UserShardedScorer:
                     torch.empty((0, k), dtype=torch.int32, device=self.device))
         return self.scorer.topk_users(users, k)
 
-    def topk_all_users(self, k: int):
-        """Per-user top-k for EVERY user, on every rank: one all-gather of ``[shard, k] x (f32, i32)`` (scores and
-        ids travel in one buffer).  Shards are padded to the common size ``per`` for the collective and trimmed."""
-        s, ids = self.topk_local(k)
-        if self.world == 1:
-            return s, ids
-        piece = torch.empty((2, self.per, k), dtype=torch.int32, device=self.device)
-        piece[0].view(torch.float32).fill_(float("nan"))
-        piece[1].fill_(-1)
-        piece[0, : self.count] = s.view(torch.int32)
-        piece[1, : self.count] = ids
-        gathered = torch.empty((self.world, 2, self.per, k), dtype=torch.int32, device=self.device)
+    def _gather_topk(self, s: torch.Tensor, ids: torch.Tensor, rows: int, k: int):
+        """One all-gather of ``[rows, k] x (f32 score, i32 id)`` per rank; scores and ids travel in one int32 buffer.
+        Ranks with fewer than `rows` results pad with (NaN, -1)."""
+        n = s.shape[0]
+        piece = torch.empty((2, rows, k), dtype=torch.int32, device=self.device)
+        if n < rows:
+            piece[0].view(torch.float32).fill_(float("nan"))
+            piece[1].fill_(-1)
+        piece[0, :n] = s.view(torch.int32)
+        piece[1, :n] = ids
+        gathered = torch.empty((self.world * 2, rows, k), dtype=torch.int32, device=self.device)
         dist.all_gather_into_tensor(gathered, piece, group=self.group)
-        gs = gathered[:, 0].reshape(self.world * self.per, k).view(torch.float32)
-        gi = gathered[:, 1].reshape(self.world * self.per, k)
+        gathered = gathered.view(self.world, 2, rows, k)
+        return gathered[:, 0].reshape(self.world * rows, k).view(torch.float32), gathered[:, 1].reshape(self.world * rows, k)
+
+    def topk_users_gathered(self, users: torch.Tensor, k: int):
+        """Top-k for `users` (ids of THIS shard; the same count on every rank), all-gathered: every rank receives
+        ``[world * n, k]`` scores and dish ids, rank r's block at rows ``[r * n, (r + 1) * n)``."""
+        s, ids = self.topk_local(k, users)
+        if self._solo:
+            return s, ids
+        return self._gather_topk(s, ids, users.numel(), k)
+
+    def topk_all_users(self, k: int):
+        """Per-user top-k for EVERY user, on every rank: one all-gather of ``[shard, k] x (f32, i32)``.
+        Shards are padded to the common size ``per`` for the collective and trimmed afterwards."""
+        s, ids = self.topk_local(k)
+        if self._solo:
+            return s, ids
+        gs, gi = self._gather_topk(s, ids, self.per, k)
         return gs[: self.num_users_total], gi[: self.num_users_total]

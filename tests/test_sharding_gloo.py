@@ -1,6 +1,7 @@
-"""world_size-2 (and 3) CPU tests of the user-sharded path over gloo: routing, the pair-score
-all-reduce and the top-k all-gather.  The per-shard scorer is a test double built on the oracle
-(the real one is a ScoringEngine on each GPU); what is under test is the host/collective logic."""
+"""world_size-2 (and 3) CPU tests of the user-sharded path over gloo: owner bucketing, the replicated-batch
+all-gather, the routed all-to-all and the top-k all-gather.  The per-shard scorer is a test double built on the
+oracle (the real one is a ScoringEngine on each GPU -- tests/test_gpu_sharding.py runs that); what is under test
+here is the host / collective logic."""
 import os
 import socket
 
@@ -23,10 +24,24 @@ class OracleShard:
         self.base, self.count = base, count
         self.device = torch.device("cpu")
 
+        self.pending = None             # like the engine: a bad id is latched, NaN is written, check() raises
+        self.pairs_scored = 0
+
     def score_pairs(self, users, items, cats):
         u = users.numpy().astype(np.int64) - self.base
-        assert u.min() >= 0 and u.max() < self.count, "pair routed to the wrong shard"
-        return torch.from_numpy(self.o.inference_f32(self.PM, self.RE, self.CE, u, items.numpy(), cats.numpy()))
+        self.pairs_scored += len(u)
+        bad = (u < 0) | (u >= self.count)
+        if bad.any() and self.pending is None:
+            self.pending = "user id %d is out of range" % int(users.numpy()[np.flatnonzero(bad)[0]])
+        out = np.full(len(u), np.nan, np.float32)
+        ok = ~bad
+        out[ok] = self.o.inference_f32(self.PM, self.RE, self.CE, u[ok], items.numpy()[ok], cats.numpy()[ok])
+        return torch.from_numpy(out)
+
+    def check(self):
+        msg, self.pending = self.pending, None
+        if msg:
+            raise IndexError(msg)
 
     def topk_users(self, users, k):
         u = users.numpy().astype(np.int64) - self.base
@@ -50,21 +65,38 @@ def _worker(rank, world, port, U, out_dir):
         dish_cats = np.random.default_rng(4).integers(0, 2, (40, 4)).astype(np.float32)
         dish_cats[dish_cats.sum(1) == 0, 1] = 1
         base, count = shard_range(U, world, rank)
-        sh = UserShardedScorer(OracleShard(PM, RE, CE, dish_cats, base, count), U)
+        shard = OracleShard(PM, RE, CE, dish_cats, base, count) if count else None     # an empty shard has no engine
+        sh = UserShardedScorer(shard, U)
         assert (sh.base, sh.count) == (base, count)
         got = sh.score_pairs(torch.from_numpy(users), torch.from_numpy(items), torch.from_numpy(cats))
         ref = oracle.inference_f32(PM, RE, CE, users, items, cats)
         assert np.array_equal(got.numpy(), ref)
         owners = sh.owner_of(torch.from_numpy(users)).numpy()
         assert np.array_equal(owners, users // sh.per)
+        # only the owner scored a pair: this rank saw exactly its bucket, not the whole batch
+        mine = int((owners == rank).sum())
+        assert (shard.pairs_scored if shard else 0) == mine
+        # routed form: every rank brings its OWN batch (different sizes, any owners) and gets its own scores back
+        rng = np.random.default_rng(100 + rank)
+        nb = 50 + 37 * rank
+        u2 = rng.integers(0, U, nb).astype(np.int32)
+        d2 = rng.integers(0, 40, nb).astype(np.int32)
+        m2 = rng.integers(0, 2, (nb, 4)).astype(np.float32); m2[m2.sum(1) == 0, 0] = 1
+        got2 = sh.score_pairs_routed(torch.from_numpy(u2), torch.from_numpy(d2), torch.from_numpy(m2))
+        assert np.array_equal(got2.numpy(), oracle.inference_f32(PM, RE, CE, u2, d2, m2))
+        empty = sh.score_pairs_routed(torch.zeros(0, dtype=torch.int32), torch.zeros(0, dtype=torch.int32), torch.zeros((0, 4)))
+        assert empty.numel() == 0
         s, ids = sh.topk_all_users(5)
         rs, ri = oracle.topk_catalogue(PM, RE, CE, dish_cats, np.arange(U), 5, dtype=np.float32)
         assert s.shape == (U, 5) and np.array_equal(ids.numpy(), ri) and np.array_equal(s.numpy(), rs.astype(np.float32))
-        try:
-            sh.score_pairs(torch.tensor([U], dtype=torch.int32), torch.tensor([0], dtype=torch.int32), torch.ones(1, 4))
-            raise AssertionError("out-of-range user accepted")
-        except IndexError:
-            pass
+        # an id no shard owns: refused on EVERY rank (collective check), in both forms
+        for bad_user in (U, -1, 10 * U + 7):
+            for fn in (sh.score_pairs, sh.score_pairs_routed):
+                try:
+                    fn(torch.tensor([0, bad_user], dtype=torch.int32), torch.tensor([0, 0], dtype=torch.int32), torch.ones(2, 4))
+                    raise AssertionError("out-of-range user accepted")
+                except IndexError:
+                    pass
         open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()
