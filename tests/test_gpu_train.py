@@ -212,7 +212,7 @@ def test_session_serves_the_training_fetches():
     pm32, re32, ce32 = (t.astype(np.float32) for t in (st.PM, st.RE, st.CE))
     refPM, refGM, _, _ = oracle.write_memory(pm32, re32, ce32, GM, users, items, cats, sign, onehot, 0.01, 0.01, 0.01,
                                              personal=False)
-    assert refPM is pm32
+    assert np.array_equal(refPM, pm32)                  # personal=False: the oracle leaves Personal_Memory alone
     assert general == pytest.approx(refGM.mean(), rel=1e-4, abs=1e-7)
     np.testing.assert_allclose(model.general_memory(), refGM, rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(model.engine.pm.cpu().numpy(), pm32, rtol=1e-3, atol=2e-6)
