@@ -18,6 +18,8 @@
 // stable, so ties go to the lower dish id as heapq.nlargest does (evaluate.py:63).
 #include <math.h>
 
+#include <type_traits>
+
 #include "m2d_engine.h"
 
 // Timing-only ablation hooks for scripts/diag/topk_diag.cpp (never defined in the product build):
@@ -126,6 +128,34 @@ __device__ __forceinline__ void sorted_insert(float (&ls)[N], int32_t (&li)[N], 
         ls[i] = ns[i];
         li[i] = ni[i];
     }
+}
+
+// sorted_insert written in place, from the last slot up: slot i takes med3(old[i-1], x, old[i]) while slots < i still
+// hold their old values, so no copy of the list is made (4 VALU per slot) and any contiguous range of slots
+// [lo, hi) can be done on its own -- the pipelined kernel spreads the ranges over the gaps between its MFMAs.
+// Ranges must be applied from the highest slots down.
+template <int N, int LO, int HI>
+__device__ __forceinline__ void sorted_insert_range(float (&ls)[N], int32_t (&li)[N], const float x, const int32_t id)
+{
+#pragma unroll
+    for (int i = HI - 1; i >= LO; --i) {
+        const unsigned long long ab = __ballot(x > ls[i]);
+        if (i > 0) {
+            const unsigned long long ab1 = __ballot(x > ls[i - 1]);
+            li[i] = lane_select(ab1, li[i - 1], lane_select(ab, id, li[i]));
+            ls[i] = __builtin_amdgcn_fmed3f(ls[i - 1], x, ls[i]);
+        } else {
+            li[0] = lane_select(ab, id, li[0]);
+            ls[0] = fmaxf(ls[0], x);
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void sorted_insert_inplace(float (&ls)[N], int32_t (&li)[N], float x, const int32_t id)
+{
+    x = fmaxf(x, -INFINITY);                     // maxNum: NaN -> -inf
+    sorted_insert_range<N, 0, N>(ls, li, x, id);
 }
 
 // NB = K / 8: float4 registers of the user operand per lane.  One stage = 32 dishes x KC floats.
@@ -583,6 +613,8 @@ __global__ void m2d_grp_scan(int32_t *blk_hist, int nblk, int32_t *grp, int32_t 
         }
         grp[16] = t;
         grp[17] = off;
+        grp[40] = 0;
+        for (int q = 1; q < GRP_MAXPAT; ++q) grp[40 + q] = total[q];      // rows per pattern (m2d_topk_grouped_bf16_pipe)
     }
 }
 
@@ -631,6 +663,7 @@ struct GroupedArgs {
     const __bf16 *rs16;      // the same rows as split bf16 (hi | lo blocks per 32-row tile)
     const int32_t *perm;     // [slots]      slot -> dish id (-1 = padding)
     const int32_t *tile_info;
+    const int32_t *grp;      // [0..15] first slot of each pattern's group, [40..55] rows per pattern
     const int32_t *users;
     int64_t nU, U, user_base;
     int32_t k, nsplit;
@@ -1071,6 +1104,425 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
     }
 }
 
+// ---- pipelined form of m2d_topk_grouped_bf16: constant-shape steps, insertions under the MFMAs ------------------
+// Same arithmetic, same lists, same LDS image as m2d_topk_grouped_bf16 above; what changes is the order in which a
+// wave issues its work.  The first form runs each 32-dish tile as [tile_info load, wait] -> [8 x (ds_read, wait,
+// MFMA)] -> [16 compares] -> [insertions]: the matrix pipe waits on a global load and on every LDS read, the compares
+// wait on the last MFMA (PMC: SQ_VALU_MFMA_BUSY 23 %).  Here a wave keeps three tiles in flight -- step q issues the
+// MFMAs of tile q-1, the LDS reads of tile q (each into the registers its k-step just freed) and the threshold
+// compares of tile q-2 in the issue slots the MFMAs leave free -- tile meta data come from a 16-entry group table
+// held in lanes and walked with scalar ALU, and tiles past the block's range run as dummies (no valid row) so the
+// steady-state step has no tail cases (the catalogue image is padded for that).  A first pipelined version that kept
+// the accumulator initialisation, the per-stage DMA burst and the branch into an insertion loop measured (stamps of
+// scripts/diag/topk_diag.cpp, 100 k dishes, E = 64, cycles per step per wave): body 1 000, insertion path 970 (56 % of
+// the steps, 1 730 each), stage wait + barrier 650; with the insertions compiled out still 1 074 + 307, of which 208
+// was the accumulator initialisation in front of each chain and ~250 the stage's LDS-DMA issue (address arithmetic +
+// 8 pieces per wave, every wave at once right after the barrier, matrix pipe idle).  Hence:
+//   * the chain starts from a zero C operand; alpha_P is added where a score enters a list (thresholds are compared
+//     as thr - alpha), padding rows are forced to -inf only in the rare partial tile;
+//   * the next stage's LDS-DMA pieces are issued a few per step inside the first steps of a stage, from a per-lane
+//     source offset computed once (consecutive pieces of a wave are a fixed stride apart in source and destination);
+//   * a step never branches into an insertion loop: the 16 compares of tile q-2 run under the MFMAs of tile q-1 as
+//     before, each folded into a per-lane 16-bit map of candidate rows (v_addc: map = 2 map + bit), and when some lane
+//     has a candidate its single best score of the tile (the max tree's result; the row is the map's set bit) is
+//     parked as (px, pid) and inserted by the NEXT step -- slot ranges of an in-place sorted insert placed between
+//     that step's MFMA groups.  Only a tile in which one lane holds two or more candidates (the first tiles of a
+//     scan, then rare) takes the immediate per-row path.
+// G = groups of 32 users per wave (8 / G waves per block, always 256 users per block).  G = 1 is what is launched.
+// G = 2 (one wave per SIMD, every A fragment feeding two independent MFMA chains) was measured slower at every shape
+// tried (100 k dishes E = 64: 4.7 ms against 3.7; 1 M dishes E = 128: 47.0 against 47.3 for the first form) and is kept
+// only as a template parameter.
+// Thresholds are one insertion stale when tile q-2 is compared: more candidates, never fewer.
+template <int E, int KR, int G>
+__global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedArgs p)
+{
+    constexpr int C = 4, WAVES = 8 / G;
+    constexpr int KS = E / 16;                             // k-steps (16 k-values) per tile
+    constexpr int S8 = E / 8;                              // 16-B slots per bf16 row
+    constexpr int RPB = 256 / (E * 2) > 0 ? 256 / (E * 2) : 1;   // rows per 256-B bank row
+    constexpr int TPS = E == 64 ? 8 : 4;                   // tiles per stage: 64 KiB stages
+    constexpr int ROW_BYTES = E * 2, TILE_BYTES = 64 * ROW_BYTES, STAGE_BYTES = TPS * TILE_BYTES;
+    constexpr int PIECES = STAGE_BYTES / 1024;
+    constexpr int PPW = PIECES / WAVES;                    // 1-KiB DMA pieces per wave per stage
+    constexpr int PCNT = (PPW + TPS - 2) / (TPS - 1);      // pieces issued per step (none in a stage's last step)
+    constexpr int PSTRIDE = WAVES * 1024;                  // a wave's consecutive pieces: this far apart, source and LDS
+    constexpr int S4 = E / 4;                              // float4 per f32 row of Personal_Memory
+    constexpr int RPK = 16 / KS;                           // compares of the previous tile per k-step
+    static_assert(PIECES % WAVES == 0 && (WAVES * 64) % S8 == 0 && ((WAVES * 64 / S8) / RPB) % S8 == 0, "piece layout");
+
+    extern __shared__ __align__(16) unsigned char smem8[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int k = p.k;
+
+    int64_t uidx[G];
+    bool uvalid[G];
+    const v4f *pmu[G];
+    float hc[G][C];                                        // <U_high, CE_c>   Model_Recommender.py:67-75
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        uidx[g] = (((int64_t)blockIdx.x * WAVES + wave) * G + g) * 32 + j;
+        uvalid[g] = uidx[g] < p.nU;
+        int64_t ul = 0;
+        if (uvalid[g]) {
+            const int32_t uid = p.users[uidx[g]];
+            ul = (int64_t)uid - p.user_base;
+            if (ul < 0 || ul >= p.U) {
+                if (atomicCAS(&p.err[0], 0, M2D_ERR_BAD_USER_ID) == 0) {
+                    p.err[1] = uid;
+                    p.err[2] = (int32_t)(uidx[g] & 0xffffffff);
+                    p.err[3] = (int32_t)(uidx[g] >> 32);
+                }
+                ul = 0;
+            }
+        }
+        pmu[g] = reinterpret_cast<const v4f *>(p.pm) + (size_t)ul * ((C + 1) * S4);
+        const v4f *ce4 = reinterpret_cast<const v4f *>(p.ce);
+#pragma unroll
+        for (int c = 0; c < C; ++c) hc[g][c] = 0.f;
+#pragma unroll 1
+        for (int q = 0; q < S4; ++q) {
+            const v4f u = pmu[g][q];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const v4f w = ce4[c * S4 + q];
+                hc[g][c] += (u.x * w.x + u.y * w.y) + (u.z * w.z + u.w * w.w);
+            }
+        }
+    }
+    // group table: lane q holds the first tile and the row count of mask pattern q (groups are padded to whole tiles)
+    int g_first = 0, g_rows = 0;
+    if (lane >= 1 && lane < GRP_MAXPAT) {
+        g_first = p.grp[lane] >> 5;
+        g_rows = p.grp[40 + lane];
+    }
+
+    bf16x8 wh[G][KS], wl[G][KS];                           // w_P[u] for k = 16 s + 8 h + (0..7), split hi / lo
+    float alpha[G], alpha_prev[G];                         // alpha_P of the tile being multiplied / being compared
+    int cur_pat = -1;
+    int gp = 0;                                            // group walk: pattern, its tile range and row count
+    int64_t g_beg = 0, g_end = 0;
+    int g_tot = 0;
+
+    float rs[G][KR];
+    int32_t ri[G][KR];
+    float thr[G], px[G];                                   // px, pid: parked candidate = this lane's best score of one tile
+    int32_t pid[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int i = 0; i < KR; ++i) {
+            rs[g][i] = -INFINITY;
+            ri[g][i] = -1;
+        }
+        thr[g] = px[g] = -INFINITY;
+        pid[g] = -1;
+        alpha[g] = alpha_prev[g] = 0.f;
+    }
+    bool pend = false;                                     // wave-uniform: some (px, pid) waits to be inserted
+
+    const int64_t per = (p.tiles + p.nsplit - 1) / p.nsplit;
+    const int64_t t_begin = (int64_t)blockIdx.y * per;
+    const int64_t t_end = min(p.tiles, t_begin + per);
+    const int64_t n = t_end > t_begin ? t_end - t_begin : 0;        // tiles of this block
+    const int64_t nst = n > 0 ? (n + 2) / TPS + 1 : 0;              // stages the steps below touch (dummies included)
+
+    // LDS-DMA: this lane's source offset inside a stage for its wave's first piece
+    const unsigned char *const src_base = reinterpret_cast<const unsigned char *>(p.rs16) + (size_t)t_begin * TILE_BYTES;
+    int dma_off;
+    {
+        const int g = wave * 64 + lane;                    // physical 16-B slot in the stage image
+        const int rw = g / S8, sl = g - rw * S8;           // stage row (hi and lo rows alike), slot in row
+        const int q = sl ^ ((rw / RPB) & (S8 - 1));        // logical slot that must land here
+        dma_off = rw * ROW_BYTES + q * 16;
+    }
+    auto issue_pieces = [&](const int64_t stage, const int first, const int count) __attribute__((always_inline)) {
+        if (stage >= nst) return;
+        const unsigned char *src = src_base + (size_t)stage * STAGE_BYTES + dma_off;
+        unsigned char *dst = smem8 + (size_t)(stage & 1) * STAGE_BYTES + wave * 1024;
+#pragma unroll
+        for (int c = 0; c < count; ++c) {
+            const int pp = first + c;
+            if (pp < PPW) lds_dma16(src + pp * PSTRIDE, dst + pp * PSTRIDE);
+        }
+    };
+
+    // this lane's byte offset inside a tile image: row j, slot (2 ks + h) ^ key = (2 ks) ^ (h ^ key)
+    const int key = (j / RPB) & (S8 - 1);
+    const int lane_off = j * ROW_BYTES + ((h ^ key) << 4);
+
+    bf16x8 ah[KS], al[KS];                                 // A fragments of the tile whose MFMAs come next
+    v16f acc0[G], acc1[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[g][r] = acc1[g][r] = -INFINITY;
+    }
+    const v16f zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    if (n > 0) {
+        issue_pieces(0, 0, PPW);
+        wait_all_vmem();
+        __syncthreads();
+        issue_pieces(1, 0, PCNT);                          // what step "0" of the first stage would have issued
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {                  // L(0)
+            const unsigned char *a = smem8 + (lane_off ^ (ks << 5));
+            ah[ks] = *reinterpret_cast<const bf16x8 *>(a);
+            al[ks] = *reinterpret_cast<const bf16x8 *>(a + 32 * ROW_BYTES);
+        }
+    }
+
+#if M2D_DIAG & 16
+    unsigned long long t_body = 0, t_slow = 0, t_bar = 0, n_slow = 0, n_step = 0, n_ins = 0, t0_, t1_;
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    auto share_threshold = [&](const int g) __attribute__((always_inline)) {
+        // the user's other lane (l ^ 32): a score that does not beat the larger of the two k-th bests cannot be in the
+        // user's merged top-k
+        const float t = rs[g][KR - 1];
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+        thr[g] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    };
+
+    // the interleaved body: M(q-1) into accN, L(q), the compares + max tree of tile q-2 (accP), and -- INS -- the
+    // parked insertion, slot ranges from the end of the list up, one range per k-step group
+    auto body = [&](auto ins_tag, v16f (&accN)[G], const v16f (&accP)[G], const int img_off, const float (&thr_rel)[G],
+                    uint32_t (&rowmap)[G], float (&mx)[G]) __attribute__((always_inline)) {
+        constexpr bool INS = decltype(ins_tag)::value;
+        float x[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            x[g] = fmaxf(px[g], -INFINITY);
+            mx[g] = -INFINITY;
+            rowmap[g] = 0u;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], wh[g][ks], ks == 0 ? zero16 : accN[g], 0, 0, 0);
+                accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], wl[g][ks], accN[g], 0, 0, 0);
+                accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], wh[g][ks], accN[g], 0, 0, 0);
+            }
+            const unsigned char *a = smem8 + (img_off ^ (ks << 5));
+            ah[ks] = *reinterpret_cast<const bf16x8 *>(a);
+            al[ks] = *reinterpret_cast<const bf16x8 *>(a + 32 * ROW_BYTES);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+#pragma unroll
+                for (int r = ks * RPK; r < (ks + 1) * RPK; ++r) {
+                    rowmap[g] = rowmap[g] + rowmap[g] + (accP[g][r] > thr_rel[g] ? 1u : 0u);   // v_cmp + v_addc
+                    mx[g] = fmaxf(mx[g], accP[g][r]);
+                }
+                if constexpr (INS) {
+                    // slots [lo, hi) of the list, highest ranges first
+                    constexpr int PER = (KR + KS - 1) / KS;
+                    if (ks == 0) sorted_insert_range<KR, (KR - PER > 0 ? KR - PER : 0), KR>(rs[g], ri[g], x[g], pid[g]);
+                    if (ks == 1) sorted_insert_range<KR, (KR - 2 * PER > 0 ? KR - 2 * PER : 0), (KR - PER > 0 ? KR - PER : 0)>(rs[g], ri[g], x[g], pid[g]);
+                    if (ks == 2) sorted_insert_range<KR, (KR - 3 * PER > 0 ? KR - 3 * PER : 0), (KR - 2 * PER > 0 ? KR - 2 * PER : 0)>(rs[g], ri[g], x[g], pid[g]);
+                    if (ks == 3) sorted_insert_range<KR, (KS == 4 ? 0 : (KR - 4 * PER > 0 ? KR - 4 * PER : 0)), (KR - 3 * PER > 0 ? KR - 3 * PER : 0)>(rs[g], ri[g], x[g], pid[g]);
+                    if (KS > 4 && ks == 4) sorted_insert_range<KR, 0, (KR - 4 * PER > 0 ? KR - 4 * PER : 0)>(rs[g], ri[g], x[g], pid[g]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (INS) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) share_threshold(g);
+        }
+    };
+
+    auto step = [&](v16f (&accN)[G], v16f (&accP)[G], const int64_t q) __attribute__((always_inline)) {
+#if M2D_DIAG & 16
+        STAMP(t0_);
+#endif
+        const int sub = (int)(q & (TPS - 1));
+        if (sub == 0) {                                    // tile q opens stage q / TPS: it must have landed, for every wave
+            wait_all_vmem();
+            __syncthreads();                               // also: every wave is done reading the buffer refilled next
+        }
+        if (sub < TPS - 1) issue_pieces(q / TPS + 1, sub * PCNT, PCNT);
+#if M2D_DIAG & 16
+        STAMP(t1_); t_bar += t1_ - t0_; t0_ = t1_;
+#endif
+#pragma unroll
+        for (int g = 0; g < G; ++g) alpha_prev[g] = alpha[g];   // tile q-2 was multiplied under the previous step's alpha
+        int nvalid = 0;
+        if (q - 1 < n) {
+            const int64_t t = t_begin + q - 1;
+            while (t >= g_end) {                            // next non-empty group (scalar; at most 15 times per block)
+                ++gp;
+                g_tot = __builtin_amdgcn_readlane(g_rows, gp);
+                g_beg = __builtin_amdgcn_readlane(g_first, gp);
+                g_end = g_beg + ((g_tot + 31) >> 5);
+            }
+            const int left = g_tot - (int)(t - g_beg) * 32;
+            nvalid = left < 32 ? left : 32;
+            if (gp != cur_pat) {
+                cur_pat = gp;
+                const int pat = gp;
+                const float inv_n = 1.0f / (float)__builtin_popcount(pat);
+                const float beta = p.b * inv_n;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    float hs = 0.f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) hs += ((pat >> c) & 1) ? hc[g][c] : 0.f;
+                    alpha[g] = p.a * (hs * inv_n);
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {                   // unrolled: every register index is static
+                        v4f w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            if ((pat >> c) & 1) {
+                                const v4f *row = pmu[g] + (c + 1) * S4 + 4 * ks + 2 * h;
+                                w0 += row[0];
+                                w1 += row[1];
+                            }
+                        }
+                        w0 *= beta;
+                        w1 *= beta;
+                        const float xx[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                        bf16x8 vh, vl;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const __bf16 xh = (__bf16)xx[i];
+                            vh[i] = xh;
+                            vl[i] = (__bf16)(xx[i] - (float)xh);
+                        }
+                        wh[g][ks] = vh;
+                        wl[g][ks] = vl;
+                    }
+                }
+            }
+        }
+        float thr_rel[G];                                  // accumulators carry no alpha: compare against thr - alpha
+#pragma unroll
+        for (int g = 0; g < G; ++g) thr_rel[g] = thr[g] - alpha_prev[g];
+        const int img_off = (int)(((q / TPS) & 1) * STAGE_BYTES + sub * TILE_BYTES) + lane_off;   // tile q
+        uint32_t rowmap[G];                                // bit 15 - r: row r of tile q-2 beats this lane's threshold
+        float mx[G];
+        if (pend) body(std::true_type{}, accN, accP, img_off, thr_rel, rowmap, mx);
+        else body(std::false_type{}, accN, accP, img_off, thr_rel, rowmap, mx);
+        if (nvalid < 32) {                                 // a group's last tile, or a dummy tile: padding rows never rank
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    accN[g][r] = (4 * h + (r & 3) + 8 * (r >> 2) < nvalid) ? accN[g][r] : -INFINITY;
+            }
+        }
+        bool cand[G];
+        unsigned long long anyc = 0ull;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            cand[g] = rowmap[g] != 0u;
+            anyc |= __ballot(cand[g]);
+        }
+#if M2D_DIAG & 16
+        STAMP(t1_); t_body += t1_ - t0_; t0_ = t1_; ++n_step;
+#endif
+        pend = false;
+#if M2D_DIAG & 8
+        asm volatile("" ::"s"(anyc), "v"(mx[0]), "v"(mx[G - 1]));
+#endif
+        if ((M2D_DIAG & 8) ? false : anyc != 0ull) {       // some lane of tile q-2 beat its threshold
+            const int32_t sbase = (int32_t)((t_begin + q - 2) * 32) + 4 * h;
+            unsigned long long multi = 0ull;
+#pragma unroll
+            for (int g = 0; g < G; ++g) multi |= __ballot((rowmap[g] & (rowmap[g] - 1u)) != 0u);   // two or more bits set
+            if (multi != 0ull) {                           // immediate per-row path (first tiles of a scan, then rare)
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (__ballot((rowmap[g] >> (15 - r)) & 1u) != 0ull)
+                            sorted_insert_inplace<KR>(rs[g], ri[g], accP[g][r] + alpha_prev[g], sbase + (r & 3) + 8 * (r >> 2));
+                    }
+                    share_threshold(g);
+                }
+#if M2D_DIAG & 16
+                ++n_ins;
+#endif
+            } else {
+                // one candidate per lane at most: it is the lane's maximum, and its row is the map's only set bit
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int r = __builtin_clz(rowmap[g] | 1u) - 16;          // bit 15 - r  ->  r  (lanes without a candidate: any)
+                    px[g] = cand[g] ? mx[g] + alpha_prev[g] : -INFINITY;
+                    pid[g] = sbase + (r & 3) + 8 * (r >> 2);
+                }
+                pend = true;
+            }
+#if M2D_DIAG & 16
+            asm volatile("" ::"v"(thr[0]), "v"(px[0]));
+            STAMP(t1_); t_slow += t1_ - t0_; ++n_slow;
+#endif
+        }
+    };
+
+    for (int64_t q = 1; q <= n + 1 && n > 0; q += 2) {
+        step(acc0, acc1, q);
+        step(acc1, acc0, q + 1);
+    }
+    if (pend) {                                            // the last parked candidates
+#pragma unroll
+        for (int g = 0; g < G; ++g) sorted_insert_inplace<KR>(rs[g], ri[g], px[g], pid[g]);
+    }
+    wait_all_vmem();                                       // no LDS-DMA may land after the lists are published below
+    __syncthreads();
+#if M2D_DIAG & 16
+    if (lane == 0 && p.dbg) {
+        unsigned long long *d = p.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave) * 8;
+        d[0] = t_body; d[1] = n_ins; d[2] = t_bar; d[3] = t_slow; d[4] = n_slow; d[5] = n_step;
+        d[6] = __builtin_amdgcn_s_memtime() - clk0; d[7] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+#endif
+
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float *ls = reinterpret_cast<float *>(smem8) + (size_t)(wave * G + g) * 2 * KR * 64;   // aliases stage 0
+        int32_t *li = reinterpret_cast<int32_t *>(ls + (size_t)KR * 64);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < KR; ++i) {
+            ls[i * 64 + lane] = rs[g][i];
+            li[i * 64 + lane] = ri[g][i] >= 0 ? p.perm[ri[g][i]] : -1;
+            cnt += ri[g][i] >= 0 ? 1 : 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int cnt_hi = __shfl(cnt, j + 32, 64);
+        if (h == 0 && uvalid[g]) {
+            const int ca = cnt, cb = cnt_hi;
+            int pa = 0, pb = 0;
+            float *os = p.out_scores + ((size_t)uidx[g] * p.nsplit + blockIdx.y) * k;
+            int32_t *oi = p.out_ids + ((size_t)uidx[g] * p.nsplit + blockIdx.y) * k;
+            for (int o = 0; o < k; ++o) {
+                const bool ha = pa < ca, hb = pb < cb;
+                if (!ha && !hb) {
+                    os[o] = __builtin_nanf("");
+                    oi[o] = -1;
+                    continue;
+                }
+                const float sa = ha ? ls[pa * 64 + lane] : 0.f, sb = hb ? ls[pb * 64 + lane + 32] : 0.f;
+                const int32_t ia = ha ? li[pa * 64 + lane] : 0, ib = hb ? li[pb * 64 + lane + 32] : 0;
+                bool take_a;
+                if (!hb) take_a = true;
+                else if (!ha) take_a = false;
+                else take_a = sa > sb || (sa == sb && ia < ib);
+                os[o] = take_a ? sa : sb;
+                oi[o] = take_a ? ia : ib;
+                pa += take_a ? 1 : 0;
+                pb += take_a ? 0 : 1;
+            }
+        }
+    }
+}
+
 int ensure_grouped(m2d_engine *h, hipStream_t st)
 {
     if (h->grp_valid) return M2D_OK;
@@ -1135,18 +1587,26 @@ void m2d_launch_merge_splits2(const float *ps, const int32_t *pi, int64_t nU, in
     m2d_launch_merge_splits(tmp_s, tmp_i, nU, G, k, out_s, out_i, st);
 }
 
-// shared tail of every MFMA retrieval launch: dish-range splits -> partial lists in scratch.  Few users: split the
-// dish range over up to max_splits blocks per user block so that a single query still uses the whole chip.
+// shared tail of every MFMA retrieval launch: dish-range splits -> partial lists in scratch.  The grouped kernels run
+// ONE block per CU (128 KiB of LDS), so the grid is ublocks x nsplit blocks dealt out in rounds of num_cu: the fewest
+// splits whose last round is at least 90 % full are taken (each split repeats the early, insertion-heavy part of a
+// scan and adds a merge pass: 65 536 users x 100 k dishes ran 3.69 ms with 2 splits and 2.91 ms with 1).  Few users:
+// up to max_splits blocks per user block, so that a single query still uses the whole chip.
 int pick_splits(m2d_engine *h, int64_t ublocks, int64_t tiles, int64_t min_tiles_per_split, int max_splits = 64)
 {
+    const int64_t cus = h->num_cu;
+    int64_t cap = tiles / min_tiles_per_split > 1 ? tiles / min_tiles_per_split : 1;
+    if (cap > max_splits) cap = max_splits;
+    int64_t lim = (2 * cus + ublocks - 1) / ublocks;        // beyond two rounds' worth of blocks nothing is gained
+    if (lim < 1) lim = 1;
+    if (lim > cap) lim = cap;
     int nsplit = 1;
-    const int64_t want = 2 * (int64_t)h->num_cu;
-    if (ublocks < want) {
-        int64_t ns = (want + ublocks - 1) / ublocks;
-        const int64_t cap = tiles / min_tiles_per_split > 1 ? tiles / min_tiles_per_split : 1;
-        if (ns > max_splits) ns = max_splits;
-        if (ns > cap) ns = cap;
-        nsplit = (int)ns;
+    double best = 0.0;
+    for (int64_t ns = 1; ns <= lim; ++ns) {
+        const int64_t blocks = ublocks * ns, rounds = (blocks + cus - 1) / cus;
+        const double fill = (double)blocks / (double)(rounds * cus);
+        if (fill > best + 1e-9) { best = fill; nsplit = (int)ns; }
+        if (fill >= 0.9) break;
     }
     if (h->opt_variant >= 100) {   // test hook: force the number of dish-range splits
         nsplit = h->opt_variant - 100;
@@ -1167,6 +1627,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     GroupedArgs a;
     a.pm = h->pm; a.ce = h->ce; a.rs = h->grp_rs; a.rs16 = reinterpret_cast<const __bf16 *>(h->grp_rs16);
     a.perm = h->grp_perm; a.tile_info = h->grp_tile_info;
+    a.grp = h->grp_work + (size_t)((h->I + 255) / 256) * GRP_MAXPAT;
     a.users = users; a.nU = nU; a.U = h->U; a.user_base = h->user_base; a.k = k; a.tiles = h->grp_tiles;
     a.a = h->a; a.b = h->b; a.err = h->err_dev; a.dbg = g_m2d_diag_buffer;
     const int64_t ublocks = (nU + 32 * WAVES - 1) / (32 * WAVES);
@@ -1190,9 +1651,19 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     float *tmp_s = h->scratch ? h->scratch + (size_t)2 * nU * nsplit * k : nullptr;
     int32_t *tmp_i = reinterpret_cast<int32_t *>(tmp_s ? tmp_s + tmp_entries : nullptr);
     if constexpr (BF16X3) {
-        auto kern = m2d_topk_grouped_bf16<E, WAVES, KR>;
-        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(WAVES * 64), lds, st, a);
+        // "topk_form": 0 = by shape (pipelined at E = 64; at E = 128 its 256 VGPRs spill and the first form is faster:
+        // 1 M dishes 50.8 ms against 47.3), 1 = first form, 2 = pipelined
+        const bool pipe = h->opt_topk_form == 2 || (h->opt_topk_form == 0 && E == 64);
+        if (!pipe) {
+            auto kern = m2d_topk_grouped_bf16<E, WAVES, KR>;
+            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(WAVES * 64), lds, st, a);
+        } else {
+            static_assert(WAVES == 8, "the pipelined kernel is written for 256 users per block");
+            auto kern = m2d_topk_grouped_bf16_pipe2<E, KR, 1>;
+            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(512), lds, st, a);
+        }
     } else {
         auto kern = m2d_topk_grouped<E8, WAVES, KR>;
         M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1206,7 +1677,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     hipLaunchKernelGGL(m2d_topk_fill_absent, dim3((unsigned)((nU + 127) / 128)), dim3(128), 0, st, final_s, final_i, nU, k,
                        h->I);
     M2D_HIP_TRY(h, hipGetLastError());
-    h->last_kernel = BF16X3 ? "m2d_topk_grouped_bf16x3" : "m2d_topk_grouped";
+    h->last_kernel = BF16X3 ? "m2d_topk_grouped_bf16x3" : "m2d_topk_grouped";      // both bf16 forms report this name
     return M2D_OK;
 }
 

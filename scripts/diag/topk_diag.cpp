@@ -3,6 +3,7 @@
 #include "../../foodrec_amd/csrc/m2d_catalogue.hip"
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 int main(int argc, char **argv)
@@ -16,6 +17,7 @@ int main(int argc, char **argv)
     h.num_cu = prop.multiProcessorCount;
     const size_t K = (C + 1) * E;
     std::vector<float> pm(U * K), re(I * E), ce(C * E), cats(I * C, 1.0f);
+    if (argc > 1) h.opt_variant = atoi(argv[1]);
     unsigned s = 1;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
     for (auto &x : pm) x = rnd();
@@ -55,13 +57,16 @@ int main(int argc, char **argv)
     {
         std::vector<unsigned long long> hd(4096 * 8);
         hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
-        double m = 0, e = 0, b = 0, sl = 0, ns = 0, st = 0;
-        for (int w = 0; w < 4096; ++w) { m += hd[w*8]; e += hd[w*8+1]; b += hd[w*8+2]; sl += hd[w*8+3]; ns += hd[w*8+4]; st += hd[w*8+5]; }
-        printf("per tile per wave (cycles): mfma %.0f  fast-epilogue %.0f  slow-epilogue %.0f (%.1f%% of tiles, %.0f each)  wait+barrier %.0f\n",
-               m / st, e / st, sl / st, 100.0 * ns / st, ns ? sl / ns : 0.0, b / st);
+        double m = 0, e = 0, b = 0, sl = 0, ns = 0, st = 0, ck = 0, rt = 0;
+        for (int w = 0; w < 4096; ++w) { m += hd[w*8]; e += hd[w*8+1]; b += hd[w*8+2]; sl += hd[w*8+3]; ns += hd[w*8+4]; st += hd[w*8+5]; ck += hd[w*8+6]; rt += hd[w*8+7]; }
+        if (rt > 0) printf("in-kernel clock: %.0f s_memtime ticks per wave over %.1f us (s_memrealtime, 100 MHz) = %.3f GHz\n", ck / 4096, rt / 4096 / 100.0, ck / rt * 0.1);
+        // pipelined bf16 kernel: d[0] = interleaved body, d[1] = sorted_insert calls, d[2] = stage wait + barrier, d[3] = slow path
+        printf("per step per wave (cycles): body %.0f  slow path %.0f (%.1f%% of steps, %.0f each, %.2f inserts each)  wait+barrier %.0f  [%.0f steps/wave]\n",
+               m / st, sl / st, 100.0 * ns / st, ns ? sl / ns : 0.0, ns ? e / ns : 0.0, b / st, st / 4096);
     }
 #endif
     const double flops = 2.0 * K * (double)U * (double)I;
-    printf("M2D_DIAG=%d  %.3f ms  %.1f TFLOP/s  (%.1f%% of 157.3)\n", M2D_DIAG, best, flops / best / 1e9, flops / best / 1e9 / 157.3 * 100);
+    printf("M2D_DIAG=%d  %s  %.3f ms  %.1f dense-equivalent TFLOP/s; executed bf16 flops %.0f TFLOP/s = %.3f of 2500\n", M2D_DIAG, h.last_kernel, best, flops / best / 1e9,
+           6.0 * E * (double)U * (double)I / best / 1e9, 6.0 * E * (double)U * (double)I / best / 1e9 / 2500.0);
     return 0;
 }
