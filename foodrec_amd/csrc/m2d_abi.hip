@@ -540,6 +540,7 @@ int m2d_set_option(m2d_engine *h, const char *name, int64_t value)
     else if (!strcmp(name, "variant")) h->opt_variant = (int)value;
     else if (!strcmp(name, "topk_bf16x3")) h->opt_topk_bf16x3 = (int)value;
     else if (!strcmp(name, "topk_form")) h->opt_topk_form = (int)value;
+    else if (!strcmp(name, "topk_grouped")) h->opt_topk_grouped = (int)value;
     else if (!strcmp(name, "mlp_bf16x3")) h->opt_mlp_bf16x3 = (int)value;
     else return fail(h, M2D_ERR_INVALID_ARG, "m2d_set_option: unknown option");
     return M2D_OK;
@@ -554,6 +555,7 @@ int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value)
     else if (!strcmp(name, "variant")) *value = h->opt_variant;
     else if (!strcmp(name, "topk_bf16x3")) *value = h->opt_topk_bf16x3;
     else if (!strcmp(name, "topk_form")) *value = h->opt_topk_form;
+    else if (!strcmp(name, "topk_grouped")) *value = h->opt_topk_grouped;
     else if (!strcmp(name, "mlp_bf16x3")) *value = h->opt_mlp_bf16x3;
     else if (!strcmp(name, "num_cu")) *value = h->num_cu;
     else return M2D_ERR_INVALID_ARG;

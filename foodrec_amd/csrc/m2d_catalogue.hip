@@ -1740,8 +1740,10 @@ int m2d_launch_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32
 {
     int rc;
     // 0/1 category masks, no ingredient table: contraction over E after sorting dishes by mask pattern
-    if (h->C == 4 && !h->dish_high && k <= 16 && (h->E == 32 || h->E == 64 || h->E == 128) && h->opt_variant != 7 &&
-        h->opt_variant != 8 && h->opt_variant != 9) {
+    // ("topk_grouped" = 0 keeps the dense kernel: dishes then arrive in id order whatever their masks, so exactly tied
+    // scores of dishes with DIFFERENT mask patterns also resolve to the lower id -- see include/m2d.h)
+    if (h->C == 4 && !h->dish_high && k <= 16 && (h->E == 32 || h->E == 64 || h->E == 128) && h->opt_topk_grouped != 0 &&
+        h->opt_variant != 7 && h->opt_variant != 8 && h->opt_variant != 9) {
         if ((rc = ensure_grouped(h, stream)) != M2D_OK) return rc;
         if (h->grp_binary && h->grp_tiles > 0) {
             // "topk_bf16x3" option: 1 = split-bf16 MFMA (E = 64 / 128), 0 = exact-f32 MFMA

@@ -99,7 +99,13 @@ int m2d_rank_candidates(m2d_engine *h, const int32_t *users, const int32_t *item
  * config 5): for each of nU users the k best dishes over all I, descending score, ties to the lower
  * dish id, NaN scores last.  out_scores f32[nU, k], out_ids i32[nU, k].  1 <= k <= 64.
  * Scores agree with m2d_score_pairs_bydish within the 1e-4 bar, not bit for bit (factored form; see the
- * "topk_bf16x3" option below). */
+ * "topk_bf16x3" option below).
+ * Tie rule, precisely: with 0/1 masks, C = 4, k <= 16 the pattern-grouped kernels scan the dishes grouped by mask
+ * pattern, so bit-equal scores resolve to the lower dish id among dishes of ONE pattern (duplicate dishes: the case
+ * the reference's evaluator can meet) and to the lower pattern (bit c = category c), then the lower id, across
+ * patterns -- which only a user vector that scores whole patterns identically (e.g. an all-zero Personal_Memory
+ * block) can produce.  Option "topk_grouped" = 0 selects the dense kernel, which scans in id order and resolves
+ * every tie to the lower id (about 5x the matrix work). */
 int m2d_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, float *out_scores,
                    int32_t *out_ids, void *stream);
 
@@ -208,7 +214,9 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
  * never depend on them.  Two numerical switches, both for build-defined paths: "topk_bf16x3" (default 1) lets
  * m2d_topk_users contract on split-bf16 MFMA (x = hi + lo, three bf16 products, fp32 accumulation; score error
  * ~1e-5 relative, inside the 1e-4 bar) where the mask table is 0/1 and E is 64 or 128; "mlp_bf16x3" (default 1)
- * does the same for layers 1-2 of m2d_score_pairs_mlp; 0 forces the exact-f32 MFMA kernels.
+ * does the same for layers 1-2 of m2d_score_pairs_mlp; 0 forces the exact-f32 MFMA kernels.  "topk_grouped"
+ * (default 1; see m2d_topk_users) and "topk_form" (0 = by shape, 1 / 2 = first / pipelined form of the split-bf16
+ * retrieval kernel; same results) select among retrieval kernels.
  * m2d_score_pairs* (the reference path) is always exact float32.  Unknown names: M2D_ERR_INVALID_ARG. */
 int m2d_set_option(m2d_engine *h, const char *name, int64_t value);
 int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value);

@@ -187,3 +187,37 @@ def test_topk_split_bf16_variant(E, k):
                                    i3.reshape(-1).contiguous()); eng.check()
     err = (s3.reshape(-1) - exact).abs().max().item()
     assert err < 3e-5, err
+
+
+@pytest.mark.parametrize("E", [64, 128, 32])
+def test_cross_pattern_ties_and_the_dense_option(E):
+    """A user whose Personal_Memory block is all zero scores every dish 0: one global tie.  The dense kernel (option
+    topk_grouped = 0) scans in id order and returns the lowest ids; the pattern-grouped kernels return the lowest ids of
+    the lowest mask pattern -- the documented tie rule of m2d_topk_users (include/m2d.h).  Users without such ties get
+    the same lists from both."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    U, I, k = 70, 3000, 10
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=E + 3)
+    PM[5] = 0.0
+    pat = (cats * (1 << np.arange(4))[None, :]).sum(1).astype(np.int64)
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    users = torch.arange(U, dtype=torch.int32, device="cuda")
+    for x3 in (1, 0):
+        eng.set_option("topk_bf16x3", x3)
+        eng.set_option("topk_grouped", 1)
+        sg, ig = eng.topk_users(users, k); eng.check()
+        assert eng.last_kernel().startswith("m2d_topk_grouped")
+        eng.set_option("topk_grouped", 0)
+        sd, idn = eng.topk_users(users, k); eng.check()
+        assert eng.last_kernel() == "m2d_topk_mfma"
+        sg, ig, sd, idn = sg.cpu().numpy(), ig.cpu().numpy(), sd.cpu().numpy(), idn.cpu().numpy()
+        assert np.all(sg[5] == 0) and np.all(sd[5] == 0)
+        assert idn[5].tolist() == list(range(k))                                  # dense: lowest ids
+        low = np.flatnonzero(pat == pat.min())[:k]
+        assert ig[5].tolist() == low.tolist()                                     # grouped: lowest pattern, then lowest ids
+        others = [u for u in range(U) if u != 5]
+        # same scores within the bar; the id lists agree except where two scores are closer than the kernels' rounding
+        assert np.all(np.abs(sg[others] - sd[others]) <= TOL * np.maximum(1.0, np.abs(sd[others])))
+        assert np.mean(np.all(ig[others] == idn[others], axis=1)) > 0.9
