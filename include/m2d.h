@@ -101,11 +101,12 @@ int m2d_rank_candidates(m2d_engine *h, const int32_t *users, const int32_t *item
  * Scores agree with m2d_score_pairs_bydish within the 1e-4 bar, not bit for bit (factored form; see the
  * "topk_bf16x3" option below).
  * Tie rule, precisely: with 0/1 masks, C = 4, k <= 16 the pattern-grouped kernels scan the dishes grouped by mask
- * pattern, so bit-equal scores resolve to the lower dish id among dishes of ONE pattern (duplicate dishes: the case
- * the reference's evaluator can meet) and to the lower pattern (bit c = category c), then the lower id, across
- * patterns -- which only a user vector that scores whole patterns identically (e.g. an all-zero Personal_Memory
- * block) can produce.  Option "topk_grouped" = 0 selects the dense kernel, which scans in id order and resolves
- * every tie to the lower id (about 5x the matrix work). */
+ * pattern (bit c = category c) and, inside a pattern, by descending row norm in 16 coarse buckets, dish id order
+ * inside a bucket; bit-equal scores resolve to the dish scanned first.  Duplicate dishes (same row, same mask: the
+ * case the reference's evaluator can meet) share a bucket, so they resolve to the lower id.  Different rows tie
+ * bit for bit only under a user vector that scores whole groups identically (e.g. an all-zero Personal_Memory block);
+ * those ties follow the scan order, not the id.  Option "topk_grouped" = 0 selects the dense kernel, which scans in
+ * id order and resolves every tie to the lower id (about 5x the matrix work). */
 int m2d_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, float *out_scores,
                    int32_t *out_ids, void *stream);
 

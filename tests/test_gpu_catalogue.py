@@ -192,8 +192,8 @@ def test_topk_split_bf16_variant(E, k):
 @pytest.mark.parametrize("E", [64, 128, 32])
 def test_cross_pattern_ties_and_the_dense_option(E):
     """A user whose Personal_Memory block is all zero scores every dish 0: one global tie.  The dense kernel (option
-    topk_grouped = 0) scans in id order and returns the lowest ids; the pattern-grouped kernels return the lowest ids of
-    the lowest mask pattern -- the documented tie rule of m2d_topk_users (include/m2d.h).  Users without such ties get
+    topk_grouped = 0) scans in id order and returns the lowest ids; the pattern-grouped kernels return dishes of the lowest mask
+    pattern, largest row norms first -- the documented scan order of m2d_topk_users (include/m2d.h).  Users without such ties get
     the same lists from both."""
     import torch
     from foodrec_amd import ScoringEngine
@@ -215,8 +215,12 @@ def test_cross_pattern_ties_and_the_dense_option(E):
         sg, ig, sd, idn = sg.cpu().numpy(), ig.cpu().numpy(), sd.cpu().numpy(), idn.cpu().numpy()
         assert np.all(sg[5] == 0) and np.all(sd[5] == 0)
         assert idn[5].tolist() == list(range(k))                                  # dense: lowest ids
-        low = np.flatnonzero(pat == pat.min())[:k]
-        assert ig[5].tolist() == low.tolist()                                     # grouped: lowest pattern, then lowest ids
+        # grouped: the lowest pattern, and inside it the scan order -- descending row norm in buckets of sigma / 4
+        assert np.all(pat[ig[5]] == pat.min())
+        nrm = np.linalg.norm(RE.astype(np.float64), axis=1)
+        in_pat = np.sort(nrm[pat == pat.min()])[::-1]
+        # (a user's two lanes each keep the first k they scan and merge ties by id: the list comes from the first 2 k scanned)
+        assert nrm[ig[5]].min() >= in_pat[2 * k - 1] - nrm.std() / 4 - 1e-6
         others = [u for u in range(U) if u != 5]
         # same scores within the bar; the id lists agree except where two scores are closer than the kernels' rounding
         assert np.all(np.abs(sg[others] - sd[others]) <= TOL * np.maximum(1.0, np.abs(sd[others])))
