@@ -73,9 +73,10 @@ class UserShardedScorer:
         """Stable bucketing by owner: ``order`` (positions grouped by owner, original order kept inside a bucket),
         ``owner[order]`` and the bucket sizes ``int64[world]`` -- all on the device, no synchronisation."""
         owner = self.owner_of(users)
-        owner_sorted, order = torch.sort(owner, stable=True)
+        # world <= 32767: 16-bit sort keys (a stable radix sort moves a quarter of the key bytes of an int64 sort)
+        owner_sorted, order = torch.sort(owner.to(torch.int16), stable=True)
         counts = torch.bincount(owner, minlength=self.world)
-        return order, owner_sorted, counts
+        return order, owner_sorted.to(torch.int64), counts
 
     def _score_local(self, users, items, cats) -> torch.Tensor:
         if users.numel() == 0:
@@ -133,10 +134,11 @@ class UserShardedScorer:
         dist.all_to_all_single(recv_counts, send_counts, group=self.group)
         sc: List[int] = send_counts.tolist()                          # the one host round trip (two small vectors)
         rc: List[int] = recv_counts.tolist()
-        rec = torch.empty((B, 2 + C), dtype=torch.int32, device=self.device)
-        rec[:, 0] = users[order]
-        rec[:, 1] = items[order]
-        rec[:, 2:] = cats.reshape(B, C).to(torch.float32)[order].view(torch.int32)
+        rec = torch.empty((B, 2 + C), dtype=torch.int32, device=self.device)        # one record per pair, gathered once
+        rec[:, 0] = users
+        rec[:, 1] = items
+        rec[:, 2:] = cats.reshape(B, C).to(torch.float32).view(torch.int32)
+        rec = rec[order]
         got = torch.empty((sum(rc), 2 + C), dtype=torch.int32, device=self.device)
         dist.all_to_all_single(got, rec, rc, sc, group=self.group)
         scores = self._score_local(got[:, 0].contiguous(), got[:, 1].contiguous(),
