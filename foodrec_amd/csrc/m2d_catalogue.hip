@@ -1189,9 +1189,8 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
 //     that step's MFMA groups.  Only a tile in which one lane holds two or more candidates (the first tiles of a
 //     scan, then rare) takes the immediate per-row path.
 // G = groups of 32 users per wave (8 / G waves per block, always 256 users per block).  G = 1 is what is launched.
-// G = 2 (one wave per SIMD, every A fragment feeding two independent MFMA chains) was measured slower at every shape
-// tried (100 k dishes E = 64: 4.7 ms against 3.7; 1 M dishes E = 128: 47.0 against 47.3 for the first form) and is kept
-// only as a template parameter.
+// G = 2 (one wave per SIMD, every A fragment feeding two independent MFMA chains) was measured slower (100 k dishes
+// E = 64: 4.7 ms against 3.7) and is kept only as a template parameter.
 // Thresholds are one insertion stale when tile q-2 is compared: more candidates, never fewer.
 template <int E, int KR, int G>
 __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedArgs p)
@@ -1208,6 +1207,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     constexpr int PSTRIDE = WAVES * 1024;                  // a wave's consecutive pieces: this far apart, source and LDS
     constexpr int S4 = E / 4;                              // float4 per f32 row of Personal_Memory
     constexpr int RPK = 16 / KS;                           // compares of the previous tile per k-step
+    constexpr int AR = KS < 4 ? KS : 4;                    // A-fragment register sets: the LDS reads run AR k-steps ahead
     static_assert(PIECES % WAVES == 0 && (WAVES * 64) % S8 == 0 && ((WAVES * 64 / S8) / RPB) % S8 == 0, "piece layout");
 
     extern __shared__ __align__(16) unsigned char smem8[];
@@ -1311,7 +1311,11 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     const int key = (j / RPB) & (S8 - 1);
     const int lane_off = j * ROW_BYTES + ((h ^ key) << 4);
 
-    bf16x8 ah[KS], al[KS];                                 // A fragments of the tile whose MFMAs come next
+    // A fragments, AR k-steps deep: set ks % AR holds k-step ks of the tile being multiplied and is refilled, as soon as
+    // its three MFMAs are issued, with the k-step AR further on in the (tile, k) stream -- the same tile's at E = 128
+    // (8 k-steps, 4 sets: 32 VGPRs instead of 64, which is what keeps this form under 256 registers there), the next
+    // tile's at E = 64
+    bf16x8 ah[AR], al[AR];
     v16f acc0[G], acc1[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -1326,7 +1330,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         __syncthreads();
         issue_pieces(1, 0, PCNT);                          // what step "0" of the first stage would have issued
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {                  // L(0)
+        for (int ks = 0; ks < AR; ++ks) {                  // the first AR k-steps of tile 0
             const unsigned char *a = smem8 + (lane_off ^ (ks << 5));
             ah[ks] = *reinterpret_cast<const bf16x8 *>(a);
             al[ks] = *reinterpret_cast<const bf16x8 *>(a + 32 * ROW_BYTES);
@@ -1348,8 +1352,8 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
 
     // the interleaved body: M(q-1) into accN, L(q), the compares + max tree of tile q-2 (accP), and -- INS -- the
     // parked insertion, slot ranges from the end of the list up, one range per k-step group
-    auto body = [&](auto ins_tag, v16f (&accN)[G], const v16f (&accP)[G], const int img_off, const float (&thr_rel)[G],
-                    uint32_t (&rowmap)[G], float (&mx)[G]) __attribute__((always_inline)) {
+    auto body = [&](auto ins_tag, v16f (&accN)[G], const v16f (&accP)[G], const int img_prev, const int img_off,
+                    const float (&thr_rel)[G], uint32_t (&rowmap)[G], float (&mx)[G]) __attribute__((always_inline)) {
         constexpr bool INS = decltype(ins_tag)::value;
         float x[G];
 #pragma unroll
@@ -1361,15 +1365,17 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
+            const int st = ks % AR;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks], wh[g][ks], ks == 0 ? zero16 : accN[g], 0, 0, 0);
-                accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], wl[g][ks], accN[g], 0, 0, 0);
-                accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], wh[g][ks], accN[g], 0, 0, 0);
+                accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[st], wh[g][ks], ks == 0 ? zero16 : accN[g], 0, 0, 0);
+                accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], wl[g][ks], accN[g], 0, 0, 0);
+                accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], wh[g][ks], accN[g], 0, 0, 0);
             }
-            const unsigned char *a = smem8 + (img_off ^ (ks << 5));
-            ah[ks] = *reinterpret_cast<const bf16x8 *>(a);
-            al[ks] = *reinterpret_cast<const bf16x8 *>(a + 32 * ROW_BYTES);
+            // k-step ks + AR of this tile (q-1), or k-step ks + AR - KS of the next (q)
+            const unsigned char *a = smem8 + (ks + AR < KS ? (img_prev ^ ((ks + AR) << 5)) : (img_off ^ ((ks + AR - KS) << 5)));
+            ah[st] = *reinterpret_cast<const bf16x8 *>(a);
+            al[st] = *reinterpret_cast<const bf16x8 *>(a + 32 * ROW_BYTES);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
 #pragma unroll
@@ -1463,10 +1469,11 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
 #pragma unroll
         for (int g = 0; g < G; ++g) thr_rel[g] = thr[g] - alpha_prev[g];
         const int img_off = (int)(((q / TPS) & 1) * STAGE_BYTES + sub * TILE_BYTES) + lane_off;   // tile q
+        const int img_prev = (int)((((q - 1) / TPS) & 1) * STAGE_BYTES + ((q - 1) & (TPS - 1)) * TILE_BYTES) + lane_off;
         uint32_t rowmap[G];                                // bit 15 - r: row r of tile q-2 beats this lane's threshold
         float mx[G];
-        if (pend) body(std::true_type{}, accN, accP, img_off, thr_rel, rowmap, mx);
-        else body(std::false_type{}, accN, accP, img_off, thr_rel, rowmap, mx);
+        if (pend) body(std::true_type{}, accN, accP, img_prev, img_off, thr_rel, rowmap, mx);
+        else body(std::false_type{}, accN, accP, img_prev, img_off, thr_rel, rowmap, mx);
         if (nvalid < 32) {                                 // a group's last tile, or a dummy tile: padding rows never rank
 #pragma unroll
             for (int g = 0; g < G; ++g) {
@@ -1718,9 +1725,9 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     float *tmp_s = h->scratch ? h->scratch + (size_t)2 * nU * nsplit * k : nullptr;
     int32_t *tmp_i = reinterpret_cast<int32_t *>(tmp_s ? tmp_s + tmp_entries : nullptr);
     if constexpr (BF16X3) {
-        // "topk_form": 0 = by shape (pipelined at E = 64; at E = 128 its 256 VGPRs spill and the first form is faster:
-        // 1 M dishes 50.8 ms against 47.3), 1 = first form, 2 = pipelined
-        const bool pipe = h->opt_topk_form == 2 || (h->opt_topk_form == 0 && E == 64);
+        // "topk_form": 0 or 2 = pipelined form (E = 64: 2.55 ms against 3.3 at 100 k dishes; E = 128: 38.3 ms against
+        // 45.4 at 1 M dishes), 1 = first form (kept as the A/B reference)
+        const bool pipe = h->opt_topk_form != 1;
         if (!pipe) {
             auto kern = m2d_topk_grouped_bf16<E, WAVES, KR>;
             M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -78,7 +78,7 @@ struct m2d_engine {
     int opt_mlp_bf16x3 = 1;             // MLP head layer 1 (build-defined) on split-bf16 MFMA; 0 = exact-f32 MFMA
     int opt_topk_bf16x3 = 1;            // retrieval (build-defined) on split-bf16 MFMA; 0 = exact-f32 MFMA
     int opt_topk_grouped = 1;           // 0/1-mask catalogues: pattern-grouped retrieval (contraction over E); 0 = dense kernel
-    int opt_topk_form = 0;              // split-bf16 retrieval kernel: 0 = by shape, 1 = first form, 2 = pipelined form
+    int opt_topk_form = 0;              // split-bf16 retrieval kernel: 0 / 2 = pipelined form, 1 = first form
 
     std::string last_error;
     const char *last_kernel = "";

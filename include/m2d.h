@@ -216,8 +216,8 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
  * m2d_topk_users contract on split-bf16 MFMA (x = hi + lo, three bf16 products, fp32 accumulation; score error
  * ~1e-5 relative, inside the 1e-4 bar) where the mask table is 0/1 and E is 64 or 128; "mlp_bf16x3" (default 1)
  * does the same for layers 1-2 of m2d_score_pairs_mlp; 0 forces the exact-f32 MFMA kernels.  "topk_grouped"
- * (default 1; see m2d_topk_users) and "topk_form" (0 = by shape, 1 / 2 = first / pipelined form of the split-bf16
- * retrieval kernel; same results) select among retrieval kernels.
+ * (default 1; see m2d_topk_users) and "topk_form" (0 / 2 = the pipelined split-bf16 retrieval kernel, 1 = its first
+ * form; same results) select among retrieval kernels.
  * m2d_score_pairs* (the reference path) is always exact float32.  Unknown names: M2D_ERR_INVALID_ARG. */
 int m2d_set_option(m2d_engine *h, const char *name, int64_t value);
 int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value);

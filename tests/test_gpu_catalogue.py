@@ -225,3 +225,28 @@ def test_cross_pattern_ties_and_the_dense_option(E):
         # same scores within the bar; the id lists agree except where two scores are closer than the kernels' rounding
         assert np.all(np.abs(sg[others] - sd[others]) <= TOL * np.maximum(1.0, np.abs(sd[others])))
         assert np.mean(np.all(ig[others] == idn[others], axis=1)) > 0.9
+
+
+@pytest.mark.parametrize("E,k", [(64, 10), (128, 10), (64, 16), (128, 13)])
+def test_both_forms_of_the_split_bf16_kernel_agree(E, k):
+    """Option topk_form: 1 = first form, 0 / 2 = pipelined form (the default).  Same contraction, same lists; the
+    pipelined form adds alpha_P when a score enters a list instead of starting the accumulator from it, so scores may
+    differ in the last bits."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    U, I = 300, 5000
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=7 * E + k, n_nan=3, dup=40)
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    users = torch.arange(U, dtype=torch.int32, device="cuda")
+    out = {}
+    for form in (1, 2):
+        eng.set_option("topk_form", form)
+        s, i = eng.topk_users(users, k); eng.check()
+        assert eng.last_kernel() == "m2d_topk_grouped_bf16x3"
+        out[form] = (s.cpu().numpy(), i.cpu().numpy())
+    (s1, i1), (s2, i2) = out[1], out[2]
+    assert np.all(np.abs(s1 - s2) <= 1e-5 * np.maximum(1.0, np.abs(s1)))
+    assert np.mean(np.all(i1 == i2, axis=1)) > 0.95
+    eng.set_option("topk_form", 1)
+    _check(eng, PM, RE, CE, cats, np.arange(0, U, 7), k)                # the first form on its own against the oracle
