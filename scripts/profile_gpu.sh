@@ -6,7 +6,7 @@ TAG=${1:-r01}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH_ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-side $@"
+BENCH_ARGS="--steps 50 --warmup 5 --no-cpu-baseline --no-side $@"
 echo "[profile] stats pass"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py $BENCH_ARGS > $OUT/stats_bench.json 2> $OUT/stats.log
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
