@@ -64,6 +64,8 @@ def parse():
                         "training step (SURVEY.md 8f N4) at its own default sizes unless --users/--dishes/--embed/--pairs "
                         "are given: loss + gradients + clip + optimizer update per step, single GPU")
     p.add_argument("--ingredients", type=int, default=10_000, help="rows of the ingredient table (workload ingredients)")
+    p.add_argument("--topk-with-ingredients", action="store_true",
+                   help="workload topk: set the ingredient table first (retrieval over [H[d] | RE[d]] rows, E = 32 / 64)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     p.add_argument("--topk-users", type=int, default=65536, help="users in the catalogue top-k side leg (0 = skip)")
@@ -570,7 +572,7 @@ def main():
     if wl == "mlp":
         rn = lambda *shape: torch.randn(shape, generator=g, device=dev)
         eng.set_mlp_head(rn(K, 256) / K ** 0.5, rn(256) * 0.1, rn(256, 64) / 16.0, rn(64) * 0.1, rn(64) / 8.0, 0.0)
-    if wl == "ingredients":
+    if wl == "ingredients" or (wl == "topk" and a.topk_with_ingredients):
         R = a.ingredients
         lens = torch.randint(1, 21, (I,), generator=g, device=dev)          # 1..20 ingredients per dish (build-chosen)
         off = torch.zeros(I + 1, dtype=torch.int32, device=dev)
@@ -725,13 +727,15 @@ def main():
                 line["roofline"]["frac"] = ach / HBM_PEAK_GBS
         if wl == "topk":
             x3 = kernel_used.endswith("bf16x3")
-            fl = (2.0 * E * (3 if x3 else 1) if kernel_used.startswith("m2d_topk_grouped") else 2.0 * K) * units
+            Ew = 2 * E if a.topk_with_ingredients else E                 # grouped rows are [H[d] | RE[d]] with the ingredient table
+            fl = (2.0 * Ew * (3 if x3 else 1) if kernel_used.startswith("m2d_topk_grouped") else 2.0 * K) * units
             tf = fl / (avg_ms * 1e-3) / 1e12
             peak = 2500.0 if x3 else 157.3
             line["config"]["workload"] = ("BASELINE configs[3]/[4] retrieval: full-catalogue top-10 for %d users per GPU over %d "
                                           "replicated dishes (users from this GPU's %d-user shard), E=%d, then all-gather of "
                                           "[users,10] x (f32 score, i32 id); build-defined generalisation of evaluate.py:39-63"
-                                          % (tk_users.numel(), I, U, E))
+                                          % (tk_users.numel(), I, U, E)) + (
+                " -- WITH the build-defined ingredient table (%d rows, 1-20 per dish)" % a.ingredients if a.topk_with_ingredients else "")
             line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                                 "traffic": None, "step_avg_ms": avg_ms, "flop_per_pair_executed": fl / units,
                                 "dense_equivalent_tflops": 2.0 * K * units / (avg_ms * 1e-3) / 1e12,

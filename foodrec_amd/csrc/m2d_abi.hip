@@ -299,6 +299,7 @@ int m2d_clear_ingredients(m2d_engine *h)
     h->ing = nullptr; h->ing_off = nullptr; h->ing_ids = nullptr; h->ing_w = nullptr; h->dish_high = nullptr;
     h->own_ing = false; h->ing_rows = 0; h->ing_nnz = 0;
     h->dish_vec_valid = false;
+    h->grp_valid = false;               // the pattern-grouped retrieval rows carry H[d] when it is set
     return M2D_OK;
 }
 
@@ -351,6 +352,7 @@ int m2d_set_ingredients(m2d_engine *h, const float *ing, int64_t R, const int32_
         return M2D_ERR_BAD_INGREDIENT;
     }
     h->dish_vec_valid = false;
+    h->grp_valid = false;
     return M2D_OK;
 }
 

@@ -698,18 +698,22 @@ __global__ __launch_bounds__(256) void m2d_grp_scatter(const float *cats, const 
 }
 
 // one wave per slot: RS[slot] = RE[perm[slot]] (zeros for padding), plus the split-bf16 image used by
-// m2d_topk_grouped_bf16: per 32-row tile [hi: 32 x E bf16][lo: 32 x E bf16], x ~= hi + lo to 2^-17 |x|
-__global__ __launch_bounds__(256) void m2d_grp_gather(const float *re, const int32_t *perm, int64_t slots, int E,
-                                                      float *rs, __bf16 *rs16)
+// m2d_topk_grouped_bf16: per 32-row tile [hi: 32 x EW bf16][lo: 32 x EW bf16], x ~= hi + lo to 2^-17 |x|.
+// With the ingredient extension (hv = H[d]) a slot's row is [H[d] | RE[d]], EW = 2 E: the high-level
+// term <a U_high, H[d]> then rides in the same contraction as the low-level one (see GroupedArgs::hv).
+__global__ __launch_bounds__(256) void m2d_grp_gather(const float *re, const float *hv, const int32_t *perm, int64_t slots,
+                                                      int E, float *rs, __bf16 *rs16)
 {
     const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= slots) return;
     const int32_t d = perm[slot];
-    __bf16 *hi = rs16 + ((slot >> 5) * 64 + (slot & 31)) * (size_t)E;
-    __bf16 *lo = hi + 32 * (size_t)E;
-    for (int e = threadIdx.x & 63; e < E; e += 64) {
-        const float x = d >= 0 ? re[(size_t)d * E + e] : 0.f;
-        rs[slot * E + e] = x;
+    const int EW = hv ? 2 * E : E;
+    __bf16 *hi = rs16 + ((slot >> 5) * 64 + (slot & 31)) * (size_t)EW;
+    __bf16 *lo = hi + 32 * (size_t)EW;
+    for (int e = threadIdx.x & 63; e < EW; e += 64) {
+        float x = 0.f;
+        if (d >= 0) x = hv ? (e < E ? hv[(size_t)d * E + e] : re[(size_t)d * E + e - E]) : re[(size_t)d * E + e];
+        rs[slot * EW + e] = x;
         const __bf16 xh = (__bf16)x;
         hi[e] = xh;
         lo[e] = (__bf16)(x - (float)xh);
@@ -719,7 +723,8 @@ __global__ __launch_bounds__(256) void m2d_grp_gather(const float *re, const int
 struct GroupedArgs {
     const float *pm;         // [U, (C+1) E]
     const float *ce;         // [C, E]
-    const float *rs;         // [slots, E]   Recipe_Embedding rows sorted by (pattern, dish id)
+    const float *rs;         // [slots, EW]  Recipe_Embedding rows sorted by (pattern, norm bucket, dish id); with the
+                             //              ingredient extension [H[d] | RE[d]], EW = 2 E
     const __bf16 *rs16;      // the same rows as split bf16 (hi | lo blocks per 32-row tile)
     const int32_t *perm;     // [slots]      slot -> dish id (-1 = padding)
     const int32_t *tile_info;
@@ -1192,7 +1197,9 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
 // G = 2 (one wave per SIMD, every A fragment feeding two independent MFMA chains) was measured slower (100 k dishes
 // E = 64: 4.7 ms against 3.7) and is kept only as a template parameter.
 // Thresholds are one insertion stale when tile q-2 is compared: more candidates, never fewer.
-template <int E, int KR, int G>
+// HV = true: the ingredient extension.  Dish rows are [H[d] | RE[d]] (E = 2 x the embedding width) and the user operand
+// is [a U_high | w_P]: score = <a U_high, H[d]> + <w_P, RE[d]>, no alpha_P term.
+template <int E, int KR, int G, bool HV = false>
 __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedArgs p)
 {
     constexpr int C = 4, WAVES = 8 / G;
@@ -1205,7 +1212,8 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     constexpr int PPW = PIECES / WAVES;                    // 1-KiB DMA pieces per wave per stage
     constexpr int PCNT = (PPW + TPS - 2) / (TPS - 1);      // pieces issued per step (none in a stage's last step)
     constexpr int PSTRIDE = WAVES * 1024;                  // a wave's consecutive pieces: this far apart, source and LDS
-    constexpr int S4 = E / 4;                              // float4 per f32 row of Personal_Memory
+    constexpr int EU = HV ? E / 2 : E;                     // embedding width of the user tables
+    constexpr int S4 = EU / 4;                             // float4 per f32 row of Personal_Memory
     constexpr int RPK = 16 / KS;                           // compares of the previous tile per k-step
     constexpr int AR = KS < 4 ? KS : 4;                    // A-fragment register sets: the LDS reads run AR k-steps ahead
     static_assert(PIECES % WAVES == 0 && (WAVES * 64) % S8 == 0 && ((WAVES * 64 / S8) / RPB) % S8 == 0, "piece layout");
@@ -1241,7 +1249,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
 #pragma unroll
         for (int c = 0; c < C; ++c) hc[g][c] = 0.f;
 #pragma unroll 1
-        for (int q = 0; q < S4; ++q) {
+        for (int q = 0; q < (HV ? 0 : S4); ++q) {          // HV: the category sum is replaced by H[d], inside the contraction
             const v4f u = pmu[g][q];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
@@ -1437,20 +1445,27 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
                     float hs = 0.f;
 #pragma unroll
                     for (int c = 0; c < C; ++c) hs += ((pat >> c) & 1) ? hc[g][c] : 0.f;
-                    alpha[g] = p.a * (hs * inv_n);
+                    alpha[g] = HV ? 0.f : p.a * (hs * inv_n);
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {                   // unrolled: every register index is static
                         v4f w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+                        if (HV && ks < KS / 2) {                        // k < EU: a U_high against H[d]
+                            const v4f *row = pmu[g] + 4 * ks + 2 * h;
+                            w0 = row[0] * p.a;
+                            w1 = row[1] * p.a;
+                        } else {
+                            const int kk = HV ? ks - KS / 2 : ks;       // k - EU: w_P against RE[d]
 #pragma unroll
-                        for (int c = 0; c < C; ++c) {
-                            if ((pat >> c) & 1) {
-                                const v4f *row = pmu[g] + (c + 1) * S4 + 4 * ks + 2 * h;
-                                w0 += row[0];
-                                w1 += row[1];
+                            for (int c = 0; c < C; ++c) {
+                                if ((pat >> c) & 1) {
+                                    const v4f *row = pmu[g] + (c + 1) * S4 + 4 * kk + 2 * h;
+                                    w0 += row[0];
+                                    w1 += row[1];
+                                }
                             }
+                            w0 *= beta;
+                            w1 *= beta;
                         }
-                        w0 *= beta;
-                        w1 *= beta;
                         const float xx[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
                         bf16x8 vh, vl;
 #pragma unroll
@@ -1597,17 +1612,19 @@ int ensure_grouped(m2d_engine *h, hipStream_t st)
     const int nblk = (int)((I + 255) / 256);
     const int64_t max_tiles = (I + 31) / 32 + GRP_MAXPAT;
     const int64_t cap_rows = (max_tiles + 16) * 32;          // + one stage of zero rows past the last tile
-    if (h->grp_cap_rows != cap_rows || !h->grp_rs) {
+    const int EW = h->dish_high ? 2 * h->E : h->E;           // ingredient extension: rows are [H[d] | RE[d]]
+    if (h->grp_cap_rows != cap_rows || h->grp_ew != EW || !h->grp_rs) {
         for (void *q : {(void *)h->grp_rs, (void *)h->grp_rs16, (void *)h->grp_perm, (void *)h->grp_tile_info, (void *)h->grp_work})
             if (q) M2D_HIP_TRY(h, hipFree(q));
         h->grp_rs = nullptr; h->grp_rs16 = nullptr; h->grp_perm = nullptr; h->grp_tile_info = nullptr; h->grp_work = nullptr;
-        M2D_HIP_TRY(h, hipMalloc((void **)&h->grp_rs, (size_t)cap_rows * h->E * sizeof(float)));
-        M2D_HIP_TRY(h, hipMalloc((void **)&h->grp_rs16, (size_t)cap_rows * h->E * 4));
+        M2D_HIP_TRY(h, hipMalloc((void **)&h->grp_rs, (size_t)cap_rows * EW * sizeof(float)));
+        M2D_HIP_TRY(h, hipMalloc((void **)&h->grp_rs16, (size_t)cap_rows * EW * 4));
         M2D_HIP_TRY(h, hipMalloc((void **)&h->grp_perm, (size_t)cap_rows * sizeof(int32_t)));
         M2D_HIP_TRY(h, hipMalloc((void **)&h->grp_tile_info, (size_t)max_tiles * sizeof(int32_t)));
         M2D_HIP_TRY(h, hipMalloc((void **)&h->grp_work, ((size_t)nblk * GRP_KEYS + GRP_WORDS + 2 * 2) * sizeof(int32_t) +
                                                         (size_t)I * sizeof(float)));
         h->grp_cap_rows = cap_rows;
+        h->grp_ew = EW;
     }
     int32_t *blk_hist = h->grp_work, *grp = h->grp_work + (size_t)nblk * GRP_KEYS, *flags = grp + 32;
     float *stat = reinterpret_cast<float *>(grp + GRP_STAT);
@@ -1616,13 +1633,14 @@ int ensure_grouped(m2d_engine *h, hipStream_t st)
     M2D_HIP_TRY(h, hipMemsetAsync(flags, 0, sizeof(int32_t), st));
     M2D_HIP_TRY(h, hipMemsetAsync(acc, 0, 2 * sizeof(double), st));
     M2D_HIP_TRY(h, hipMemsetAsync(h->grp_perm, 0xFF, (size_t)cap_rows * sizeof(int32_t), st));
-    hipLaunchKernelGGL(m2d_grp_norm_stats, dim3(nblk), dim3(256), 0, st, h->re, I, h->E, norm, acc);
+    // scan order by the norm of the row that carries the larger term: H[d] (weight a) when the ingredient table is set
+    hipLaunchKernelGGL(m2d_grp_norm_stats, dim3(nblk), dim3(256), 0, st, h->dish_high ? h->dish_high : h->re, I, h->E, norm, acc);
     hipLaunchKernelGGL(m2d_grp_norm_params, dim3(1), dim3(1), 0, st, acc, I, stat);
     hipLaunchKernelGGL(m2d_grp_hist, dim3(nblk), dim3(256), 0, st, h->dish_cats, norm, stat, I, h->C, blk_hist, flags);
     hipLaunchKernelGGL(m2d_grp_scan, dim3(1), dim3(GRP_KEYS), 0, st, blk_hist, nblk, grp, h->grp_tile_info);
     hipLaunchKernelGGL(m2d_grp_scatter, dim3(nblk), dim3(256), 0, st, h->dish_cats, norm, stat, I, h->C, blk_hist, grp, h->grp_perm);
-    hipLaunchKernelGGL(m2d_grp_gather, dim3((unsigned)((cap_rows + 3) / 4)), dim3(256), 0, st, h->re, h->grp_perm,
-                       cap_rows, h->E, h->grp_rs, reinterpret_cast<__bf16 *>(h->grp_rs16));
+    hipLaunchKernelGGL(m2d_grp_gather, dim3((unsigned)((cap_rows + 3) / 4)), dim3(256), 0, st, h->re, h->dish_high,
+                       h->grp_perm, cap_rows, h->E, h->grp_rs, reinterpret_cast<__bf16 *>(h->grp_rs16));
     M2D_HIP_TRY(h, hipGetLastError());
     int32_t host[3] = {0, 0, 0};   // tiles, slots, flags  (a table build may synchronise)
     M2D_HIP_TRY(h, hipMemcpyAsync(host, grp + 16, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1691,10 +1709,11 @@ int pick_splits(m2d_engine *h, int64_t ublocks, int64_t tiles, int64_t min_tiles
     return nsplit;
 }
 
-template <int E8, int WAVES, int KR, bool BF16X3>
+template <int E8, int WAVES, int KR, bool BF16X3, bool HV = false>
 int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, float *final_s, int32_t *final_i,
                    hipStream_t st)
 {
+    static_assert(!HV || BF16X3, "the ingredient form exists for the pipelined split-bf16 kernel only");
     constexpr int E = E8 * 8;
     constexpr int TPS = E <= 32 ? 16 : (E == 64 ? 8 : 4);
     const size_t lds = (size_t)2 * TPS * 32 * E * sizeof(float);
@@ -1727,8 +1746,12 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     if constexpr (BF16X3) {
         // "topk_form": 0 or 2 = pipelined form (E = 64: 2.55 ms against 3.3 at 100 k dishes; E = 128: 38.3 ms against
         // 45.4 at 1 M dishes), 1 = first form (kept as the A/B reference)
-        const bool pipe = h->opt_topk_form != 1;
-        if (!pipe) {
+        const bool pipe = HV || h->opt_topk_form != 1;
+        if constexpr (HV) {
+            auto kern = m2d_topk_grouped_bf16_pipe2<E, KR, 1, true>;
+            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(512), lds, st, a);
+        } else if (!pipe) {
             auto kern = m2d_topk_grouped_bf16<E, WAVES, KR>;
             M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(WAVES * 64), lds, st, a);
@@ -1816,10 +1839,19 @@ int m2d_launch_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32
     // 0/1 category masks, no ingredient table: contraction over E after sorting dishes by mask pattern
     // ("topk_grouped" = 0 keeps the dense kernel: dishes then arrive in id order whatever their masks, so exactly tied
     // scores of dishes with DIFFERENT mask patterns also resolve to the lower id -- see include/m2d.h)
-    if (h->C == 4 && !h->dish_high && k <= 16 && (h->E == 32 || h->E == 64 || h->E == 128) && h->opt_topk_grouped != 0 &&
-        h->opt_variant != 7 && h->opt_variant != 8 && h->opt_variant != 9) {
+    // ingredient extension: rows [H[d] | RE[d]] of width 2 E on the pipelined split-bf16 kernel (E = 32 / 64)
+    const bool hv_ok = h->dish_high && h->opt_topk_bf16x3 != 0 && (h->E == 32 || h->E == 64);
+    if (h->C == 4 && (!h->dish_high || hv_ok) && k <= 16 && (h->E == 32 || h->E == 64 || h->E == 128) &&
+        h->opt_topk_grouped != 0 && h->opt_variant != 7 && h->opt_variant != 8 && h->opt_variant != 9) {
         if ((rc = ensure_grouped(h, stream)) != M2D_OK) return rc;
-        if (h->grp_binary && h->grp_tiles > 0) {
+        if (hv_ok && h->grp_binary && h->grp_tiles > 0) {
+            if (h->E == 32)
+                return k <= 10 ? launch_grouped<8, 8, 10, true, true>(h, users, nU, k, out_scores, out_ids, stream)
+                               : launch_grouped<8, 8, 16, true, true>(h, users, nU, k, out_scores, out_ids, stream);
+            return k <= 10 ? launch_grouped<16, 8, 10, true, true>(h, users, nU, k, out_scores, out_ids, stream)
+                           : launch_grouped<16, 8, 16, true, true>(h, users, nU, k, out_scores, out_ids, stream);
+        }
+        if (!h->dish_high && h->grp_binary && h->grp_tiles > 0) {
             // "topk_bf16x3" option: 1 = split-bf16 MFMA (E = 64 / 128), 0 = exact-f32 MFMA
             const bool x3 = h->opt_topk_bf16x3 != 0 && (h->E == 64 || h->E == 128);
 #define M2D_GRP(EV, X3)                                                                                       \

@@ -57,6 +57,7 @@ struct m2d_engine {
     int32_t *grp_tile_info = nullptr;   // [tiles]           pattern | valid rows << 8
     int32_t *grp_work = nullptr;        // block histograms / group offsets / flags
     int64_t grp_tiles = 0, grp_cap_rows = 0;
+    int grp_ew = 0;                     // row width of grp_rs: E, or 2 E with the ingredient extension ([H[d] | RE[d]])
     bool grp_valid = false, grp_binary = false;
 
     // training step: optimizer slots and gradient scratch, created by m2d_train_begin

@@ -100,6 +100,8 @@ int m2d_rank_candidates(m2d_engine *h, const int32_t *users, const int32_t *item
  * dish id, NaN scores last.  out_scores f32[nU, k], out_ids i32[nU, k].  1 <= k <= 64.
  * Scores agree with m2d_score_pairs_bydish within the 1e-4 bar, not bit for bit (factored form; see the
  * "topk_bf16x3" option below).
+ * With the ingredient table set (m2d_set_ingredients) the high-level term uses H[d]; E = 32 / 64 stay on the
+ * pattern-grouped split-bf16 kernel (rows [H[d] | RE[d]]), other shapes use the dense kernel.
  * Tie rule, precisely: with 0/1 masks, C = 4, k <= 16 the pattern-grouped kernels scan the dishes grouped by mask
  * pattern (bit c = category c) and, inside a pattern, by descending row norm in 16 coarse buckets, dish id order
  * inside a bucket; bit-equal scores resolve to the dish scanned first.  Duplicate dishes (same row, same mask: the
