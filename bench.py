@@ -30,6 +30,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -74,6 +75,9 @@ def parse():
                    help="profiling aid: every user at most once per step (pairs <= users), no table reuse")
     p.add_argument("--sweep", action="store_true", help="also time the kernel knobs (stderr only)")
     p.add_argument("--opt", action="append", default=[], help="engine option name=value")
+    p.add_argument("--side-timeout", type=float, default=420.0,
+                   help="seconds the legs after the timed region may take before rank 0 prints the headline line without "
+                        "them and every rank exits (a collective that never completes must not cost the line)")
     p.add_argument("--dry-run", action="store_true",
                    help="launch plumbing only (CPU, gloo): the ranks rendezvous, exchange their shard ranges and rank 0 "
                         "prints a line with value null -- nothing is scored, no GPU is touched (tests/test_bench_contract.py)")
@@ -622,35 +626,8 @@ def main():
     Bc = min(1 << 18, B)
     timed_sample = out[:Bc].clone() if wl == "pairs" else None           # parity sample of the TIMED kernel's scores
 
-    # N > 1: the user-sharded retrieval step and the owner-routed pair step (outside the timed region, repeated)
-    topk_ag = routed = None
-    if use_dist and not a.no_side and wl == "pairs":
-        if a.topk_users > 0:
-            try:
-                topk_ag = sharded_topk_leg(torch, dist, eng, U, I, C, E, dev, user_base, min(a.topk_users, U), world)
-            except Exception as e:                                     # noqa: BLE001 -- never lose the headline line
-                topk_ag = {"error": "%s: %s" % (type(e).__name__, e)}
-                dist.barrier()
-        try:
-            routed = routed_pairs_leg(torch, dist, eng, U, I, C, dev, world, min(B, 1 << 22))
-        except Exception as e:                                         # noqa: BLE001
-            routed = {"error": "%s: %s" % (type(e).__name__, e)}
-
-    if a.sweep and rank == 0:
-        so = torch.empty_like(out)
-        for pf in (1, 2, 4):
-            for nt in (0, 1):
-                for bpc in (2, 4, 8, 16):
-                    eng.set_option("prefetch", pf); eng.set_option("nt_loads", nt); eng.set_option("blocks_per_cu", bpc)
-                    time_steps(torch, eng, users, items, cats, so, 3)
-                    w, per = time_steps(torch, eng, users, items, cats, so, 10)
-                    ms = sorted(per)[len(per) // 2]
-                    print("sweep pf=%d nt=%d blocks_per_cu=%2d: %.3f ms  %.2f Gpairs/s  %.0f GB/s" %
-                          (pf, nt, bpc, ms, B / ms / 1e6, B * algorithmic_bytes_per_pair(C, E) / ms / 1e6), file=sys.stderr)
-        for k, v in opts_used.items():
-            eng.set_option(k, v)
-
     rc = 0
+    line = None
     if rank == 0:
         bpp = algorithmic_bytes_per_pair(C, E)
         avg_ms = sum(per_launch_ms) / len(per_launch_ms)
@@ -687,6 +664,47 @@ def main():
                          "kernel_avg_ms": avg_ms, "algorithmic_bytes_per_pair": bpp, "pairs_per_launch": B,
                          "table_bytes": table_bytes},
         }
+
+    # the headline is complete here; everything below decorates it.  Should a leg never return (a collective that
+    # does not complete on some rank), rank 0 still prints the line and every rank leaves.
+    def give_up():
+        if rank == 0:
+            line["side_legs"] = "not finished within %.0f s: headline line only" % a.side_timeout
+            print(json.dumps(line))
+            sys.stdout.flush()
+        os._exit(0)
+    watchdog = threading.Timer(a.side_timeout, give_up)
+    watchdog.daemon = True
+    watchdog.start()
+
+    # N > 1: the user-sharded retrieval step and the owner-routed pair step (outside the timed region, repeated)
+    topk_ag = routed = None
+    if use_dist and not a.no_side and wl == "pairs":
+        if a.topk_users > 0:
+            try:
+                topk_ag = sharded_topk_leg(torch, dist, eng, U, I, C, E, dev, user_base, min(a.topk_users, U), world)
+            except Exception as e:                                     # noqa: BLE001 -- never lose the headline line
+                topk_ag = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            routed = routed_pairs_leg(torch, dist, eng, U, I, C, dev, world, min(B, 1 << 22))
+        except Exception as e:                                         # noqa: BLE001
+            routed = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    if a.sweep and rank == 0:
+        so = torch.empty_like(out)
+        for pf in (1, 2, 4):
+            for nt in (0, 1):
+                for bpc in (2, 4, 8, 16):
+                    eng.set_option("prefetch", pf); eng.set_option("nt_loads", nt); eng.set_option("blocks_per_cu", bpc)
+                    time_steps(torch, eng, users, items, cats, so, 3)
+                    w, per = time_steps(torch, eng, users, items, cats, so, 10)
+                    ms = sorted(per)[len(per) // 2]
+                    print("sweep pf=%d nt=%d blocks_per_cu=%2d: %.3f ms  %.2f Gpairs/s  %.0f GB/s" %
+                          (pf, nt, bpc, ms, B / ms / 1e6, B * algorithmic_bytes_per_pair(C, E) / ms / 1e6), file=sys.stderr)
+        for k, v in opts_used.items():
+            eng.set_option(k, v)
+
+    if rank == 0:
         if cache_resident and wl in ("pairs", "ingredients"):
             # both tables stay in the 256 MiB Infinity Cache between launches: the algorithmic rate is a cache rate and can
             # exceed the HBM peak, so no HBM fraction is published for this shape
@@ -781,11 +799,13 @@ def main():
                 rc = 3
                 print("bench.py: PARITY FAILURE: timed kernel vs CPU restatement, max |d| / max(1, |ref|) = %.3e > %.0e"
                       % (err, PARITY_TOL), file=sys.stderr)
+        watchdog.cancel()
         print(json.dumps(line))
         sys.stdout.flush()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    watchdog.cancel()
     if rc:
         sys.exit(rc)
 
