@@ -1361,14 +1361,13 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     // the interleaved body: M(q-1) into accN, L(q), the compares + max tree of tile q-2 (accP), and -- INS -- the
     // parked insertion, slot ranges from the end of the list up, one range per k-step group
     auto body = [&](auto ins_tag, v16f (&accN)[G], const v16f (&accP)[G], const int img_prev, const int img_off,
-                    const float (&thr_rel)[G], uint32_t (&rowmap)[G], float (&mx)[G]) __attribute__((always_inline)) {
+                    const float (&thr_rel)[G], unsigned long long (&m)[G][16], float (&mx)[G]) __attribute__((always_inline)) {
         constexpr bool INS = decltype(ins_tag)::value;
         float x[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             x[g] = fmaxf(px[g], -INFINITY);
             mx[g] = -INFINITY;
-            rowmap[g] = 0u;
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1388,8 +1387,8 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
             for (int g = 0; g < G; ++g) {
 #pragma unroll
                 for (int r = ks * RPK; r < (ks + 1) * RPK; ++r) {
-                    rowmap[g] = rowmap[g] + rowmap[g] + (accP[g][r] > thr_rel[g] ? 1u : 0u);   // v_cmp + v_addc
-                    mx[g] = fmaxf(mx[g], accP[g][r]);
+                    m[g][r] = __ballot(accP[g][r] > thr_rel[g]);       // one v_cmp into an SGPR pair; folded into a
+                    mx[g] = fmaxf(mx[g], accP[g][r]);                  // per-lane row map only if some lane has a candidate
                 }
                 if constexpr (INS) {
                     // slots [lo, hi) of the list, highest ranges first
@@ -1485,10 +1484,10 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         for (int g = 0; g < G; ++g) thr_rel[g] = thr[g] - alpha_prev[g];
         const int img_off = (int)(((q / TPS) & 1) * STAGE_BYTES + sub * TILE_BYTES) + lane_off;   // tile q
         const int img_prev = (int)((((q - 1) / TPS) & 1) * STAGE_BYTES + ((q - 1) & (TPS - 1)) * TILE_BYTES) + lane_off;
-        uint32_t rowmap[G];                                // bit 15 - r: row r of tile q-2 beats this lane's threshold
+        unsigned long long m[G][16];                       // lane masks: row r of tile q-2 beats the lane's threshold
         float mx[G];
-        if (pend) body(std::true_type{}, accN, accP, img_prev, img_off, thr_rel, rowmap, mx);
-        else body(std::false_type{}, accN, accP, img_prev, img_off, thr_rel, rowmap, mx);
+        if (pend) body(std::true_type{}, accN, accP, img_prev, img_off, thr_rel, m, mx);
+        else body(std::false_type{}, accN, accP, img_prev, img_off, thr_rel, m, mx);
         if (nvalid < 32) {                                 // a group's last tile, or a dummy tile: padding rows never rank
 #pragma unroll
             for (int g = 0; g < G; ++g) {
@@ -1497,25 +1496,32 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
                     accN[g][r] = (4 * h + (r & 3) + 8 * (r >> 2) < nvalid) ? accN[g][r] : -INFINITY;
             }
         }
-        bool cand[G];
         unsigned long long anyc = 0ull;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            cand[g] = rowmap[g] != 0u;
-            anyc |= __ballot(cand[g]);
-        }
+        for (int g = 0; g < G; ++g) anyc |= __ballot(mx[g] > thr_rel[g]);
 #if M2D_DIAG & 16
         STAMP(t1_); t_body += t1_ - t0_; t0_ = t1_; ++n_step;
 #endif
         pend = false;
 #if M2D_DIAG & 8
-        asm volatile("" ::"s"(anyc), "v"(mx[0]), "v"(mx[G - 1]));
+        asm volatile("" ::"s"(anyc), "s"(m[0][0] | m[0][5] | m[0][10] | m[0][15]), "v"(mx[0]), "v"(mx[G - 1]));
 #endif
         if ((M2D_DIAG & 8) ? false : anyc != 0ull) {       // some lane of tile q-2 beat its threshold
             const int32_t sbase = (int32_t)((t_begin + q - 2) * 32) + 4 * h;
+            // per-lane 16-bit map of candidate rows (bit 15 - r), built here -- in the quarter of the steps that have a
+            // candidate -- from the sixteen lane masks: map = 2 map + mask bit, one v_addc each
+            uint32_t rowmap[G];
+            bool cand[G];
             unsigned long long multi = 0ull;
 #pragma unroll
-            for (int g = 0; g < G; ++g) multi |= __ballot((rowmap[g] & (rowmap[g] - 1u)) != 0u);   // two or more bits set
+            for (int g = 0; g < G; ++g) {
+                rowmap[g] = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    asm("v_addc_co_u32_e64 %0, vcc, %1, %1, %2" : "=v"(rowmap[g]) : "v"(rowmap[g]), "s"(m[g][r]) : "vcc");
+                cand[g] = rowmap[g] != 0u;
+                multi |= __ballot((rowmap[g] & (rowmap[g] - 1u)) != 0u);                      // two or more bits set
+            }
             if (multi != 0ull) {                           // immediate per-row path (first tiles of a scan, then rare)
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
