@@ -1188,11 +1188,11 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
 //   * the next stage's LDS-DMA pieces are issued a few per step inside the first steps of a stage, from a per-lane
 //     source offset computed once (consecutive pieces of a wave are a fixed stride apart in source and destination);
 //   * a step never branches into an insertion loop: the 16 compares of tile q-2 run under the MFMAs of tile q-1 as
-//     before, each folded into a per-lane 16-bit map of candidate rows (v_addc: map = 2 map + bit), and when some lane
-//     has a candidate its single best score of the tile (the max tree's result; the row is the map's set bit) is
-//     parked as (px, pid) and inserted by the NEXT step -- slot ranges of an in-place sorted insert placed between
-//     that step's MFMA groups.  Only a tile in which one lane holds two or more candidates (the first tiles of a
-//     scan, then rare) takes the immediate per-row path.
+//     before and leave 16 lane masks in SGPRs; when some lane has a candidate the masks are folded into a per-lane
+//     16-bit map of candidate rows (v_addc: map = 2 map + mask bit), the lane's single best score of the tile (the max
+//     tree's result; its row is the map's set bit) is parked as (px, pid) and inserted by the NEXT step -- slot
+//     ranges of an in-place sorted insert placed between that step's MFMA groups.  Only a tile in which one lane
+//     holds two or more candidates (the first tiles of a scan, then rare) takes the immediate per-row path.
 // G = groups of 32 users per wave (8 / G waves per block, always 256 users per block).  G = 1 is what is launched.
 // G = 2 (one wave per SIMD, every A fragment feeding two independent MFMA chains) was measured slower (100 k dishes
 // E = 64: 4.7 ms against 3.7) and is kept only as a template parameter.
@@ -1527,7 +1527,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
                 for (int g = 0; g < G; ++g) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        if (__ballot((rowmap[g] >> (15 - r)) & 1u) != 0ull)
+                        if (m[g][r] != 0ull)
                             sorted_insert_inplace<KR>(rs[g], ri[g], accP[g][r] + alpha_prev[g], sbase + (r & 3) + 8 * (r >> 2));
                     }
                     share_threshold(g);
