@@ -69,7 +69,8 @@ def retrieval_cases(draw):
     dup = draw(st.integers(0, I // 3))
     x3 = draw(st.booleans())
     splits = draw(st.sampled_from([0, 0, 102, 107, 164]))
-    return E, U, I, k, n_users, seed, n_nan, dup, x3, splits
+    form = draw(st.sampled_from([0, 0, 1]))                             # split-bf16 kernel: pipelined (default) / first form
+    return E, U, I, k, n_users, seed, n_nan, dup, x3, splits, form
 
 
 @settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
@@ -79,11 +80,12 @@ def test_retrieval_any_catalogue(case):
     exactly tied dishes, forced dish-range splits and both arithmetic forms: the checks of test_gpu_catalogue._check."""
     from foodrec_amd import ScoringEngine
     from test_gpu_catalogue import _check, _tables
-    E, U, I, k, n_users, seed, n_nan, dup, x3, splits = case
+    E, U, I, k, n_users, seed, n_nan, dup, x3, splits, form = case
     PM, RE, CE, cats = _tables(U, I, 4, E, seed=seed, n_nan=n_nan, dup=dup)
     eng = ScoringEngine(PM, RE, CE)
     eng.set_dish_categories(cats)
     eng.set_option("topk_bf16x3", int(x3))
+    eng.set_option("topk_form", form)
     if splits:
         eng.set_option("variant", splits)
     users = np.random.default_rng(seed).choice(U, n_users, replace=False)
@@ -161,4 +163,48 @@ def test_training_step_any_shape(seed, learner, C, E, B):
         err = np.abs(got.cpu().numpy().astype(np.float64) - ref)
         bound = tol if tol is not None else 1e-5 * np.maximum(1.0, np.abs(ref))
         assert np.all(err <= bound), (learner, C, E, B, err.max())
+    eng.close()
+
+
+@settings(max_examples=25, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(st.sampled_from([32, 64, 64, 128, 24]), st.integers(1, 50), st.integers(1, 500), st.sampled_from([1, 4, 10, 16]),
+       st.integers(0, 2 ** 31 - 1), st.booleans(), st.sampled_from([0, 0, 103]))
+def test_retrieval_with_ingredients_any_catalogue(E, U, I, k, seed, weighted, splits):
+    """m2d_topk_users with the ingredient table set (rows [H[d] | RE[d]] on the pattern-grouped kernel at E = 32 / 64,
+    the dense kernel otherwise): returned scores against the float64 restatement, descending order, optimality, NaN
+    dishes (empty ingredient list or empty mask) never ahead of a scored one."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    from test_gpu_catalogue import _tables
+    k = min(k, I)
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=seed, n_nan=min(I // 5, 2))
+    rng = np.random.default_rng(seed ^ 0x5A5A)
+    R = int(rng.integers(1, 60))
+    lens = rng.integers(0, 6, I)                                        # empty lists included
+    off = np.zeros(I + 1, np.int32); off[1:] = np.cumsum(lens)
+    ids = rng.integers(0, R, off[-1]).astype(np.int32)
+    w = rng.uniform(0.5, 2.0, len(ids)).astype(np.float32) if weighted else None
+    ING = (rng.standard_normal((R, E)) / np.sqrt(E)).astype(np.float32)
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    eng.set_ingredients(ING, off, ids, w)
+    if splits:
+        eng.set_option("variant", splits)
+    users = np.arange(U, dtype=np.int32)
+    s, idx = eng.topk_users(torch.as_tensor(users, device="cuda"), k); eng.check()
+    grouped = E in (32, 64) and cats.sum() > 0
+    assert (eng.last_kernel() == "m2d_topk_grouped_bf16x3") == grouped, eng.last_kernel()
+    s, idx = s.cpu().numpy(), idx.cpu().numpy()
+    for u in range(U):
+        ref = oracle.inference_ingredients(PM, RE, ING, off, ids, w, np.full(I, u), np.arange(I), cats)
+        assert len(set(idx[u].tolist())) == k and idx[u].min() >= 0 and idx[u].max() < I
+        assert_scores_close(s[u], ref[idx[u]], what="user %d" % u)
+        key = np.where(np.isnan(s[u]), -np.inf, s[u])
+        assert np.all(key[:-1] >= key[1:])
+        rest = np.delete(np.where(np.isnan(ref), -np.inf, ref), idx[u])
+        if rest.size and np.isfinite(key[-1]):
+            assert rest.max() <= key[-1] + 1e-4 * max(1.0, abs(key[-1]))
+        if rest.size and not np.isfinite(key[-1]):
+            assert not np.isfinite(rest).any()                          # a NaN made the list only when nothing scored was left
     eng.close()
