@@ -18,7 +18,7 @@ restatement of the reference graph timed on this box's host cores; TF itself is 
 `--gpus N` with N > 1 and no launcher environment: this process starts the N ranks itself (it runs the
 torch.distributed.run command above as a child BEFORE importing torch or touching a GPU) and exits with the
 child's status.  At N > 1 the line also carries `sharded_topk_allgather` (the user-sharded full-catalogue
-top-k + RCCL all-gather, median of 5) and `routed_pairs_alltoall` (pairs routed to the owners of their users).
+top-k + RCCL all-gather, median of 7) and `routed_pairs_alltoall` (pairs routed to the owners of their users).
 
 Exit status: 3 when the in-run parity check of the timed kernel against the CPU restatement fails.
 """
@@ -260,47 +260,53 @@ def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10):
             "kernel": kernel}
 
 
-def sharded_topk_leg(torch, dist, eng, U, I, C, E, dev, user_base, n_users, world, k=10, repeats=5):
+def sharded_topk_leg(torch, dist, eng, U, I, C, E, dev, user_base, n_users, world, k=10, repeats=7):
     """Every rank: top-k over the replicated catalogue for n_users of ITS users, then ONE all-gather of
     [n_users, k] x (f32 score, i32 id) per rank, through foodrec_amd.sharding.  Timed
-    `repeats` times between barriers; the median of the max-over-ranks wall time is reported."""
+    `repeats` times between barriers; the median of the max-over-ranks wall time is reported.  `dist` is None in a
+    single-process run (N = 1 without a launcher): the same leg with no peers, so that the N = 1 line carries the
+    number the N > 1 lines are compared with."""
     from foodrec_amd.sharding import UserShardedScorer
     g = torch.Generator(device=dev)
     g.manual_seed(11)                                     # same dish masks on every rank (replicated)
     pat = torch.randint(1, 2 ** C, (I,), generator=g, device=dev, dtype=torch.int32)
     dish_cats = ((pat[:, None] >> torch.arange(C, device=dev, dtype=torch.int32)[None, :]) & 1).to(torch.float32)
     eng.set_dish_categories(dish_cats)
-    sh = UserShardedScorer(eng, world * U, device=dev, always_collective=True)
+    sh = UserShardedScorer(eng, world * U, device=dev, always_collective=dist is not None)
     users = (torch.randperm(U, generator=g, device=dev)[:n_users].to(torch.int32) + int(user_base)).contiguous()
     sh.topk_users_gathered(users[:1024], k)               # builds the retrieval tables, warms RCCL up
-    for _ in range(2):                                    # the first full launches run 5-10 % slow (clock ramp)
+    for _ in range(5):                                    # the first full launches run 5-10 % slow (clock ramp)
         sh.topk_users_gathered(users, k)
     walls, tk_ms, ag_ms = [], [], []
     for _ in range(repeats):
         torch.cuda.synchronize()
-        dist.barrier()
+        if dist is not None:
+            dist.barrier()
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         t0 = time.perf_counter()
         e0.record()
         s, ids = sh.topk_local(k, users)
         e1.record()
-        gs, gi = sh._gather_topk(s, ids, n_users, k)
+        gs, gi = sh._gather_topk(s, ids, n_users, k) if dist is not None else (s, ids)
         e2.record()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         t = torch.tensor([wall, e0.elapsed_time(e1), e1.elapsed_time(e2)], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
         w, a_, b_ = (float(x) for x in t.tolist())
         walls.append(w); tk_ms.append(a_); ag_ms.append(b_)
     eng.check()
-    r = dist.get_rank()
+    r = dist.get_rank() if dist is not None else 0
     ok = bool(torch.equal(gi[r * n_users:(r + 1) * n_users], ids) and torch.equal(gs[r * n_users:(r + 1) * n_users], s))
     wall = median(walls)
     return {"users_per_gpu": n_users, "dishes": I, "k": k, "repeats": repeats, "wall_ms_median": wall * 1e3,
             "wall_ms_all": [w * 1e3 for w in walls], "topk_ms_median": median(tk_ms), "allgather_ms_median": median(ag_ms),
-            "allgather_bytes_per_rank": n_users * k * 8, "users_per_s_whole_job": world * n_users / wall,
-            "pairs_per_s_whole_job": world * n_users * I / wall, "kernel": eng.last_kernel(), "own_slice_roundtrip_ok": ok,
-            "what": "max over ranks per repeat, median over repeats; per-shard full-catalogue top-k + one RCCL all-gather"}
+            "allgather_bytes_per_rank": n_users * k * 8 if dist is not None else 0,
+            "users_per_s_whole_job": world * n_users / wall, "pairs_per_s_whole_job": world * n_users * I / wall,
+            "kernel": eng.last_kernel(), "own_slice_roundtrip_ok": ok,
+            "what": "max over ranks per repeat, median over repeats; per-shard full-catalogue top-k + one RCCL all-gather"
+                    + ("" if dist is not None else " (single process: no peers, no collective)")}
 
 
 def routed_pairs_leg(torch, dist, eng, U, I, C, dev, world, B, repeats=5):
@@ -679,16 +685,18 @@ def main():
 
     # N > 1: the user-sharded retrieval step and the owner-routed pair step (outside the timed region, repeated)
     topk_ag = routed = None
-    if use_dist and not a.no_side and wl == "pairs":
+    if not a.no_side and wl == "pairs":
         if a.topk_users > 0:
             try:
-                topk_ag = sharded_topk_leg(torch, dist, eng, U, I, C, E, dev, user_base, min(a.topk_users, U), world)
+                topk_ag = sharded_topk_leg(torch, dist if use_dist else None, eng, U, I, C, E, dev, user_base,
+                                           min(a.topk_users, U), world)
             except Exception as e:                                     # noqa: BLE001 -- never lose the headline line
                 topk_ag = {"error": "%s: %s" % (type(e).__name__, e)}
-        try:
-            routed = routed_pairs_leg(torch, dist, eng, U, I, C, dev, world, min(B, 1 << 22))
-        except Exception as e:                                         # noqa: BLE001
-            routed = {"error": "%s: %s" % (type(e).__name__, e)}
+        if use_dist:
+            try:
+                routed = routed_pairs_leg(torch, dist, eng, U, I, C, dev, world, min(B, 1 << 22))
+            except Exception as e:                                     # noqa: BLE001
+                routed = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if a.sweep and rank == 0:
         so = torch.empty_like(out)
