@@ -1304,14 +1304,28 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         const int q = sl ^ ((rw / RPB) & (S8 - 1));        // logical slot that must land here
         dma_off = rw * ROW_BYTES + q * 16;
     }
+    // a wave's pieces of one stage: buffer_load ... lds with the stage's base in an SGPR descriptor, the per-lane
+    // source offset (computed once, above) as the 32-bit VGPR offset and the piece's 8 KiB multiple as the scalar
+    // offset -- no 64-bit per-lane address arithmetic per piece (1-2 % over global_load_lds with VGPR addresses)
+    typedef int v4i_ __attribute__((ext_vector_type(4)));
     auto issue_pieces = [&](const int64_t stage, const int first, const int count) __attribute__((always_inline)) {
         if (stage >= nst) return;
-        const unsigned char *src = src_base + (size_t)stage * STAGE_BYTES + dma_off;
+        const uint64_t b = (uint64_t)(uintptr_t)(src_base + (size_t)stage * STAGE_BYTES);
+        v4i_ rsrc;                                         // raw buffer (stride 0) over this stage of the catalogue image
+        rsrc.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+        rsrc.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xffffu));
+        rsrc.z = STAGE_BYTES;
+        rsrc.w = 0x00020000;
         unsigned char *dst = smem8 + (size_t)(stage & 1) * STAGE_BYTES + wave * 1024;
 #pragma unroll
         for (int c = 0; c < count; ++c) {
             const int pp = first + c;
-            if (pp < PPW) lds_dma16(src + pp * PSTRIDE, dst + pp * PSTRIDE);
+            if (pp < PPW) {
+                const uint32_t m0v = __builtin_amdgcn_readfirstlane(
+                    (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)(dst + pp * PSTRIDE));
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             ::"s"(m0v), "v"(dma_off), "s"(rsrc), "s"(pp * PSTRIDE) : "memory", "m0");
+            }
         }
     };
 
