@@ -79,6 +79,7 @@ void release(m2d_engine *h)
             if (q) (void)hipFree((void *)q);
     }
     if (h->mlp_w1x3) (void)hipFree(h->mlp_w1x3);
+    if (h->mlp_w1pc) (void)hipFree(h->mlp_w1pc);
     if (h->dish_high) (void)hipFree(h->dish_high);
     if (h->own_ing) {
         if (h->ing) (void)hipFree((void *)h->ing);
@@ -397,6 +398,8 @@ int m2d_clear_mlp_head(m2d_engine *h)
     }
     if (h->mlp_w1x3) (void)hipFree(h->mlp_w1x3);
     h->mlp_w1x3 = nullptr;
+    if (h->mlp_w1pc) (void)hipFree(h->mlp_w1pc);
+    h->mlp_w1pc = nullptr;
     h->mlp_w1 = h->mlp_b1 = h->mlp_w2 = h->mlp_b2 = h->mlp_w3 = nullptr;
     h->own_mlp = false;
     h->mlp_h1 = h->mlp_h2 = 0;
@@ -544,6 +547,7 @@ int m2d_set_option(m2d_engine *h, const char *name, int64_t value)
     else if (!strcmp(name, "topk_form")) h->opt_topk_form = (int)value;
     else if (!strcmp(name, "topk_grouped")) h->opt_topk_grouped = (int)value;
     else if (!strcmp(name, "mlp_bf16x3")) h->opt_mlp_bf16x3 = (int)value;
+    else if (!strcmp(name, "mlp_form")) h->opt_mlp_form = (int)value;
     else return fail(h, M2D_ERR_INVALID_ARG, "m2d_set_option: unknown option");
     return M2D_OK;
 }
@@ -559,6 +563,7 @@ int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value)
     else if (!strcmp(name, "topk_form")) *value = h->opt_topk_form;
     else if (!strcmp(name, "topk_grouped")) *value = h->opt_topk_grouped;
     else if (!strcmp(name, "mlp_bf16x3")) *value = h->opt_mlp_bf16x3;
+    else if (!strcmp(name, "mlp_form")) *value = h->opt_mlp_form;
     else if (!strcmp(name, "num_cu")) *value = h->num_cu;
     else return M2D_ERR_INVALID_ARG;
     return M2D_OK;

@@ -44,6 +44,7 @@ struct m2d_engine {
     int32_t mlp_h1 = 0, mlp_h2 = 0;
     bool own_mlp = false;
     void *mlp_w1x3 = nullptr;           // split-bf16 image of W1 for the bf16x3 layer-1 path (built lazily)
+    void *mlp_w1pc = nullptr;           // W1 | W2 image of the producer / consumer kernel (built lazily)
 
     // factored dish vectors for catalogue retrieval (built lazily by m2d_topk_users)
     float *dish_vec = nullptr;  // [I_pad, (C+1)*E]
@@ -76,6 +77,7 @@ struct m2d_engine {
     int opt_nt = 1;
     int opt_blocks_per_cu = 8;
     int opt_variant = 0;
+    int opt_mlp_form = 0;               // split-bf16 MLP head: 0 = matrix waves fed by gather / DMA waves (m2d_mlp_pc), 1 = every wave gathers its own rows
     int opt_mlp_bf16x3 = 1;             // MLP head layer 1 (build-defined) on split-bf16 MFMA; 0 = exact-f32 MFMA
     int opt_topk_bf16x3 = 1;            // retrieval (build-defined) on split-bf16 MFMA; 0 = exact-f32 MFMA
     int opt_topk_grouped = 1;           // 0/1-mask catalogues: pattern-grouped retrieval (contraction over E); 0 = dense kernel

@@ -389,6 +389,457 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split-bf16 head, producer / consumer form (the default for the shapes it covers).  The kernel above makes every
+// wave gather its own rows with one 16-byte load per lane and row -- 32 cache lines per wave-instruction, which blocks
+// the wave's in-order issue (and with it its MFMAs) while the cache has misses outstanding: layer 1 took 93 k cycles
+// per tile and wave from a 0.5 GB table against 77 k from a table that sits in L2, for 31 k cycles of MFMAs.  Here the
+// roles are split by wave, one matrix wave per SIMD beside a memory wave:
+//   waves 0-3  consumers   32 pairs each (tile = 128 pairs): ds_read + MFMA, and in the MFMA shadows the hi / lo
+//                          split of the next period's z.  Layer 1 in periods of 32 k-values (48 MFMAs), layer 2 in
+//                          two periods (W2 halves), layer 3 per lane.
+//   waves 4, 6 gatherers   64 pairs each: whole 128-byte lines of the two gathered rows (8 rows per wave-instruction,
+//                          16 B per lane), two periods ahead of use; z = u * d and the reference score's partial
+//                          sums; ds_write_b128 of z into the consumer's B-operand order (the transpose the per-lane
+//                          loads of the kernel above were avoiding).
+//   waves 5, 7 loaders     LDS-DMA of the W1 / W2 image, half a ring stage each per period (16 pieces of 1 KiB), two
+//                          periods ahead.  Their vmcnt queue holds nothing else: the DMA is inline asm the compiler's
+//                          wait bookkeeping does not see, and in a wave that also had row loads in flight the waits
+//                          it places for those came out one to three periods too strict.
+// Hand-off: one s_barrier per period, placed in the MIDDLE of the consumers' period P.  Passing it means: period P + 1
+// (ring stage and z set) is complete in LDS, and the consumers are done with period P - 1 and the first half of P.
+// The consumers therefore read the first fragments of period P + 1 under the last MFMAs of period P and never wait
+// for LDS at a period boundary.  The ring holds 7 half-stages of 16 KiB (3.5 periods: the stage two periods ahead can
+// be written while the current one and the next are live); z needs 2 sets (a consumer copies its z into registers
+// half a period before it uses it).
+// LDS: ring 7 x 16 KiB | z sets 2 x (4 consumers x 4 KiB f32) | reference-score sums 512 B | biases.
+constexpr int PC_HALF = 16384, PC_STAGE = 2 * PC_HALF, PC_NHB = 7, PC_ZSET = 16384;
+constexpr int PC_Z_OFF = PC_NHB * PC_HALF, PC_BASE_OFF = PC_Z_OFF + 2 * PC_ZSET, PC_B1_OFF = PC_BASE_OFF + 512;
+constexpr int PC_LDS_BYTES = PC_B1_OFF + (MH1 + 2 * MH2) * 4;
+constexpr int PC_PAIRS = 128;             // pairs per tile
+typedef int v4i_pc __attribute__((ext_vector_type(4)));
+
+// W1 [K, 256] f32 -> per 32 k-values one ring stage of two halves (16 k-values each), a half = [hi: 256 n x 32 B |
+// lo: same]; the two 16-byte slots of a row (k-values 8 h .. 8 h + 7) are swapped for rows with (n >> 3) & 1, so the
+// b128 fragment reads of 16 rows (32 B apart: rows 8 apart share a bank range) are conflict-free.
+__global__ __launch_bounds__(256) void m2d_mlp_image_pc_w1(const float *w1, int K, __bf16 *out)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one (k, n) element
+    if (t >= (int64_t)K * MH1) return;
+    const int k = (int)(t / MH1), n = (int)(t % MH1);
+    const int kk = k & 15, hh = kk >> 3, j = kk & 7;
+    const float x = w1[t];
+    const __bf16 hi = (__bf16)x;
+    __bf16 *half = out + (size_t)(k >> 4) * (PC_HALF / 2);
+    const int e = n * 16 + ((hh ^ ((n >> 3) & 1)) << 3) + j;
+    half[e] = hi;
+    half[PC_HALF / 4 + e] = (__bf16)(x - (float)hi);
+}
+
+// W2 [256, 64] f32 -> two ring stages = four halves (layer-2 k-steps 4 q .. 4 q + 3), each [hi, lo][mt 2][ks 4][h 2]
+// [m 32][j 8]: the 16 bytes at (mt, ks, h, m) are W2[n][32 mt + m] for the 8 hidden units lane half h of layer-1
+// accumulator tile ks >> 1 holds in registers 8 (ks & 1) + j (as m2d_mlp_split_w2).
+__global__ __launch_bounds__(256) void m2d_mlp_image_pc_w2(const float *w2, __bf16 *out)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;                   // [ks 16][mt 2][h 2][m 32][j 8]
+    if (t >= MH1 * MH2) return;
+    const int j = t & 7, m = (t >> 3) & 31, hh = (t >> 8) & 1, mt = (t >> 9) & 1, ks = t >> 10;
+    const int n = 32 * (ks >> 1) + 16 * (ks & 1) + (j & 3) + 8 * (j >> 2) + 4 * hh;
+    const float x = w2[n * MH2 + 32 * mt + m];
+    const __bf16 hi = (__bf16)x;
+    __bf16 *half = out + (size_t)(ks >> 2) * (PC_HALF / 2);
+    const int e = mt * 2048 + (ks & 3) * 512 + hh * 256 + m * 8 + j;
+    half[e] = hi;
+    half[2 * 2048 + e] = (__bf16)(x - (float)hi);
+}
+
+#if M2D_MLP_DIAG & 64
+// diag bit 6: block 0 logs every wave's arrival at and release from its first 128 barriers
+#define pc_barrier() do { unsigned long long ta_, tr_; MSTAMP(ta_); asm volatile("s_barrier" ::: "memory"); MSTAMP(tr_); \
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && nbar_ < 128 && p.dbg) { unsigned long long *d_ = p.dbg + 4096 * 8 + ((threadIdx.x >> 6) * 128 + nbar_) * 2; d_[0] = ta_; d_[1] = tr_; } ++nbar_; } while (0)
+#else
+__device__ __forceinline__ void pc_barrier()
+{
+    asm volatile("s_barrier" ::: "memory");
+}
+#endif
+
+template <int N>
+__device__ __forceinline__ void pc_wait_vmem()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+typedef float v2f_pc __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_pc __attribute__((ext_vector_type(2)));
+
+template <int KCH>
+__global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
+{
+    extern __shared__ __align__(16) unsigned char pcs[];
+    float *sbase = reinterpret_cast<float *>(pcs + PC_BASE_OFF);        // [4 consumers][32]
+    float *sb1 = reinterpret_cast<float *>(pcs + PC_B1_OFF);            // [256]
+    float *sb2 = sb1 + MH1, *sw3 = sb2 + MH2;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    constexpr int K = KCH * 64, NH = 2 * KCH, NP = NH + 2;
+    const int64_t ntiles = (p.B + PC_PAIRS - 1) / PC_PAIRS;
+#if M2D_MLP_DIAG & 64
+    int nbar_ = 0;
+#endif
+
+    for (int i = threadIdx.x; i < MH1; i += 512) sb1[i] = p.b1[i];
+    if (threadIdx.x < MH2) {
+        sb2[threadIdx.x] = p.b2[threadIdx.x];
+        sw3[threadIdx.x] = p.w3[threadIdx.x];
+    }
+    __syncthreads();
+
+    if (wave < 4) {
+        // ======================================= consumer =======================================
+        const int pl = lane & 31, h = lane >> 5;
+#if M2D_MLP_DIAG
+        unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, n_t = 0, t0_ = 0, t1_;
+#endif
+        const unsigned a_off = pl * 32 + ((h ^ ((pl >> 3) & 1)) << 4);     // this lane's 16 B of a W1 row, tile 0
+        // z set: [blk = 2 k-step + h][k-values 0-3 | 4-7 of the lane's 8][pair slot ^ (2 blk + part)][16 B]
+        const unsigned z_off[2][2] = {{wave * 4096u + h * 1024 + ((pl ^ (2 * h)) << 4),
+                                       wave * 4096u + h * 1024 + 512 + ((pl ^ (2 * h + 1)) << 4)},
+                                      {wave * 4096u + (2 + h) * 1024 + ((pl ^ (4 + 2 * h)) << 4),
+                                       wave * 4096u + (2 + h) * 1024 + 512 + ((pl ^ (5 + 2 * h)) << 4)}};
+        const unsigned w2_off = (h * 32 + pl) * 16;
+        unsigned hb = 0, zb = 0;                                          // half-buffer of this period's first half; z set
+        bf16x8 ah[4], al[4], bA[2][2], bB[2][2];                          // b?[k-step][hi, lo]
+        v4f zraw[4];
+        auto hb_add = [](unsigned x, unsigned d) { const unsigned y = x + d; return y >= PC_NHB ? y - PC_NHB : y; };
+        auto frag = [&](unsigned half_off, int nt, bf16x8 &fh, bf16x8 &fl) __attribute__((always_inline)) {
+            const unsigned char *q = pcs + half_off + nt * 1024 + a_off;
+            fh = *reinterpret_cast<const bf16x8 *>(q);
+            fl = *reinterpret_cast<const bf16x8 *>(q + PC_HALF / 2);
+        };
+        // chunk c = 2 k-step + part: 4 of the next period's z values -> their place in the split B operand
+        auto split = [&](int c, bf16x8 (&nb)[2][2]) __attribute__((always_inline)) {
+            const v4f zz = zraw[c];
+            const v2f_pc z01 = {zz.x, zz.y}, z23 = {zz.z, zz.w};
+            const uint32_t h01 = __builtin_bit_cast(uint32_t, __builtin_convertvector(z01, bf16x2_pc));
+            const uint32_t h23 = __builtin_bit_cast(uint32_t, __builtin_convertvector(z23, bf16x2_pc));
+            const v2f_pc f01 = {__builtin_bit_cast(float, h01 << 16), __builtin_bit_cast(float, h01 & 0xffff0000u)};
+            const v2f_pc f23 = {__builtin_bit_cast(float, h23 << 16), __builtin_bit_cast(float, h23 & 0xffff0000u)};
+            const bf16x2_pc l01 = __builtin_convertvector(z01 - f01, bf16x2_pc), l23 = __builtin_convertvector(z23 - f23, bf16x2_pc);
+            const bf16x2_pc g01 = __builtin_bit_cast(bf16x2_pc, h01), g23 = __builtin_bit_cast(bf16x2_pc, h23);
+            const int ks = c >> 1, o = 4 * (c & 1);
+            nb[ks][0][o] = g01.x; nb[ks][0][o + 1] = g01.y; nb[ks][0][o + 2] = g23.x; nb[ks][0][o + 3] = g23.y;
+            nb[ks][1][o] = l01.x; nb[ks][1][o + 1] = l01.y; nb[ks][1][o + 2] = l23.x; nb[ks][1][o + 3] = l23.y;
+        };
+        auto zread = [&](unsigned zset) __attribute__((always_inline)) {
+            const unsigned char *q = pcs + PC_Z_OFF + zset * PC_ZSET;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) zraw[c] = *reinterpret_cast<const v4f *>(q + z_off[c >> 1][c & 1]);
+        };
+        v16f acc1[8];
+        // one layer-1 period: 2 k-steps x 8 hidden tiles x 3 MFMAs; fragments two steps ahead (4 register sets), the
+        // barrier after the first k-step, the NEXT period's operands read and split under the last steps
+        auto period = [&](bf16x8 (&b)[2][2], bf16x8 (&nb)[2][2]) __attribute__((always_inline)) {
+            const unsigned h0 = hb * PC_HALF, h1 = hb_add(hb, 1) * PC_HALF, h2 = hb_add(hb, 2) * PC_HALF;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                if (it == 8) { MACC(t_a); pc_barrier(); MACC(t_b); }
+                const int jt = it + 2;
+                frag(jt < 8 ? h0 : jt < 16 ? h1 : h2, jt & 7, ah[jt & 3], al[jt & 3]);
+                if (it == 10) zread(zb ^ 1);
+                if (it >= 12) split(it - 12, nb);
+                const int nt = it & 7, ksl = it >> 3;
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[it & 3], b[ksl][0], acc1[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[it & 3], b[ksl][1], acc1[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[it & 3], b[ksl][0], acc1[nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            hb = hb_add(hb, 2);
+            zb ^= 1;
+        };
+        pc_barrier();                                                     // period 0 is published
+        MSTAMP(t0_);
+        frag(0, 0, ah[0], al[0]);
+        frag(0, 1, ah[1], al[1]);
+        zread(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) split(c, bA);
+        for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[nt][r] = sb1[hidden_unit<true>(nt, r, h)];
+#pragma unroll 1
+            for (int kc = 0; kc < KCH; ++kc) {
+                period(bA, bB);
+                period(bB, bA);
+            }
+            // ---- layer 2: relu(acc1) split hi / lo is the B operand; W2 is ring stages NH and NH + 1 ----
+            MACC(t_a);
+            v16f acc2[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[mt][r] = sb2[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                if ((ks & 7) == 4) { MACC(t_c); pc_barrier(); MACC(t_b); }
+                bf16x8 bh, bl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float hv = fmaxf(acc1[ks >> 1][8 * (ks & 1) + j], 0.f);
+                    const __bf16 hi = (__bf16)hv;
+                    bh[j] = hi;
+                    bl[j] = (__bf16)(hv - (float)hi);
+                }
+                const unsigned char *img = pcs + hb_add(hb, (ks >> 2) & 1) * PC_HALF + (ks & 3) * 1024 + w2_off;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const bf16x8 wh = *reinterpret_cast<const bf16x8 *>(img + mt * 4096);
+                    const bf16x8 wl = *reinterpret_cast<const bf16x8 *>(img + (2 + mt) * 4096);
+                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bh, acc2[mt], 0, 0, 0);
+                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bl, acc2[mt], 0, 0, 0);
+                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc2[mt], 0, 0, 0);
+                }
+                if ((ks & 7) == 7) { hb = hb_add(hb, 2); zb ^= 1; }
+            }
+            // the next tile's period 0 was published by the last barrier
+            MACC(t_c);
+            frag(hb * PC_HALF, 0, ah[0], al[0]);
+            frag(hb * PC_HALF, 1, ah[1], al[1]);
+            zread(zb);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) split(c, bA);
+            // ---- layer 3 and the reference score (summed by the producer; NaN there = an id was out of range) ----
+            float o = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    o = fmaf(sw3[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h], fmaxf(acc2[mt][r], 0.f), o);
+            o += __shfl_xor(o, 32, 64);
+            const int64_t pi = tile * PC_PAIRS + wave * 32 + pl;
+            if (h == 0 && pi < p.B) p.out[pi] = sbase[wave * 32 + pl] + (o + p.b3);
+#if M2D_MLP_DIAG
+            MACC(t_d); ++n_t;
+#endif
+        }
+#if M2D_MLP_DIAG
+        if (lane == 0 && p.dbg) {
+            unsigned long long *d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+            d[0] = t_a; d[1] = t_b; d[2] = t_c; d[3] = t_d; d[4] = n_t;
+        }
+#endif
+        return;
+    }
+
+    if (wave & 1) {
+        // ======================================= loader (waves 5, 7) =======================================
+        // half li of every ring stage: 16 pieces of 1 KiB (hi 8, lo 8), two periods ahead of its use.  The stage's
+        // base sits in an SGPR descriptor, the lane offset in one VGPR, the piece in the scalar offset.
+        const int li = (wave - 5) >> 1;
+        const unsigned char *img = reinterpret_cast<const unsigned char *>(p.w1x3) + li * PC_HALF;
+        const int voff = lane * 16;
+        unsigned hbn = li;                                                // half-buffer of this wave's half of the stage being fetched
+#if M2D_MLP_DIAG
+        unsigned long long t_a = 0, t_b = 0, t_c = 0, n_t = 0, t0_, t1_;
+#endif
+        auto dma = [&](int q) __attribute__((always_inline)) {
+            if (!(M2D_MLP_DIAG & 4)) {                                    // diag bit 2: no DMA
+                const uint64_t sb = (uint64_t)(uintptr_t)(img + (size_t)q * PC_STAGE);
+                v4i_pc rsrc;
+                rsrc.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)sb);
+                rsrc.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(sb >> 32) & 0xffffu));
+                rsrc.z = PC_HALF;
+                rsrc.w = 0x00020000;
+                unsigned char *dst = pcs + hbn * PC_HALF;
+#pragma unroll
+                for (int pc = 0; pc < 16; ++pc) {
+                    const uint32_t m0v = __builtin_amdgcn_readfirstlane(
+                        (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)(dst + pc * 1024));
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                                 ::"s"(m0v), "v"(voff), "s"(rsrc), "s"(pc * 1024) : "memory", "m0");
+                }
+            }
+            hbn = hbn + 2 >= PC_NHB ? hbn + 2 - PC_NHB : hbn + 2;
+        };
+        dma(0);
+        MSTAMP(t0_);
+        for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#if M2D_MLP_DIAG
+            ++n_t;
+#endif
+#pragma unroll 1
+            for (int q = 0; q < NP; ++q) {
+                dma(q + 1 < NP ? q + 1 : 0);                              // the stage after the one about to be published
+                MACC(t_a);
+                pc_wait_vmem<16>();                                       // stage q landed; the one just requested stays in flight
+                MACC(t_b);
+                pc_barrier();
+                MACC(t_c);
+            }
+        }
+        pc_wait_vmem<0>();
+        pc_barrier();
+#if M2D_MLP_DIAG
+        if (lane == 0 && p.dbg) {
+            unsigned long long *d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+            d[0] = t_a; d[1] = t_b; d[2] = t_c; d[4] = n_t;
+        }
+#endif
+        return;
+    }
+
+    // ======================================= gatherer (waves 4, 6) =======================================
+    {
+        const int g = (wave - 4) >> 1;                                    // serves consumers 2 g, 2 g + 1: pairs [64 g, 64 g + 64)
+        const int r8 = lane >> 3, s = lane & 7;
+        // this lane's 16 bytes of z: block s >> 1, part s & 1, pair slot swizzled by s
+        const unsigned z_w = (2 * g) * 4096 + (s >> 1) * 1024 + (s & 1) * 512 + ((r8 ^ s) << 4);
+        const unsigned char *pm = reinterpret_cast<const unsigned char *>(p.pm);
+        const unsigned char *dt = reinterpret_cast<const unsigned char *>(p.dt);
+        // rows as 32-bit offsets in units of 16 B, this lane's slot included: (row * K / 4 + s) -- the launcher takes
+        // this kernel only for tables under 64 GiB.  One 64-bit shift-add per load turns one into an address.
+        uint32_t cu[8], cd[8], nu[8], nd[8];                              // this tile / the next one
+        unsigned badmask = 0, nbadmask = 0;
+        v4f ra[2][8], rb_[2][8];
+        v2f_pc base[8];
+        auto load_ids = [&](int64_t tile) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int64_t pi = tile * PC_PAIRS + 64 * g + 8 * i + r8;
+                if (pi >= p.B) pi = p.B - 1;                              // any valid pair; masked when converted
+                nu[i] = (uint32_t)p.users[pi];
+                nd[i] = (uint32_t)p.items[pi];
+            }
+        };
+        auto convert_ids = [&](int64_t tile) __attribute__((always_inline)) {
+            nbadmask = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t pi = tile * PC_PAIRS + 64 * g + 8 * i + r8;
+                const bool valid = pi < p.B;
+                const int32_t uid = (int32_t)nu[i], did = (int32_t)nd[i];
+                int64_t ul = (int64_t)uid - p.user_base;
+                int32_t dl = did;
+                if (valid && (ul < 0 || ul >= p.U)) { if (s == 0) latch(p.err, M2D_ERR_BAD_USER_ID, uid, pi); nbadmask |= 1u << i; }
+                if (valid && (did < 0 || (int64_t)did >= p.I)) { if (s == 0) latch(p.err, M2D_ERR_BAD_ITEM_ID, did, pi); nbadmask |= 1u << i; }
+                if (!valid || ul < 0 || ul >= p.U) ul = 0;
+                if (!valid || did < 0 || (int64_t)did >= p.I) dl = 0;
+                nu[i] = (uint32_t)ul * (uint32_t)(K / 4) + (uint32_t)s;
+                nd[i] = (uint32_t)dl * (uint32_t)(K / 4) + (uint32_t)s;
+            }
+        };
+        auto gather = [&](int set, const uint32_t (&iu)[8], const uint32_t (&id)[8], int half) __attribute__((always_inline)) {
+            if (M2D_MLP_DIAG & 8) return;                                 // diag bit 3: no row requests
+            const unsigned char *bu = pm + half * 128, *bd = dt + half * 128;       // uniform
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                uint32_t ou = iu[i], od = id[i];
+                asm volatile("" : "+v"(ou), "+v"(od));                    // keep the 64-bit products out of registers
+                // user rows are read about once per batch: non-temporal, so they do not push the dish vectors (each
+                // read ~10 times) out of L2 / the Infinity Cache
+                ra[set][i] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(bu + (uint64_t)ou * 16));
+                rb_[set][i] = *reinterpret_cast<const v4f *>(bd + (uint64_t)od * 16);
+                __builtin_amdgcn_sched_barrier(0);                        // one pair of addresses live at a time
+            }
+        };
+        unsigned zb = 0;                                                  // z set being written
+        // per 4 k-values of a pair: 2 packed multiplies, 2 packed adds into the reference score, one 16-byte store
+        auto build = [&](int set) __attribute__((always_inline)) {
+            if (M2D_MLP_DIAG & 2) return;                                 // diag bit 1: no z build
+            unsigned char *zs = pcs + PC_Z_OFF + zb * PC_ZSET + z_w;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const v4f zz = ra[set][i] * rb_[set][i];
+                const v2f_pc z01 = {zz.x, zz.y}, z23 = {zz.z, zz.w};
+                base[i] += z01 + z23;
+                *reinterpret_cast<v4f *>(zs + (i >> 2) * 4096 + (i & 3) * 128) = zz;
+            }
+        };
+        // prologue: offsets of this block's first two tiles; the first two periods' rows
+        const int64_t tile0 = blockIdx.x;
+        auto next_of = [&](int64_t t) { return t + gridDim.x < ntiles ? t + gridDim.x : t; };   // none left: any valid rows
+        load_ids(tile0);
+        pc_wait_vmem<0>();
+        convert_ids(tile0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { cu[i] = nu[i]; cd[i] = nd[i]; }
+        badmask = nbadmask;
+        load_ids(next_of(tile0));
+        pc_wait_vmem<0>();
+        convert_ids(next_of(tile0));
+        gather(0, cu, cd, 0);
+        gather(1, cu, cd, 1);
+#if M2D_MLP_DIAG
+        unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, n_t = 0, t0_, t1_;
+        MSTAMP(t0_);
+#endif
+        for (int64_t tile = tile0; tile < ntiles; tile += gridDim.x) {
+#if M2D_MLP_DIAG
+            ++n_t;
+#endif
+#pragma unroll
+            for (int i = 0; i < 8; ++i) base[i] = 0.f;
+            // producing z of period q: build it from the rows requested two steps ago (ordinary loads: the compiler
+            // places the vmcnt waits, and in this wave it sees every outstanding request), request the rows two
+            // periods on, publish
+            auto step = [&](int set, const uint32_t (&iu)[8], const uint32_t (&id)[8], int half, bool last)
+                            __attribute__((always_inline)) {
+                MACC(t_d);
+                build(set);
+                MACC(t_a);
+                gather(set, iu, id, half);
+                asm volatile("" ::: "memory");
+                MACC(t_b);
+                if (last) {
+                    // reference score = sum of z over the 8 lanes of a row; an id out of range makes it NaN
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float b = base[i].x + base[i].y;
+                        b += __shfl_xor(b, 1, 64);
+                        b += __shfl_xor(b, 2, 64);
+                        b += __shfl_xor(b, 4, 64);
+                        if ((badmask >> i) & 1) b = __builtin_nanf("");
+                        if (s == 0) sbase[(2 * g + (i >> 2)) * 32 + 8 * (i & 3) + r8] = b;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                MACC(t_c);
+                pc_barrier();
+                zb ^= 1;
+            };
+#pragma unroll 1
+            for (int q = 0; q < NH - 2; q += 2) {
+                step(0, cu, cd, q + 2, false);
+                step(1, cu, cd, q + 3, false);
+            }
+            step(0, nu, nd, 0, false);                                    // the last two request the next tile's rows
+            step(1, nu, nd, 1, true);
+            // the two W2 periods: nothing to build.  The offsets move up one tile; the ids of the tile after the next
+            // are requested before the first of the two barriers and converted before the second.
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { cu[i] = nu[i]; cd[i] = nd[i]; }
+            badmask = nbadmask;
+            const int64_t t2 = next_of(next_of(tile));
+            load_ids(t2);
+            pc_barrier();
+            zb ^= 1;
+            pc_wait_vmem<0>();
+            convert_ids(t2);
+            pc_barrier();
+            zb ^= 1;
+        }
+        pc_wait_vmem<0>();
+        pc_barrier();
+#if M2D_MLP_DIAG
+        if (lane == 0 && p.dbg) {
+            unsigned long long *d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
+            d[0] = t_a; d[1] = t_b; d[2] = t_c; d[3] = t_d; d[4] = n_t;
+        }
+#endif
+    }
+}
+
 // (diag epilogue is emitted by the macro below, inside the kernel)
 // Any K / H1 / H2: one wave per pair, activations in LDS.  Slow; for shapes the MFMA kernel does not cover.
 __global__ __launch_bounds__(256) void m2d_mlp_generic(MlpArgs p)
@@ -454,7 +905,30 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
     a.w1x3 = a.w2x3 = nullptr;
     const bool mfma_ok = a.H1 == MH1 && a.H2 == MH2 && a.K % 64 == 0 && h->opt_variant != 9;
     const int kch = a.K / 64;
-    if (mfma_ok && (kch == 5 || kch == 10 || kch == 20 || kch == 3)) {
+    const bool pc_ok = (uint64_t)h->U * a.K * 4 < (1ull << 36) && (uint64_t)h->I * a.K * 4 < (1ull << 36);   // 32-bit row offsets in 16-B units
+    if (mfma_ok && (kch == 5 || kch == 10 || kch == 20 || kch == 3) && h->opt_mlp_bf16x3 != 0 && h->opt_mlp_form == 0 && pc_ok) {
+        // producer / consumer form: its own image of W1 | W2, (2 kch + 2) ring stages of 32 KiB, built once per head
+        if (!h->mlp_w1pc) {
+            M2D_HIP_TRY(h, hipMalloc((void **)&h->mlp_w1pc, (size_t)(2 * kch + 2) * PC_STAGE));
+            hipLaunchKernelGGL(m2d_mlp_image_pc_w1, dim3((unsigned)(((int64_t)a.K * MH1 + 255) / 256)), dim3(256), 0, stream,
+                               h->mlp_w1, a.K, reinterpret_cast<__bf16 *>(h->mlp_w1pc));
+            hipLaunchKernelGGL(m2d_mlp_image_pc_w2, dim3(MH1 * MH2 / 256), dim3(256), 0, stream, h->mlp_w2,
+                               reinterpret_cast<__bf16 *>(h->mlp_w1pc) + (size_t)(2 * kch) * (PC_STAGE / 2));
+            M2D_HIP_TRY(h, hipGetLastError());
+        }
+        a.w1x3 = reinterpret_cast<const __bf16 *>(h->mlp_w1pc);
+        const int64_t ntiles = (B + PC_PAIRS - 1) / PC_PAIRS;
+        const unsigned grid = (unsigned)(ntiles < h->num_cu ? ntiles : h->num_cu);
+#define M2D_MLP_PC_CASE(N)                                                                                  \
+    if (kch == N) {                                                                                         \
+        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_mlp_pc<N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                           PC_LDS_BYTES));                                                  \
+        hipLaunchKernelGGL((m2d_mlp_pc<N>), dim3(grid), dim3(512), PC_LDS_BYTES, stream, a);                \
+    }
+        M2D_MLP_PC_CASE(3) M2D_MLP_PC_CASE(5) M2D_MLP_PC_CASE(10) M2D_MLP_PC_CASE(20)
+#undef M2D_MLP_PC_CASE
+        h->last_kernel = "m2d_mlp_pc_bf16x3";
+    } else if (mfma_ok && (kch == 5 || kch == 10 || kch == 20 || kch == 3)) {
         const size_t lds = (size_t)(2 * RING_FLOATS + MH1 + 2 * MH2) * sizeof(float);
         const int64_t ntiles = (B + 32 * MWAVES - 1) / (32 * MWAVES);
         const unsigned grid = (unsigned)(ntiles < h->num_cu ? ntiles : h->num_cu);

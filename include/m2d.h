@@ -217,7 +217,9 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
  * never depend on them.  Two numerical switches, both for build-defined paths: "topk_bf16x3" (default 1) lets
  * m2d_topk_users contract on split-bf16 MFMA (x = hi + lo, three bf16 products, fp32 accumulation; score error
  * ~1e-5 relative, inside the 1e-4 bar) where the mask table is 0/1 and E is 64 or 128; "mlp_bf16x3" (default 1)
- * does the same for layers 1-2 of m2d_score_pairs_mlp; 0 forces the exact-f32 MFMA kernels.  "topk_grouped"
+ * does the same for layers 1-2 of m2d_score_pairs_mlp; 0 forces the exact-f32 MFMA kernels.  "mlp_form" (default 0)
+ * picks between the two split-bf16 head kernels, same results within the split's rounding: 0 = matrix waves fed by
+ * gather / DMA waves, 1 = every wave gathers its own rows.  "topk_grouped"
  * (default 1; see m2d_topk_users) and "topk_form" (0 / 2 = the pipelined split-bf16 retrieval kernel, 1 = its first
  * form; same results) select among retrieval kernels.
  * m2d_score_pairs* (the reference path) is always exact float32.  Unknown names: M2D_ERR_INVALID_ARG. */

@@ -5,11 +5,13 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
-int main()
+int main(int argc, char **argv)
 {
-    const int64_t U = 200000, I = 100000, B = 1 << 20;
+    // optional: table sizes (small tables = scattered rows that hit in L2: separates the address path from HBM)
+    const int64_t U = argc > 1 ? atoll(argv[1]) : 200000, I = argc > 2 ? atoll(argv[2]) : 100000, B = 1 << 20;
     const int C = 4, E = 128;
     const size_t K = (C + 1) * E;
     m2d_engine h;
@@ -23,13 +25,14 @@ int main()
     h.mlp_w1 = dev(K * 256, 0.1f); h.mlp_b1 = dev(256, 0.1f); h.mlp_w2 = dev(256 * 64, 0.1f); h.mlp_b2 = dev(64, 0.1f);
     h.mlp_w3 = dev(64, 0.1f); h.mlp_b3 = 0.f; h.mlp_h1 = 256; h.mlp_h2 = 64;
     hipMalloc(&h.err_dev, 16); hipMemset(h.err_dev, 0, 16);
+    if (argc > 3) h.opt_mlp_form = atoi(argv[3]);
     std::vector<int32_t> hu(B), hi(B);
     for (int64_t i = 0; i < B; ++i) { s = s * 1664525u + 1013904223u; hu[i] = (s >> 4) % U; s = s * 1664525u + 1013904223u; hi[i] = (s >> 4) % I; }
     int32_t *du, *di; float *out;
     hipMalloc(&du, B * 4); hipMalloc(&di, B * 4); hipMalloc(&out, B * 4);
     hipMemcpy(du, hu.data(), B * 4, hipMemcpyHostToDevice); hipMemcpy(di, hi.data(), B * 4, hipMemcpyHostToDevice);
 #if M2D_MLP_DIAG
-    unsigned long long *dbg; hipMalloc(&dbg, 4096 * 8 * 8); hipMemset(dbg, 0, 4096 * 8 * 8); g_m2d_mlp_diag_buffer = dbg;
+    unsigned long long *dbg; hipMalloc(&dbg, 4096 * 8 * 8 + 8 * 128 * 2 * 8); hipMemset(dbg, 0, 4096 * 8 * 8 + 8 * 128 * 2 * 8); g_m2d_mlp_diag_buffer = dbg;
 #endif
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     m2d_launch_score_pairs_mlp(&h, du, di, B, out, nullptr);
@@ -49,9 +52,43 @@ int main()
     {
         std::vector<unsigned long long> hd(2048 * 8);
         hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
+        if (h.opt_mlp_form == 0) {
+            // producer / consumer kernel: per role, cycles per tile per wave
+            double c[8] = {0}, g[8] = {0}, l[8] = {0};
+            for (int b = 0; b < 256; ++b)
+                for (int w = 0; w < 8; ++w) {
+                    double *dst = w < 4 ? c : (w & 1) ? l : g;
+                    for (int k = 0; k < 8; ++k) dst[k] += hd[(b * 8 + w) * 8 + k];
+                }
+            printf("\n  consumer: layer 1 %.0f  barrier wait %.0f  layer 2 %.0f  layer 3 + out %.0f   [%.1f tiles/wave]\n", c[0] / c[4], c[1] / c[4], c[2] / c[4], c[3] / c[4], c[4] / 1024);
+            printf("  gatherer: build (with its row waits) %.0f  row requests %.0f  rest %.0f  barrier %.0f\n", g[0] / g[4], g[1] / g[4], g[2] / g[4], g[3] / g[4]);
+            printf("  loader:   issue %.0f  landing wait %.0f  barrier %.0f\n", l[0] / l[4], l[1] / l[4], l[2] / l[4]);
+            for (int w = 0; w < 8; ++w) {                   // per wave index, averaged over blocks
+                double a[5] = {0};
+                for (int b = 0; b < 256; ++b) for (int k = 0; k < 5; ++k) a[k] += hd[(b * 8 + w) * 8 + k];
+                printf("    wave %d: %.0f %.0f %.0f %.0f\n", w, a[0] / a[4], a[1] / a[4], a[2] / a[4], a[3] / a[4]);
+            }
+        } else {
         double p = 0, l1 = 0, b = 0, l23 = 0, nt = 0, vm = 0, gw = 0, mz = 0;
         for (int w = 0; w < 2048; ++w) { p += hd[w*8]; l1 += hd[w*8+1]; b += hd[w*8+2]; l23 += hd[w*8+3]; nt += hd[w*8+4]; vm += hd[w*8+5]; gw += hd[w*8+6]; mz += hd[w*8+7]; }
         printf("per tile per wave (cycles): prologue %.0f  layer1 %.0f (10 chunks)  vmcnt-wait %.0f  barrier %.0f  layers2-3 %.0f  gather-wait %.0f  make_z %.0f\n", p / nt, l1 / nt, vm / nt, b / nt, l23 / nt, gw / nt, mz / nt);
+        }
+    }
+#endif
+#if M2D_MLP_DIAG & 64
+    {
+        std::vector<unsigned long long> tr(8 * 128 * 2);
+        hipMemcpy(tr.data(), dbg + 4096 * 8, tr.size() * 8, hipMemcpyDeviceToHost);
+        // per barrier: interval since the previous release, and each wave's arrival relative to the release (negative = waited)
+        unsigned long long prev = 0;
+        for (int b = 0; b < 72; ++b) {
+            unsigned long long rel = 0;
+            for (int w = 0; w < 8; ++w) rel = std::max(rel, tr[(w * 128 + b) * 2 + 1]);
+            printf("\n  bar %3d  +%5lld :", b, prev ? (long long)(rel - prev) : 0LL);
+            for (int w = 0; w < 8; ++w) printf(" %6lld", (long long)tr[(w * 128 + b) * 2] - (long long)rel);
+            prev = rel;
+        }
+        printf("\n");
     }
 #endif
     const double fl = 2.0 * (K * 256 + 256 * 64 + 64) * (double)B;

@@ -19,6 +19,6 @@ s=json.load(open(sys.argv[1]+"/summary.json"))
 for k,v in s["kernels"].items():
     if "m2d" in k: print(k[:70], {a:round(b,1) for a,b in v.items()})
 for k,v in s["counters"].items():
-    if "m2d_topk_mfma" in k or "m2d_mlp_mfma" in k:
+    if "m2d_topk" in k or "m2d_mlp" in k:
         print(k[:60]); print({a:(b["avg_per_dispatch"] if isinstance(b,dict) else b) for a,b in v.items()})
 PY

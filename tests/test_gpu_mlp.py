@@ -22,9 +22,10 @@ def _head(K, H1, H2, rng, scale=1.0):
                                               (256, 4, 256, 64, "m2d_mlp_mfma"), (32, 5, 256, 64, "m2d_mlp_mfma"),
                                               (200, 4, 256, 64, "m2d_mlp_generic"), (64, 4, 128, 32, "m2d_mlp_generic"),
                                               (6, 3, 10, 7, "m2d_mlp_generic")])
-@pytest.mark.parametrize("B", [1, 255, 256, 257, 3000])
-@pytest.mark.parametrize("x3", [1, 0])                   # layer 1 on split-bf16 MFMA (default) / exact-f32 MFMA
-def test_mlp_scores_match_restatement(E, C, H1, H2, kernel, B, x3):
+@pytest.mark.parametrize("B", [1, 127, 128, 129, 255, 256, 257, 3000])
+@pytest.mark.parametrize("x3,form", [(1, 0), (1, 1), (0, 0)])   # split-bf16 MFMA: producer / consumer kernel (default),
+                                                                  # every-wave-gathers kernel; exact-f32 MFMA
+def test_mlp_scores_match_restatement(E, C, H1, H2, kernel, B, x3, form):
     import torch
     from foodrec_amd import ScoringEngine
     from oracle import m2d_oracle as oracle
@@ -42,11 +43,13 @@ def test_mlp_scores_match_restatement(E, C, H1, H2, kernel, B, x3):
         eng.score_pairs_mlp(ut, it)
     eng.set_dish_categories(dish_cats)
     eng.set_mlp_head(*head)
-    if kernel == "m2d_mlp_generic" and not x3:
+    if kernel == "m2d_mlp_generic" and (not x3 or form):
         pytest.skip("the generic kernel has one form")
     eng.set_option("mlp_bf16x3", x3)
+    eng.set_option("mlp_form", form)
     got = eng.score_pairs_mlp(ut, it); eng.check()
-    assert eng.last_kernel() == kernel + ("_bf16x3" if x3 and kernel == "m2d_mlp_mfma" else "")
+    want = kernel if kernel == "m2d_mlp_generic" or not x3 else ("m2d_mlp_mfma_bf16x3" if form else "m2d_mlp_pc_bf16x3")
+    assert eng.last_kernel() == want
     ref = oracle.inference_mlp(PM, RE, CE, dish_cats, *head, users, items)
     base = oracle.inference_f64(PM, RE, CE, users, items, dish_cats[items])
     ok = ~np.isnan(ref)
