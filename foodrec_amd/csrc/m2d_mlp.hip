@@ -808,11 +808,20 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
                 pc_barrier();
                 zb ^= 1;
             };
+#if M2D_MLP_DIAG & 16
+            // diag bit 4 (timing only, wrong arithmetic): rows requested ONE period ahead
+#pragma unroll 1
+            for (int q = 0; q < NH - 2; q += 2) {
+                step(0, cu, cd, q + 1, false);
+                step(0, cu, cd, q + 2, false);
+            }
+#else
 #pragma unroll 1
             for (int q = 0; q < NH - 2; q += 2) {
                 step(0, cu, cd, q + 2, false);
                 step(1, cu, cd, q + 3, false);
             }
+#endif
             step(0, nu, nd, 0, false);                                    // the last two request the next tile's rows
             step(1, nu, nd, 1, true);
             // the two W2 periods: nothing to build.  The offsets move up one tile; the ids of the tile after the next

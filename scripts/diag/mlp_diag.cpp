@@ -28,6 +28,12 @@ int main(int argc, char **argv)
     if (argc > 3) h.opt_mlp_form = atoi(argv[3]);
     std::vector<int32_t> hu(B), hi(B);
     for (int64_t i = 0; i < B; ++i) { s = s * 1664525u + 1013904223u; hu[i] = (s >> 4) % U; s = s * 1664525u + 1013904223u; hi[i] = (s >> 4) % I; }
+    if (argc > 4 && atoi(argv[4])) {                        // pairs grouped by user (what a reuse-aware caller would hand over)
+        std::vector<std::pair<int32_t, int32_t>> pr(B);
+        for (int64_t i = 0; i < B; ++i) pr[i] = {hu[i], hi[i]};
+        std::sort(pr.begin(), pr.end());
+        for (int64_t i = 0; i < B; ++i) { hu[i] = pr[i].first; hi[i] = pr[i].second; }
+    }
     int32_t *du, *di; float *out;
     hipMalloc(&du, B * 4); hipMalloc(&di, B * 4); hipMalloc(&out, B * 4);
     hipMemcpy(du, hu.data(), B * 4, hipMemcpyHostToDevice); hipMemcpy(di, hi.data(), B * 4, hipMemcpyHostToDevice);
