@@ -543,11 +543,17 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
                 if (it == 8) { MACC(t_a); pc_barrier(); MACC(t_b); }
+                if (M2D_MLP_DIAG & 256) continue;                         // diag bit 8 (timing only): the memory waves alone
                 const int jt = it + 2;
                 frag(jt < 8 ? h0 : jt < 16 ? h1 : h2, jt & 7, ah[jt & 3], al[jt & 3]);
                 if (it == 10) zread(zb ^ 1);
                 if (it >= 12) split(it - 12, nb);
                 const int nt = it & 7, ksl = it >> 3;
+                if (M2D_MLP_DIAG & 512) {                                  // diag bit 9 (timing only): LDS reads and the split, no MFMA
+                    asm volatile("" ::"v"(ah[it & 3]), "v"(al[it & 3]), "v"(b[ksl][0]), "v"(b[ksl][1]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
                 acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[it & 3], b[ksl][0], acc1[nt], 0, 0, 0);
                 acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[it & 3], b[ksl][1], acc1[nt], 0, 0, 0);
                 acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[it & 3], b[ksl][0], acc1[nt], 0, 0, 0);
@@ -558,6 +564,9 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
         };
         pc_barrier();                                                     // period 0 is published
         MSTAMP(t0_);
+#if M2D_MLP_DIAG
+        const unsigned long long clk0_ = __builtin_amdgcn_s_memtime(), rt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
         frag(0, 0, ah[0], al[0]);
         frag(0, 1, ah[1], al[1]);
         zread(0);
@@ -627,6 +636,7 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
         if (lane == 0 && p.dbg) {
             unsigned long long *d = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 8;
             d[0] = t_a; d[1] = t_b; d[2] = t_c; d[3] = t_d; d[4] = n_t;
+            d[5] = __builtin_amdgcn_s_memtime() - clk0_; d[6] = __builtin_amdgcn_s_memrealtime() - rt0_;
         }
 #endif
         return;

@@ -69,6 +69,7 @@ int main(int argc, char **argv)
             printf("\n  consumer: layer 1 %.0f  barrier wait %.0f  layer 2 %.0f  layer 3 + out %.0f   [%.1f tiles/wave]\n", c[0] / c[4], c[1] / c[4], c[2] / c[4], c[3] / c[4], c[4] / 1024);
             printf("  gatherer: build (with its row waits) %.0f  row requests %.0f  rest %.0f  barrier %.0f\n", g[0] / g[4], g[1] / g[4], g[2] / g[4], g[3] / g[4]);
             printf("  loader:   issue %.0f  landing wait %.0f  barrier %.0f\n", l[0] / l[4], l[1] / l[4], l[2] / l[4]);
+            if (c[6] > 0) printf("  in-kernel clock (consumers): %.0f ticks over %.1f us = %.3f GHz\n", c[5] / 1024, c[6] / 1024 / 100.0, c[5] / c[6] * 0.1);
             for (int w = 0; w < 8; ++w) {                   // per wave index, averaged over blocks
                 double a[5] = {0};
                 for (int b = 0; b < 256; ++b) for (int k = 0; k < 5; ++k) a[k] += hd[(b * 8 + w) * 8 + k];
