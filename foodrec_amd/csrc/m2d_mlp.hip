@@ -551,6 +551,9 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
                 const int nt = it & 7, ksl = it >> 3;
                 if (M2D_MLP_DIAG & 512) {                                  // diag bit 9 (timing only): LDS reads and the split, no MFMA
                     asm volatile("" ::"v"(ah[it & 3]), "v"(al[it & 3]), "v"(b[ksl][0]), "v"(b[ksl][1]));
+                    if (M2D_MLP_DIAG & 1024) {                             // + bit 10: idle for about the three MFMAs' wall time
+                        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     continue;
                 }
