@@ -178,6 +178,43 @@ def usable_cores():
     return max(1, n)
 
 
+def mlp_baseline(torch, PM, RE, CE, dish_cats, head, users, items, user_base, gpu_sample, budget_s):
+    """The build's float64 restatement of the 3-layer head (oracle/m2d_oracle.py::inference_mlp; the head has no reference
+    counterpart) on the first pairs of the timed batch: a live parity check of the TIMED kernel's scores, and its rate
+    on this box's host cores (numpy / BLAS threads as configured) beside the GPU number."""
+    import numpy as np
+    from oracle import m2d_oracle
+    n = gpu_sample.numel()
+    pm, re, ce, dc = PM.cpu().numpy(), RE.cpu().numpy(), CE.cpu().numpy(), dish_cats.cpu().numpy()
+    hd = [h.cpu().numpy() if hasattr(h, "cpu") else h for h in head]
+    u = (users[:n].cpu().numpy() - int(user_base)).astype(np.int64)
+    d = items[:n].cpu().numpy().astype(np.int64)
+    ref = m2d_oracle.inference_mlp(pm, re, ce, dc, *hd, u, d)                 # float64: the parity sample
+    # the rate: the same arithmetic in float32 with the dish vectors built once (as the engine keeps them), on slices
+    # of 65536 pairs of the timed batch
+    Dt = m2d_oracle.dish_vectors(re, ce, dc, m2d_oracle.DEFAULT_COEF, np.float32)
+    W1, b1, W2, b2, w3, b3 = [np.asarray(x, dtype=np.float32) for x in hd]
+    nb = min(65536, users.numel())
+    ub = (users[:nb].cpu().numpy() - int(user_base)).astype(np.int64)
+    db = items[:nb].cpu().numpy().astype(np.int64)
+    pm2 = pm.reshape(pm.shape[0], -1)
+    calls, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < min(budget_s, 10.0) * 0.5:
+        z = pm2[ub] * Dt[db]
+        h2 = np.maximum(np.maximum(z @ W1 + b1, 0) @ W2 + b2, 0)
+        (z.sum(axis=1) + (h2 @ w3 + b3)).sum()
+        calls += 1
+    rate = calls * nb / (time.perf_counter() - t0)
+    got = gpu_sample.cpu().numpy().astype(np.float64)
+    err = float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))))
+    ok = bool(err <= PARITY_TOL and np.array_equal(np.isnan(got), np.isnan(ref)))
+    return ({"value": rate, "unit": "pairs/s", "cores": usable_cores(), "kind": "port",
+             "sample": "numpy float32 restatement of the build-defined head (gather, multiply, two BLAS GEMMs, dot) on %d-pair "
+                       "slices of the timed batch, dish vectors built once, %d calls; parity: float64 restatement on the "
+                       "first %d pairs" % (nb, calls, n),
+             "max_rel_diff_vs_gpu": err, "parity_tolerance": PARITY_TOL, "parity_ok": ok}, ok)
+
+
 def cpu_baseline(torch, PM, RE, CE, users, items, cats, budget_s):
     """CPU restatement of the reference graph (oracle/torch_graph.py) on this box's host cores.
 
@@ -579,9 +616,12 @@ def main():
     if wl in ("mlp", "topk"):
         pat = torch.randint(1, 2 ** C, (I,), generator=g, device=dev, dtype=torch.int32)
         eng.set_dish_categories(((pat[:, None] >> torch.arange(C, device=dev, dtype=torch.int32)[None, :]) & 1).float())
+    mlp_head = mlp_cats = None
     if wl == "mlp":
         rn = lambda *shape: torch.randn(shape, generator=g, device=dev)
-        eng.set_mlp_head(rn(K, 256) / K ** 0.5, rn(256) * 0.1, rn(256, 64) / 16.0, rn(64) * 0.1, rn(64) / 8.0, 0.0)
+        mlp_head = (rn(K, 256) / K ** 0.5, rn(256) * 0.1, rn(256, 64) / 16.0, rn(64) * 0.1, rn(64) / 8.0, 0.0)
+        eng.set_mlp_head(*mlp_head)
+        mlp_cats = ((pat[:, None] >> torch.arange(C, device=dev, dtype=torch.int32)[None, :]) & 1).float()
     if wl == "ingredients" or (wl == "topk" and a.topk_with_ingredients):
         R = a.ingredients
         lens = torch.randint(1, 21, (I,), generator=g, device=dev)          # 1..20 ingredients per dish (build-chosen)
@@ -631,6 +671,7 @@ def main():
     opts_used = {k: eng.get_option(k) for k in ("prefetch", "nt_loads", "blocks_per_cu")}
     Bc = min(1 << 18, B)
     timed_sample = out[:Bc].clone() if wl == "pairs" else None           # parity sample of the TIMED kernel's scores
+    mlp_sample = out[:4096].clone() if wl == "mlp" else None             # same, for the head (checked in mlp_baseline)
 
     rc = 0
     line = None
@@ -740,6 +781,11 @@ def main():
                                           "accumulate)" if x3 else "f32 (v_mfma_f32_32x32x2_f32, exact)"),
                                 "hbm_algorithmic_GBps": hbm, "hbm_frac": hbm / HBM_PEAK_GBS}
             line["dtype"] = "bf16x3" if x3 else "f32"
+            if not a.no_cpu_baseline and world == 1:
+                cb, ok = mlp_baseline(torch, PM, RE, CE, mlp_cats, mlp_head, users, items, user_base, mlp_sample, a.cpu_seconds)
+                line["cpu_baseline"] = cb
+                if not ok:
+                    rc = 3
         if wl == "ingredients":
             bpp_i = (C + 3) * E * 4 + C * 4 + 12                       # one extra E-float row per pair
             ach = bpp_i * B / (avg_ms * 1e-3) / 1e9
@@ -768,6 +814,11 @@ def main():
                                 "dtype": ("split bf16 (3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)" if x3 else
                                           "f32 (v_mfma_f32_32x32x2_f32, exact)")}
             line["dtype"] = "bf16x3" if x3 else "f32"
+            if not a.no_cpu_baseline and world == 1:
+                cb, ok = mlp_baseline(torch, PM, RE, CE, mlp_cats, mlp_head, users, items, user_base, mlp_sample, a.cpu_seconds)
+                line["cpu_baseline"] = cb
+                if not ok:
+                    rc = 3
         if not a.no_side and wl == "pairs":
             nr, probe, hbm_only = side_measurements(torch, eng, PM, U, I, C, E, dev, user_base)
             line["roofline"]["no_reuse"] = nr

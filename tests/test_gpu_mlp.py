@@ -99,3 +99,38 @@ def test_mlp_with_ingredient_table():
     got = eng.score_pairs_mlp(torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda")); eng.check()
     H = oracle.dish_high_vectors(ING, off, ids)
     assert_scores_close(got.cpu().numpy(), oracle.inference_mlp(PM, RE, CE, dish_cats, *head, users, items, dish_high=H))
+
+
+@pytest.mark.parametrize("E,B", [(128, 300_001), (64, 200_000), (32, 150_017)])
+def test_mlp_many_tiles_per_block(E, B):
+    """Batches of several tiles per workgroup: the producer / consumer kernel's steady state (row requests, ring stages
+    and z sets that cross tile boundaries, the id conversion two tiles ahead) -- the small cases above run one tile per
+    workgroup.  Every score against the every-wave-gathers kernel (an independent implementation), a sample against the
+    float64 restatement, and an out-of-range id deep in the batch."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    C = 4 if E != 32 else 5
+    U, I = 5000, 3000
+    PM, RE, CE, users, items, _ = random_case(U, I, C, E, B, seed=E)
+    rng = np.random.default_rng(E + 7)
+    dish_cats = rng.integers(0, 2, (I, C)).astype(np.float32)
+    dish_cats[dish_cats.sum(1) == 0, 1] = 1
+    head = _head((C + 1) * E, 256, 64, rng, scale=4.0)
+    eng = ScoringEngine(PM, RE, CE); eng.set_dish_categories(dish_cats); eng.set_mlp_head(*head)
+    ut, it = torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda")
+    got = eng.score_pairs_mlp(ut, it); eng.check()
+    assert eng.last_kernel() == "m2d_mlp_pc_bf16x3"
+    eng.set_option("mlp_form", 1)
+    other = eng.score_pairs_mlp(ut, it); eng.check()
+    assert eng.last_kernel() == "m2d_mlp_mfma_bf16x3"
+    eng.set_option("mlp_form", 0)
+    g, o = got.cpu().numpy(), other.cpu().numpy()
+    assert np.isfinite(g).all()
+    assert np.max(np.abs(g - o) / np.maximum(1.0, np.abs(o))) < 5e-5      # two split-bf16 kernels, different summation orders
+    pick = np.concatenate([np.arange(0, 300), rng.integers(0, B, 3000), np.arange(B - 300, B)])
+    ref = oracle.inference_mlp(PM, RE, CE, dish_cats, *head, users[pick], items[pick])
+    assert_scores_close(g[pick], ref, what="E%d sample" % E)
+    bad = items.copy(); pos = B - 12_345; bad[pos] = I + 3
+    with pytest.raises(IndexError, match="item id %d at position %d" % (I + 3, pos)):
+        out = eng.score_pairs_mlp(ut, torch.as_tensor(bad, device="cuda")); eng.check()
