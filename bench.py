@@ -42,9 +42,15 @@ INFINITY_CACHE_BYTES = 256 << 20   # tables smaller than this never leave the di
 PARITY_TOL = 1e-4            # north_star: scores within 1e-4 fp32, as |d| <= tol * max(1, |ref|)
 
 
-def algorithmic_bytes_per_pair(C: int, E: int) -> int:
-    """user block + dish row + mask + two ids + score."""
-    return (C + 2) * E * 4 + C * 4 + 12
+def algorithmic_bytes_per_pair(C: int, E: int, mean_active=None):
+    """user block + dish row + mask + two ids + score.
+
+    `mean_active` (the batch's mean number of categories with a non-zero mask weight): the byte count of the path as
+    built -- the Personal_Memory row of a category whose weight is 0 is multiplied by 0 in the reference graph
+    (Model_Recommender.py:82) and is not fetched, so a pair needs U_high + `active` low-level rows, not C + 1 rows."""
+    if mean_active is None:
+        return (C + 2) * E * 4 + C * 4 + 12
+    return (2.0 + mean_active) * E * 4 + C * 4 + 12
 
 
 def parse():
@@ -510,7 +516,8 @@ def ingredients_leg(torch, eng, users, items, cats, I, C, E, dev, R):
     eng.clear_ingredients()
     ms = median(per)
     B = users.numel()
-    bpp = (C + 3) * E * 4 + C * 4 + 12
+    active = float((cats != 0).sum(1).float().mean().item()) if eng.get_option("skip_masked") != 0 else float(C)
+    bpp = (3.0 + active) * E * 4 + C * 4 + 12          # U_high + H[d] + RE[d] + the low-level rows of the active categories
     return {"ingredient_rows": R, "ingredients_per_dish": "uniform 1..20", "kernel": kern, "kernel_median_ms": ms,
             "pairs_per_s": B / ms * 1e3, "algorithmic_bytes_per_pair": bpp, "achieved": bpp * B / ms / 1e6, "unit": "GB/s",
             "frac": bpp * B / ms / 1e6 / HBM_PEAK_GBS,
@@ -668,7 +675,7 @@ def main():
 
     # what the timed region ran and produced -- read BEFORE any side leg launches another kernel or writes a buffer
     kernel_used = eng.last_kernel()
-    opts_used = {k: eng.get_option(k) for k in ("prefetch", "nt_loads", "blocks_per_cu")}
+    opts_used = {k: eng.get_option(k) for k in ("prefetch", "nt_loads", "blocks_per_cu", "skip_masked")}
     Bc = min(1 << 18, B)
     timed_sample = out[:Bc].clone() if wl == "pairs" else None           # parity sample of the TIMED kernel's scores
     mlp_sample = out[:4096].clone() if wl == "mlp" else None             # same, for the head (checked in mlp_baseline)
@@ -676,7 +683,10 @@ def main():
     rc = 0
     line = None
     if rank == 0:
-        bpp = algorithmic_bytes_per_pair(C, E)
+        bpp_survey = algorithmic_bytes_per_pair(C, E)
+        skip = wl in ("pairs", "ingredients") and eng.get_option("skip_masked") != 0
+        mean_active = float((cats != 0).sum(1).float().mean().item()) if skip else float(C)
+        bpp = algorithmic_bytes_per_pair(C, E, mean_active) if skip else bpp_survey
         avg_ms = sum(per_launch_ms) / len(per_launch_ms)
         achieved = bpp * B / (avg_ms * 1e-3) / 1e9
         traffic = None
@@ -684,7 +694,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = "E%d_B%d_U%d_I%d" % (E, B, U, I)
+                key = "E%d_B%d_U%d_I%d%s" % (E, B, U, I, "_skip" if skip else "")
                 traffic = tj.get(key, {}).get("fabric_bytes_per_launch", tj.get(key, {}).get("hbm_bytes_per_launch"))
             except Exception:
                 traffic = None
@@ -711,6 +721,15 @@ def main():
                          "kernel_avg_ms": avg_ms, "algorithmic_bytes_per_pair": bpp, "pairs_per_launch": B,
                          "table_bytes": table_bytes},
         }
+        if skip:
+            line["roofline"].update({
+                "mean_active_categories": mean_active, "survey_bytes_per_pair": bpp_survey,
+                "bytes_model": "mask-aware: (2 + active categories) x E x 4 + C x 4 + 12 per pair, averaged over the batch. "
+                               "SURVEY.md 8d's count charges all C low-level rows of the user block (%d B); the rows of "
+                               "categories whose mask weight is 0 are multiplied by 0 in the reference graph and this "
+                               "kernel does not fetch them (option skip_masked, default 1), so by that count the same run "
+                               "would read %.3f of the peak -- more bytes than were moved" %
+                               (bpp_survey, bpp_survey * B / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)})
 
     # the headline is complete here; everything below decorates it.  Should a leg never return (a collective that
     # does not complete on some rank), rank 0 still prints the line and every rank leaves.
@@ -787,7 +806,7 @@ def main():
                 if not ok:
                     rc = 3
         if wl == "ingredients":
-            bpp_i = (C + 3) * E * 4 + C * 4 + 12                       # one extra E-float row per pair
+            bpp_i = (3.0 + mean_active) * E * 4 + C * 4 + 12            # one extra E-float row per pair
             ach = bpp_i * B / (avg_ms * 1e-3) / 1e9
             line["config"]["workload"] = ("BASELINE configs[1] WITH the build-defined ingredient table: %d users x %d dishes "
                                           "x %d ingredients per GPU, 1-20 ingredients per dish, E=%d; high-level path from the "

@@ -548,6 +548,7 @@ int m2d_set_option(m2d_engine *h, const char *name, int64_t value)
     else if (!strcmp(name, "topk_grouped")) h->opt_topk_grouped = (int)value;
     else if (!strcmp(name, "mlp_bf16x3")) h->opt_mlp_bf16x3 = (int)value;
     else if (!strcmp(name, "mlp_form")) h->opt_mlp_form = (int)value;
+    else if (!strcmp(name, "skip_masked")) h->opt_skip_masked = (int)value;
     else return fail(h, M2D_ERR_INVALID_ARG, "m2d_set_option: unknown option");
     return M2D_OK;
 }
@@ -564,6 +565,7 @@ int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value)
     else if (!strcmp(name, "topk_grouped")) *value = h->opt_topk_grouped;
     else if (!strcmp(name, "mlp_bf16x3")) *value = h->opt_mlp_bf16x3;
     else if (!strcmp(name, "mlp_form")) *value = h->opt_mlp_form;
+    else if (!strcmp(name, "skip_masked")) *value = h->opt_skip_masked;
     else if (!strcmp(name, "num_cu")) *value = h->num_cu;
     else return M2D_ERR_INVALID_ARG;
     return M2D_OK;

@@ -77,6 +77,7 @@ struct m2d_engine {
     int opt_nt = 1;
     int opt_blocks_per_cu = 8;
     int opt_variant = 0;
+    int opt_skip_masked = 1;            // pair kernels: rows of categories with mask weight 0 are not fetched (their products are 0)
     int opt_mlp_form = 0;               // split-bf16 MLP head: 0 = matrix waves fed by gather / DMA waves (m2d_mlp_pc), 1 = every wave gathers its own rows
     int opt_mlp_bf16x3 = 1;             // MLP head layer 1 (build-defined) on split-bf16 MFMA; 0 = exact-f32 MFMA
     int opt_topk_bf16x3 = 1;            // retrieval (build-defined) on split-bf16 MFMA; 0 = exact-f32 MFMA

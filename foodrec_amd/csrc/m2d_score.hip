@@ -38,6 +38,7 @@ struct ScoreArgs {
     float a;
     float b;
     int32_t *err;
+    int32_t skip_masked;   // do not fetch the Personal_Memory rows of categories whose mask weight is 0 (their products are 0)
 };
 
 __device__ __forceinline__ void latch_error(int32_t *err, int code, int64_t value, int64_t index)
@@ -134,6 +135,9 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
             m = BYDISH ? cp[did] : cp[pi];
         }
         const int32_t ul32 = (int32_t)ul;
+        // categories whose weight is exactly 0 contribute 0 * U_low[c] = 0 to :82-:90: their rows are not fetched
+        // (a NaN weight compares unequal to 0 and keeps its row)
+        const int32_t act = p.skip_masked ? ((m.x != 0.f ? 1 : 0) | (m.y != 0.f ? 2 : 0) | (m.z != 0.f ? 4 : 0) | (m.w != 0.f ? 8 : 0)) : 15;
 
         v4f ub[PF][C + 1];
         v4f ib[PF];
@@ -143,9 +147,14 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
         auto issue = [&](int s, int slot) {
             const int32_t us = __shfl(ul32, s, LPP);
             const int32_t ds = __shfl(did, s, LPP);
+            const int32_t as = __shfl(act, s, LPP);
             const v4f *pu = pm4 + (size_t)us * urow4 + jc;
+            ub[slot][0] = ld4<NT>(pu);
 #pragma unroll
-            for (int r = 0; r <= C; ++r) ub[slot][r] = ld4<NT>(pu + (size_t)r * E4);
+            for (int r = 1; r <= C; ++r) {
+                ub[slot][r] = v4f{0.f, 0.f, 0.f, 0.f};
+                if ((as >> (r - 1)) & 1) ub[slot][r] = ld4<NT>(pu + (size_t)r * E4);
+            }
             ib[slot] = re4[(size_t)ds * E4 + jc];
             if constexpr (HV) hb[slot] = hv4[(size_t)ds * E4 + jc];
         };
@@ -247,8 +256,13 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4_small(ScoreArgs p)
         }
         const v4f *pu = pm4 + (size_t)ul * urow4 + jc;
         v4f ub[C + 1];
+        const float mw[C] = {m.x, m.y, m.z, m.w};
+        ub[0] = pu[0];
 #pragma unroll
-        for (int r = 0; r <= C; ++r) ub[r] = pu[(size_t)r * E4];
+        for (int r = 1; r <= C; ++r) {                     // a category of weight 0 contributes 0: its row is not fetched
+            ub[r] = v4f{0.f, 0.f, 0.f, 0.f};
+            if (!p.skip_masked || mw[r - 1] != 0.f) ub[r] = pu[(size_t)r * E4];
+        }
         const v4f ib = re4[(size_t)did * E4 + jc];
         v4f hb = {0.f, 0.f, 0.f, 0.f};
         if constexpr (HV) hb = hv4[(size_t)did * E4 + jc];
@@ -312,6 +326,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_generic(ScoreArgs p)
         for (int c = 0; c < C; ++c) {
             const float mc = mrow[c];
             n += mc;
+            if (p.skip_masked && mc == 0.f) continue;      // 0 * row = 0: the row is not fetched
             for (int e = lane; e < E; e += 64) {
                 if (!p.hv) hs = fmaf(um[e], mc * p.ce[(size_t)c * E + e], hs);
                 ls = fmaf(it[e], mc * um[(size_t)(c + 1) * E + e], ls);
@@ -409,5 +424,6 @@ int m2d_launch_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *i
     a.users = users; a.items = items; a.cats = cats; a.out = out;
     a.B = B; a.U = h->U; a.I = h->I; a.user_base = h->user_base;
     a.E = h->E; a.C = h->C; a.a = h->a; a.b = h->b; a.err = h->err_dev;
+    a.skip_masked = h->opt_skip_masked;
     return by_dish ? launch_any<true>(h, a, stream) : launch_any<false>(h, a, stream);
 }

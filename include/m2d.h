@@ -213,7 +213,12 @@ int m2d_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_t *item
  * bad_value / bad_index (host pointers, may be NULL) receive the offending id and its position. */
 int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_index);
 
-/* Kernel-selection knobs for benchmarking ("prefetch", "nt_loads", "blocks_per_cu", "variant"): results
+/* "skip_masked" (default 1): the pair kernels do not fetch the Personal_Memory row of a category whose mask weight is
+ * exactly 0 -- the reference graph multiplies that row by 0 (Model_Recommender.py:82), so for finite tables the score
+ * is the same to the bit and a pair moves (2 + active categories) x E x 4 bytes of rows instead of (C + 2) x E x 4.
+ * The one input on which it shows is a non-finite value inside such a row (0 x inf = NaN in the literal graph); 0
+ * restores the literal fetch-and-multiply.
+ * Kernel-selection knobs for benchmarking ("prefetch", "nt_loads", "blocks_per_cu", "variant"): results
  * never depend on them.  Two numerical switches, both for build-defined paths: "topk_bf16x3" (default 1) lets
  * m2d_topk_users contract on split-bf16 MFMA (x = hi + lo, three bf16 products, fp32 accumulation; score error
  * ~1e-5 relative, inside the 1e-4 bar) where the mask table is 0/1 and E is 64 or 128; "mlp_bf16x3" (default 1)

@@ -19,6 +19,9 @@ def test_algorithmic_bytes_follow_survey_8d():
     b = _bench()
     # (C+2)*E*4 + C*4 + 12: SURVEY.md section 8d
     assert [b.algorithmic_bytes_per_pair(4, E) for E in (32, 64, 128, 200)] == [796, 1564, 3100, 4828]
+    # mask-aware count: U_high + the rows of the categories a dish has; all four categories = the survey's count
+    assert b.algorithmic_bytes_per_pair(4, 64, 4.0) == 1564
+    assert b.algorithmic_bytes_per_pair(4, 64, 1.0) == 3 * 256 + 28
     assert b.HBM_PEAK_GBS == 8000.0
 
 

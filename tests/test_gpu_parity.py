@@ -245,3 +245,35 @@ def test_host_buffer_call_equals_the_device_op(torch_cuda, B):
     assert np.array_equal(eng.score_pairs_host(users, items, cats), ref, equal_nan=True)      # latch cleared, engine usable
     with pytest.raises(ValueError):
         eng.score_pairs_host(users, items[:-1] if B > 1 else np.zeros(2, np.int32), cats)
+
+
+@pytest.mark.parametrize("E,B", [(64, 5000), (200, 700), (24, 300)])       # c4 kernel (full / partial groups) and the small-batch form
+def test_rows_of_weight_zero_categories_are_not_needed(E, B):
+    """The Personal_Memory row of a category whose mask weight is 0 is multiplied by 0 (Model_Recommender.py:82): the
+    kernels do not fetch it (option skip_masked, default 1).  Same scores either way for finite tables; a non-finite
+    value in such a row is the one input on which the literal graph (0 * inf = NaN, option 0) and the default differ."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    U, I, C = 400, 300, 4
+    PM, RE, CE, users, items, cats = random_case(U, I, C, E, B, seed=E + 1)
+    rng = np.random.default_rng(E)
+    cats = (rng.integers(1, 16, B)[:, None] >> np.arange(C)[None, :] & 1).astype(np.float32)      # non-empty 0/1 masks
+    cats[::7] *= rng.uniform(0.5, 2.0, (len(cats[::7]), C)).astype(np.float32)                    # some weighted masks
+    eng = ScoringEngine(PM, RE, CE)
+    ut, it, ct = (torch.as_tensor(x, device="cuda") for x in (users, items, cats))
+    on = eng.score_pairs(ut, it, ct).cpu().numpy(); eng.check()
+    eng.set_option("skip_masked", 0)
+    off = eng.score_pairs(ut, it, ct).cpu().numpy(); eng.check()
+    assert np.array_equal(on, off)                                          # the skipped terms are exact zeros
+    assert_scores_close(on, oracle.inference_f64(PM, RE, CE, users, items, cats))
+    # poison the row of a category pair 0 does not have
+    c0 = int(np.flatnonzero(cats[0] == 0)[0]) if (cats[0] == 0).any() else None
+    if c0 is not None:
+        PM2 = PM.copy(); PM2[users[0], c0 + 1, :] = np.inf
+        eng2 = ScoringEngine(PM2, RE, CE)
+        got = eng2.score_pairs(ut[:1], it[:1], ct[:1]).cpu().numpy(); eng2.check()
+        assert got[0] == on[0]                                              # default: the row is never read
+        eng2.set_option("skip_masked", 0)
+        lit = eng2.score_pairs(ut[:1], it[:1], ct[:1]).cpu().numpy(); eng2.check()
+        assert np.isnan(lit[0]) and np.isnan(oracle.inference_f64(PM2, RE, CE, users[:1], items[:1], cats[:1])[0])
