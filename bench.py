@@ -789,11 +789,19 @@ def main():
                                           "uniform random pairs, masks from the resident dish table" % (U, I, C, E, K))
             x3 = kernel_used.endswith("bf16x3")
             # split-bf16 form: layers 1-2 run as 3 bf16 MFMAs per product (executed flops = 3 x algorithmic) against the
-            # dense bf16 peak; the exact form runs everything on the f32 MFMA against its peak
-            ex = 3.0 * 2.0 * (K * 256 + 256 * 64) * B / (avg_ms * 1e-3) / 1e12 if x3 else tf
+            # dense bf16 peak; the exact form runs everything on the f32 MFMA against its peak.  The producer / consumer
+            # kernel groups the pairs by dish mask pattern and runs only the k-blocks a pattern keeps (the E k-values of a
+            # category of weight 0 are zeros in z): executed flops and fetched bytes count those blocks only
+            grouped = kernel_used.startswith("m2d_mlp_pc") and eng.get_option("skip_masked") != 0 and E >= 64
+            act = float((mlp_cats[items.long()] != 0).sum(1).float().mean().item()) if grouped else float(C)
+            Ka = (1.0 + act) * E                                          # k-values of layer 1 actually multiplied, per pair
+            ex = 3.0 * 2.0 * (Ka * 256 + 256 * 64) * B / (avg_ms * 1e-3) / 1e12 if x3 else tf
+            dense_ex = 3.0 * 2.0 * (K * 256 + 256 * 64) * B / (avg_ms * 1e-3) / 1e12 if x3 else tf
             peak = 2500.0 if x3 else 157.3
-            hbm = (2 * K * 4 + 12) * B / (avg_ms * 1e-3) / 1e9
+            hbm = (2 * Ka * 4 + 12) * B / (avg_ms * 1e-3) / 1e9
             line["roofline"] = {"bound": "mfma", "achieved": ex, "peak": peak, "unit": "TFLOP/s", "frac": ex / peak,
+                                "mean_active_categories": act, "k_values_multiplied_per_pair": Ka,
+                                "dense_equivalent_frac": dense_ex / peak,
                                 "traffic": None, "kernel_avg_ms": avg_ms, "flop_per_pair": fl, "pairs_per_launch": B,
                                 "algorithmic_tflops": tf, "f32_mfma_equivalent_frac": tf / 157.3,
                                 "dtype": ("split bf16 for layers 1-2 (3 x v_mfma_f32_32x32x16_bf16 per product, fp32 "

@@ -80,6 +80,7 @@ void release(m2d_engine *h)
     }
     if (h->mlp_w1x3) (void)hipFree(h->mlp_w1x3);
     if (h->mlp_w1pc) (void)hipFree(h->mlp_w1pc);
+    if (h->mlp_pg) (void)hipFree(h->mlp_pg);
     if (h->dish_high) (void)hipFree(h->dish_high);
     if (h->own_ing) {
         if (h->ing) (void)hipFree((void *)h->ing);

@@ -45,6 +45,8 @@ struct m2d_engine {
     bool own_mlp = false;
     void *mlp_w1x3 = nullptr;           // split-bf16 image of W1 for the bf16x3 layer-1 path (built lazily)
     void *mlp_w1pc = nullptr;           // W1 | W2 image of the producer / consumer kernel (built lazily)
+    int32_t *mlp_pg = nullptr;          // per-launch pair grouping of that kernel: histogram | tile count | tile blocks | slot -> pair
+    size_t mlp_pg_cap = 0;              // ints
 
     // factored dish vectors for catalogue retrieval (built lazily by m2d_topk_users)
     float *dish_vec = nullptr;  // [I_pad, (C+1)*E]

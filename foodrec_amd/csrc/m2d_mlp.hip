@@ -58,6 +58,11 @@ struct MlpArgs {
     const __bf16 *w1x3;        // split-bf16 image of W1 (m2d_mlp_split_w1), or null
     const __bf16 *w2x3;        // split-bf16 fragment image of W2 (m2d_mlp_split_w2), or null
     unsigned long long *dbg;   // scripts/diag only
+    // producer / consumer kernel: pairs grouped by dish mask pattern (m2d_mlp_pg_* below)
+    const int32_t *perm;         // [ntiles * 128] slot -> pair index, -1 = padding
+    const uint32_t *tile_blocks; // [ntiles] the E-wide k-blocks a tile's pattern keeps: nibble j = j-th block, bits 28-31 = count
+    const int32_t *ntiles_dev;   // [1]
+    int32_t pshift;              // log2(periods of 32 k-values per block)
 };
 
 __device__ __forceinline__ void latch(int32_t *err, int code, int64_t value, int64_t index)
@@ -453,6 +458,95 @@ __global__ __launch_bounds__(256) void m2d_mlp_image_pc_w2(const float *w2, __bf
     half[2 * 2048 + e] = (__bf16)(x - (float)hi);
 }
 
+// ---- pairs grouped by dish mask pattern ------------------------------------------------------------------------
+// The E k-values of a category whose mask weight is 0 are zeros in the dish vector: z = 0 there whatever the user row
+// holds, and a tile whose 128 pairs all lack that category can skip those periods altogether -- their MFMAs, their
+// share of the W1 stream and their row requests.  So a launch first buckets its pairs by the dish's pattern of
+// non-zero weights (a histogram, a scan that pads every bucket to whole tiles, a scatter of pair indices) and the
+// kernel walks tiles of one pattern each; scores go back to out[pair].  With uniform non-empty subsets of 4
+// categories a tile runs (1 + 2.13) / 5 of the periods on average.  group = 0 (option skip_masked = 0, or blocks that
+// are not a power-of-two number of periods): one bucket, every block.
+constexpr int PG_MAXPAT = 64;             // C <= 6: up to 7 blocks fit the nibbles of a word beside their count
+
+__device__ __forceinline__ int pg_pattern(const float *cats, int C, int64_t I, int32_t did, int group)
+{
+    if (!group || did < 0 || (int64_t)did >= I) return (1 << C) - 1;      // bad ids: any bucket (the gatherer reports them)
+    int pat = 0;
+    for (int c = 0; c < C; ++c) pat |= (cats[(size_t)did * C + c] != 0.f ? 1 : 0) << c;
+    return pat;
+}
+
+__global__ __launch_bounds__(256) void m2d_mlp_pg_hist(const int32_t *items, int64_t B, int64_t I, const float *cats, int C,
+                                                       int group, int32_t *hist)
+{
+    __shared__ int32_t sh[PG_MAXPAT];
+    if (threadIdx.x < PG_MAXPAT) sh[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B; i += (int64_t)gridDim.x * 256)
+        atomicAdd(&sh[pg_pattern(cats, C, I, items[i], group)], 1);
+    __syncthreads();
+    if (threadIdx.x < PG_MAXPAT && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+}
+
+// one block: bucket starts (whole tiles), each tile's block word, the tile count; hist becomes the scatter cursors
+__global__ __launch_bounds__(256) void m2d_mlp_pg_scan(int32_t *hist, int C, uint32_t *tile_blocks, int32_t *ntiles)
+{
+    __shared__ int32_t start[PG_MAXPAT + 1];
+    const int npat = 1 << C;
+    if (threadIdx.x == 0) {
+        int32_t t = 0;
+        for (int q = 0; q < npat; ++q) {
+            start[q] = t;
+            t += (hist[q] + PC_PAIRS - 1) / PC_PAIRS;
+        }
+        start[npat] = t;
+        ntiles[0] = t;
+    }
+    __syncthreads();
+    for (int q = 0; q < npat; ++q) {
+        uint32_t w = 0;                                                   // block 0 (the high-level E values) always
+        int nb = 1;
+        for (int c = 0; c < C; ++c)
+            if ((q >> c) & 1) w |= (uint32_t)(c + 1) << (4 * nb++);
+        w |= (uint32_t)nb << 28;
+        for (int t = start[q] + threadIdx.x; t < start[q + 1]; t += 256) tile_blocks[t] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < npat) hist[threadIdx.x] = start[threadIdx.x] * PC_PAIRS;
+}
+
+// chunks of 4096 pairs: count per pattern in LDS, reserve each pattern's range with ONE global add per chunk, place
+__global__ __launch_bounds__(256) void m2d_mlp_pg_scatter(const int32_t *items, int64_t B, int64_t I, const float *cats, int C,
+                                                          int group, int32_t *cursor, int32_t *perm)
+{
+    __shared__ int32_t cnt[PG_MAXPAT], base[PG_MAXPAT];
+    constexpr int CH = 4096;
+    for (int64_t c0 = (int64_t)blockIdx.x * CH; c0 < B; c0 += (int64_t)gridDim.x * CH) {
+        if (threadIdx.x < PG_MAXPAT) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        int pat[CH / 256];
+#pragma unroll
+        for (int r = 0; r < CH / 256; ++r) {
+            const int64_t i = c0 + r * 256 + threadIdx.x;
+            pat[r] = i < B ? pg_pattern(cats, C, I, items[i], group) : -1;
+            if (pat[r] >= 0) atomicAdd(&cnt[pat[r]], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x < PG_MAXPAT) {
+            const int n = cnt[threadIdx.x];
+            base[threadIdx.x] = n ? atomicAdd(&cursor[threadIdx.x], n) : 0;
+            cnt[threadIdx.x] = 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CH / 256; ++r) {
+            const int64_t i = c0 + r * 256 + threadIdx.x;
+            if (pat[r] >= 0) perm[base[pat[r]] + atomicAdd(&cnt[pat[r]], 1)] = (int32_t)i;
+        }
+        __syncthreads();
+    }
+}
+
 #if M2D_MLP_DIAG & 64
 // diag bit 6: block 0 logs every wave's arrival at and release from its first 128 barriers
 #define pc_barrier() do { unsigned long long ta_, tr_; MSTAMP(ta_); asm volatile("s_barrier" ::: "memory"); MSTAMP(tr_); \
@@ -481,8 +575,18 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
     float *sb1 = reinterpret_cast<float *>(pcs + PC_B1_OFF);            // [256]
     float *sb2 = sb1 + MH1, *sw3 = sb2 + MH2;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    constexpr int K = KCH * 64, NH = 2 * KCH, NP = NH + 2;
-    const int64_t ntiles = (p.B + PC_PAIRS - 1) / PC_PAIRS;
+    constexpr int K = KCH * 64, NH = 2 * KCH;
+    // tiles of one mask pattern each (m2d_mlp_pg_scan); without grouping (perm == null): the pairs as they come, every block
+    const int64_t ntiles = p.perm ? (int64_t)__builtin_amdgcn_readfirstlane(p.ntiles_dev[0]) : (p.B + PC_PAIRS - 1) / PC_PAIRS;
+    if ((int64_t)blockIdx.x >= ntiles) return;                            // the grid is sized for the most tiles B pairs can make
+    const int pshift = p.pshift;
+    // a tile keeps the k-blocks of its pattern: its periods are kmap(0 .. nper - 1), then the two W2 stages NH, NH + 1
+    auto tile_word = [&](int64_t tile) {
+        return p.perm ? (uint32_t)__builtin_amdgcn_readfirstlane((int)p.tile_blocks[tile])
+                      : (0x06543210u | ((uint32_t)(NH >> pshift) << 28));             // every block: nibble j = j, count = K / E
+    };
+    auto nper_of = [&](uint32_t w) { return (int)(w >> 28) << pshift; };
+    auto kmap = [&](uint32_t w, int q) { return (int)(((w >> (4 * (q >> pshift))) & 15u) << pshift) | (q & ((1 << pshift) - 1)); };
 #if M2D_MLP_DIAG & 64
     int nbar_ = 0;
 #endif
@@ -580,8 +684,9 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
             for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc1[nt][r] = sb1[hidden_unit<true>(nt, r, h)];
+            const int nper = nper_of(tile_word(tile));                    // even (blocks of >= 2 periods, or every block)
 #pragma unroll 1
-            for (int kc = 0; kc < KCH; ++kc) {
+            for (int kc = 0; kc < nper / 2; ++kc) {
                 period(bA, bB);
                 period(bB, bA);
             }
@@ -629,8 +734,9 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
                 for (int r = 0; r < 16; ++r)
                     o = fmaf(sw3[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h], fmaxf(acc2[mt][r], 0.f), o);
             o += __shfl_xor(o, 32, 64);
-            const int64_t pi = tile * PC_PAIRS + wave * 32 + pl;
-            if (h == 0 && pi < p.B) p.out[pi] = sbase[wave * 32 + pl] + (o + p.b3);
+            const int64_t slot = tile * PC_PAIRS + wave * 32 + pl;
+            const int32_t pi = p.perm ? p.perm[slot] : (slot < p.B ? (int32_t)slot : -1);   // -1: padding
+            if (h == 0 && pi >= 0) p.out[pi] = sbase[wave * 32 + pl] + (o + p.b3);
 #if M2D_MLP_DIAG
             MACC(t_d); ++n_t;
 #endif
@@ -681,9 +787,13 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
 #if M2D_MLP_DIAG
             ++n_t;
 #endif
+            const uint32_t tw = tile_word(tile);
+            const int nper = nper_of(tw);
 #pragma unroll 1
-            for (int q = 0; q < NP; ++q) {
-                dma(q + 1 < NP ? q + 1 : 0);                              // the stage after the one about to be published
+            for (int q = 0; q < nper + 2; ++q) {
+                // the stage after the one about to be published: this tile's next period, W2's two halves, the next
+                // tile's first period (block 0 of every pattern)
+                dma(q + 1 < nper ? kmap(tw, q + 1) : q + 1 == nper ? NH : q + 1 == nper + 1 ? NH + 1 : 0);
                 MACC(t_a);
                 pc_wait_vmem<16>();                                       // stage q landed; the one just requested stays in flight
                 MACC(t_b);
@@ -716,21 +826,26 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
         unsigned badmask = 0, nbadmask = 0;
         v4f ra[2][8], rb_[2][8];
         v2f_pc base[8];
+        int32_t npi[8];                                                   // pair index of each slot of the tile being converted
         auto load_ids = [&](int64_t tile) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                int64_t pi = tile * PC_PAIRS + 64 * g + 8 * i + r8;
-                if (pi >= p.B) pi = p.B - 1;                              // any valid pair; masked when converted
+                const int64_t slot = tile * PC_PAIRS + 64 * g + 8 * i + r8;
+                npi[i] = p.perm ? p.perm[slot] : (slot < p.B ? (int32_t)slot : -1);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int32_t pi = npi[i] >= 0 ? npi[i] : 0;              // padding slot: any valid pair; masked when converted
                 nu[i] = (uint32_t)p.users[pi];
                 nd[i] = (uint32_t)p.items[pi];
             }
         };
-        auto convert_ids = [&](int64_t tile) __attribute__((always_inline)) {
+        auto convert_ids = [&](int64_t) __attribute__((always_inline)) {
             nbadmask = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int64_t pi = tile * PC_PAIRS + 64 * g + 8 * i + r8;
-                const bool valid = pi < p.B;
+                const int64_t pi = npi[i];
+                const bool valid = pi >= 0;
                 const int32_t uid = (int32_t)nu[i], did = (int32_t)nd[i];
                 int64_t ul = (int64_t)uid - p.user_base;
                 int32_t dl = did;
@@ -824,15 +939,17 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
 #if M2D_MLP_DIAG & 16
             // diag bit 4 (timing only, wrong arithmetic): rows requested ONE period ahead
 #pragma unroll 1
-            for (int q = 0; q < NH - 2; q += 2) {
+            for (int q = 0; q < nper_of(tile_word(tile)) - 2; q += 2) {
                 step(0, cu, cd, q + 1, false);
                 step(0, cu, cd, q + 2, false);
             }
 #else
+            const uint32_t tw = tile_word(tile);
+            const int nper = nper_of(tw);
 #pragma unroll 1
-            for (int q = 0; q < NH - 2; q += 2) {
-                step(0, cu, cd, q + 2, false);
-                step(1, cu, cd, q + 3, false);
+            for (int q = 0; q < nper - 2; q += 2) {
+                step(0, cu, cd, kmap(tw, q + 2), false);
+                step(1, cu, cd, kmap(tw, q + 3), false);
             }
 #endif
             step(0, nu, nd, 0, false);                                    // the last two request the next tile's rows
@@ -925,9 +1042,11 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
     a.K = (h->C + 1) * h->E; a.H1 = h->mlp_h1; a.H2 = h->mlp_h2; a.err = h->err_dev;
     a.dbg = g_m2d_mlp_diag_buffer;
     a.w1x3 = a.w2x3 = nullptr;
+    a.perm = nullptr; a.tile_blocks = nullptr; a.ntiles_dev = nullptr; a.pshift = 0;
     const bool mfma_ok = a.H1 == MH1 && a.H2 == MH2 && a.K % 64 == 0 && h->opt_variant != 9;
     const int kch = a.K / 64;
-    const bool pc_ok = (uint64_t)h->U * a.K * 4 < (1ull << 36) && (uint64_t)h->I * a.K * 4 < (1ull << 36);   // 32-bit row offsets in 16-B units
+    const bool pc_ok = (uint64_t)h->U * a.K * 4 < (1ull << 36) && (uint64_t)h->I * a.K * 4 < (1ull << 36) &&   // 32-bit row offsets in 16-B units
+                       h->E % 32 == 0 && ((h->E / 32) & (h->E / 32 - 1)) == 0 && h->C <= 6 && h->dish_cats;       // k-blocks of whole periods
     if (mfma_ok && (kch == 5 || kch == 10 || kch == 20 || kch == 3) && h->opt_mlp_bf16x3 != 0 && h->opt_mlp_form == 0 && pc_ok) {
         // producer / consumer form: its own image of W1 | W2, (2 kch + 2) ring stages of 32 KiB, built once per head
         if (!h->mlp_w1pc) {
@@ -939,8 +1058,36 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
             M2D_HIP_TRY(h, hipGetLastError());
         }
         a.w1x3 = reinterpret_cast<const __bf16 *>(h->mlp_w1pc);
-        const int64_t ntiles = (B + PC_PAIRS - 1) / PC_PAIRS;
-        const unsigned grid = (unsigned)(ntiles < h->num_cu ? ntiles : h->num_cu);
+        // pairs bucketed by the dish's pattern of non-zero mask weights; every bucket padded to whole tiles
+        const int npat = 1 << h->C;
+        a.pshift = __builtin_ctz((unsigned)(h->E / 32));
+        const bool group = h->opt_skip_masked != 0 && a.pshift >= 1;      // E = 32: a block is one period, keep every block
+        int64_t tiles_max = (B + PC_PAIRS - 1) / PC_PAIRS;
+        if (group) {
+            tiles_max += npat;
+            const size_t need = (size_t)(PG_MAXPAT + 4) + (size_t)tiles_max + (size_t)tiles_max * PC_PAIRS;
+            if (need > h->mlp_pg_cap) {
+                if (h->mlp_pg) M2D_HIP_TRY(h, hipFree(h->mlp_pg));
+                h->mlp_pg = nullptr;
+                h->mlp_pg_cap = 0;
+                M2D_HIP_TRY(h, hipMalloc((void **)&h->mlp_pg, need * sizeof(int32_t)));
+                h->mlp_pg_cap = need;
+            }
+            int32_t *hist = h->mlp_pg, *ntl = hist + PG_MAXPAT, *perm = ntl + 4 + tiles_max;
+            uint32_t *tblocks = reinterpret_cast<uint32_t *>(ntl + 4);
+            M2D_HIP_TRY(h, hipMemsetAsync(hist, 0, (PG_MAXPAT + 4) * sizeof(int32_t), stream));
+            M2D_HIP_TRY(h, hipMemsetAsync(perm, 0xFF, (size_t)tiles_max * PC_PAIRS * sizeof(int32_t), stream));
+            const unsigned gcap = (unsigned)h->num_cu * 8;
+            const int64_t hb = (B + 255) / 256, sb = (B + 4095) / 4096;
+            hipLaunchKernelGGL(m2d_mlp_pg_hist, dim3((unsigned)(hb < gcap ? hb : gcap)), dim3(256), 0, stream, items, B, h->I,
+                               h->dish_cats, h->C, 1, hist);
+            hipLaunchKernelGGL(m2d_mlp_pg_scan, dim3(1), dim3(256), 0, stream, hist, h->C, tblocks, ntl);
+            hipLaunchKernelGGL(m2d_mlp_pg_scatter, dim3((unsigned)(sb < gcap ? sb : gcap)), dim3(256), 0, stream, items, B, h->I,
+                               h->dish_cats, h->C, 1, hist, perm);
+            M2D_HIP_TRY(h, hipGetLastError());
+            a.perm = perm; a.tile_blocks = tblocks; a.ntiles_dev = ntl;
+        }
+        const unsigned grid = (unsigned)(tiles_max < h->num_cu ? tiles_max : h->num_cu);
 #define M2D_MLP_PC_CASE(N)                                                                                  \
     if (kch == N) {                                                                                         \
         M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_mlp_pc<N>, hipFuncAttributeMaxDynamicSharedMemorySize, \

@@ -217,7 +217,8 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
  * exactly 0 -- the reference graph multiplies that row by 0 (Model_Recommender.py:82), so for finite tables the score
  * is the same to the bit and a pair moves (2 + active categories) x E x 4 bytes of rows instead of (C + 2) x E x 4.
  * The one input on which it shows is a non-finite value inside such a row (0 x inf = NaN in the literal graph); 0
- * restores the literal fetch-and-multiply.
+ * restores the literal fetch-and-multiply.  m2d_score_pairs_mlp uses the same fact per tile: it groups a launch's pairs by
+ * the dish's pattern of non-zero weights and does not multiply the k-blocks a pattern lacks (0 = pairs as they come).
  * Kernel-selection knobs for benchmarking ("prefetch", "nt_loads", "blocks_per_cu", "variant"): results
  * never depend on them.  Two numerical switches, both for build-defined paths: "topk_bf16x3" (default 1) lets
  * m2d_topk_users contract on split-bf16 MFMA (x = hi + lo, three bf16 products, fp32 accumulation; score error

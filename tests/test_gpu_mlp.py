@@ -116,21 +116,31 @@ def test_mlp_many_tiles_per_block(E, B):
     rng = np.random.default_rng(E + 7)
     dish_cats = rng.integers(0, 2, (I, C)).astype(np.float32)
     dish_cats[dish_cats.sum(1) == 0, 1] = 1
+    dish_cats[::5] *= rng.uniform(0.25, 3.0, (len(dish_cats[::5]), C)).astype(np.float32)     # weighted masks: the pattern is "weight != 0"
+    dish_cats[11] = 0                                                                          # a dish without categories: NaN, its own bucket
     head = _head((C + 1) * E, 256, 64, rng, scale=4.0)
     eng = ScoringEngine(PM, RE, CE); eng.set_dish_categories(dish_cats); eng.set_mlp_head(*head)
     ut, it = torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda")
     got = eng.score_pairs_mlp(ut, it); eng.check()
     assert eng.last_kernel() == "m2d_mlp_pc_bf16x3"
+    # the same kernel without the grouping by mask pattern (every k-block of every tile): the skipped terms are zeros
+    eng.set_option("skip_masked", 0)
+    plain = eng.score_pairs_mlp(ut, it).cpu().numpy(); eng.check()
+    eng.set_option("skip_masked", 1)
+    gg = got.cpu().numpy()
+    assert np.array_equal(np.isnan(gg), np.isnan(plain)) and np.isnan(gg).sum() == (items == 11).sum()
+    assert np.nanmax(np.abs(gg - plain) / np.maximum(1.0, np.abs(plain))) < 2e-6
     eng.set_option("mlp_form", 1)
     other = eng.score_pairs_mlp(ut, it); eng.check()
     assert eng.last_kernel() == "m2d_mlp_mfma_bf16x3"
     eng.set_option("mlp_form", 0)
     g, o = got.cpu().numpy(), other.cpu().numpy()
-    assert np.isfinite(g).all()
-    assert np.max(np.abs(g - o) / np.maximum(1.0, np.abs(o))) < 5e-5      # two split-bf16 kernels, different summation orders
+    ok = items != 11
+    assert np.isfinite(g[ok]).all() and np.isnan(o[~ok]).all()
+    assert np.max(np.abs(g[ok] - o[ok]) / np.maximum(1.0, np.abs(o[ok]))) < 5e-5      # two split-bf16 kernels, different summation orders
     pick = np.concatenate([np.arange(0, 300), rng.integers(0, B, 3000), np.arange(B - 300, B)])
     ref = oracle.inference_mlp(PM, RE, CE, dish_cats, *head, users[pick], items[pick])
-    assert_scores_close(g[pick], ref, what="E%d sample" % E)
+    assert_scores_close(g[pick], ref, what="E%d sample" % E)                # NaN rows (dish 11) must agree too
     bad = items.copy(); pos = B - 12_345; bad[pos] = I + 3
     with pytest.raises(IndexError, match="item id %d at position %d" % (I + 3, pos)):
         out = eng.score_pairs_mlp(ut, torch.as_tensor(bad, device="cuda")); eng.check()
