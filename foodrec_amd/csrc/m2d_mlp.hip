@@ -479,11 +479,23 @@ __device__ __forceinline__ int pg_pattern(const float *cats, int C, int64_t I, i
 __global__ __launch_bounds__(256) void m2d_mlp_pg_hist(const int32_t *items, int64_t B, int64_t I, const float *cats, int C,
                                                        int group, int32_t *hist)
 {
+    // lane p of a wave counts pattern p in a register (one ballot + popcount per pattern and 64 pairs: no contended
+    // atomics on a dozen addresses), then one LDS add and one global add per pattern and block
     __shared__ int32_t sh[PG_MAXPAT];
+    const int lane = threadIdx.x & 63, npat = 1 << C;
     if (threadIdx.x < PG_MAXPAT) sh[threadIdx.x] = 0;
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < B; i += (int64_t)gridDim.x * 256)
-        atomicAdd(&sh[pg_pattern(cats, C, I, items[i], group)], 1);
+    int32_t cnt = 0;
+    const int64_t step = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < B; i0 += step) {   // block-uniform trip count: every ballot is full-wave
+        const int64_t i = i0 + threadIdx.x;
+        const int pat = i < B ? pg_pattern(cats, C, I, items[i], group) : -1;
+        for (int q = 0; q < npat; ++q) {
+            const unsigned long long b = __ballot(pat == q);
+            if (lane == q) cnt += __popcll(b);
+        }
+    }
+    if (lane < npat && cnt) atomicAdd(&sh[lane], cnt);
     __syncthreads();
     if (threadIdx.x < PG_MAXPAT && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
 }
