@@ -768,7 +768,8 @@ def main():
                     w, per = time_steps(torch, eng, users, items, cats, so, 10)
                     ms = sorted(per)[len(per) // 2]
                     print("sweep pf=%d nt=%d blocks_per_cu=%2d: %.3f ms  %.2f Gpairs/s  %.0f GB/s" %
-                          (pf, nt, bpc, ms, B / ms / 1e6, B * algorithmic_bytes_per_pair(C, E) / ms / 1e6), file=sys.stderr)
+                          (pf, nt, bpc, ms, B / ms / 1e6, B * (line["roofline"]["algorithmic_bytes_per_pair"] if line else
+                                                            algorithmic_bytes_per_pair(C, E)) / ms / 1e6), file=sys.stderr)
         for k, v in opts_used.items():
             eng.set_option(k, v)
 
