@@ -208,3 +208,36 @@ def test_retrieval_with_ingredients_any_catalogue(E, U, I, k, seed, weighted, sp
         if rest.size and not np.isfinite(key[-1]):
             assert not np.isfinite(rest).any()                          # a NaN made the list only when nothing scored was left
     eng.close()
+
+
+@settings(max_examples=20, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(st.sampled_from([(4, 64), (4, 128), (5, 32), (2, 64), (4, 256)]), st.integers(1, 30_000), st.integers(1, 60),
+       st.integers(1, 40), st.integers(0, 2 ** 31 - 1), st.booleans(), st.booleans())
+def test_mlp_head_any_batch(shape, B, U, I, seed, weighted, skip):
+    """The 3-layer head's producer / consumer kernel on arbitrary batches: any mix of dish mask patterns (weighted masks,
+    dishes without categories -> NaN), few dishes (buckets of very different sizes, most of them padding), grouped by
+    pattern or not, against the float64 restatement."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    C, E = shape
+    K = (C + 1) * E
+    rng = np.random.default_rng(seed)
+    s = 1.0 / np.sqrt(E)
+    PM = (rng.standard_normal((U, C + 1, E)) * s).astype(np.float32)
+    RE = (rng.standard_normal((I, E)) * s).astype(np.float32)
+    CE = (rng.standard_normal((C, E)) * s).astype(np.float32)
+    users = rng.integers(0, U, B).astype(np.int32)
+    items = rng.integers(0, I, B).astype(np.int32)
+    dish_cats = rng.integers(0, 2, (I, C)).astype(np.float32)       # all-zero rows included: NaN scores
+    if weighted:
+        dish_cats *= rng.uniform(0.1, 3.0, (I, C)).astype(np.float32)
+    head = ((rng.standard_normal((K, 256)) * 4 / np.sqrt(K)).astype(np.float32), (rng.standard_normal(256) * 0.1).astype(np.float32),
+            (rng.standard_normal((256, 64)) / 4).astype(np.float32), (rng.standard_normal(64) * 0.1).astype(np.float32),
+            (rng.standard_normal(64) / 2).astype(np.float32), 0.125)
+    eng = ScoringEngine(PM, RE, CE); eng.set_dish_categories(dish_cats); eng.set_mlp_head(*head)
+    eng.set_option("skip_masked", int(skip))
+    got = eng.score_pairs_mlp(torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda")); eng.check()
+    assert eng.last_kernel() == "m2d_mlp_pc_bf16x3"
+    ref = oracle.inference_mlp(PM, RE, CE, dish_cats, *head, users, items)
+    assert_scores_close(got.cpu().numpy(), ref, what="C%d E%d B%d" % (C, E, B))
