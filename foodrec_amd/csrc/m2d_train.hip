@@ -293,7 +293,11 @@ __global__ __launch_bounds__(256) void m2d_train_apply(float *var, float *s0, fl
 {
     typedef typename RowVec<VEC>::T vf;
     if (err[0] != 0) return;    // an id was out of range: like TF's InvalidArgumentError, the step applies nothing
-    if (r.rule == M2D_LEARNER_ADAM) r.lr = r.lr * sqrtf(1.0f - st->b2p) / (1.0f - st->b1p);   // AdamOptimizer._apply_dense
+    if (r.rule == M2D_LEARNER_ADAM) {                                     // AdamOptimizer._apply_dense; kept wave-uniform (SGPRs)
+        const float b1p = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, st->b1p)));
+        const float b2p = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, st->b2p)));
+        r.lr = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, r.lr * sqrtf(1.0f - b2p) / (1.0f - b1p))));
+    }
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
