@@ -498,6 +498,29 @@ def side_measurements(torch, eng, PM, U, I, C, E, dev, user_base):
     return nr, probe, hbm_only
 
 
+def user_high_leg(torch, eng, users, items, cats, C, E):
+    """Outside the timed region: the same batch with the serving option "user_high_table" (the high-level sum from the
+    derived table <U_high[u], CE_c>, 16 B per pair, instead of the gathered U_high row).  Not the headline: the table
+    keeps part of the forward pass across launches."""
+    out = torch.empty(users.numel(), dtype=torch.float32, device=users.device)
+    eng.set_option("user_high_table", 1)
+    try:
+        time_steps(torch, eng, users, items, cats, out, 3)
+        _, per = time_steps(torch, eng, users, items, cats, out, 20)
+        eng.check()
+        kern = eng.last_kernel()
+    finally:
+        eng.set_option("user_high_table", 0)
+    ms = median(per)
+    B = users.numel()
+    active = float((cats != 0).sum(1).float().mean().item()) if eng.get_option("skip_masked") != 0 else float(C)
+    bpp = (1.0 + active) * E * 4 + 2 * C * 4 + 12
+    return {"kernel": kern, "kernel_median_ms": ms, "pairs_per_s": B / ms * 1e3, "algorithmic_bytes_per_pair": bpp,
+            "achieved": bpp * B / ms / 1e6, "unit": "GB/s", "frac": bpp * B / ms / 1e6 / HBM_PEAK_GBS,
+            "what": "option user_high_table = 1: sum_c m_c <U_high[u], CE_c> / n from a 16 B-per-user derived table instead "
+                    "of the gathered E x 4-byte U_high row; same scores within 1e-6"}
+
+
 def ingredients_leg(torch, eng, users, items, cats, I, C, E, dev, R):
     """Outside the timed region: the same batch with BASELINE configs[1]'s 10k-row ingredient table on the high-level
     path (build-defined extension; --workload ingredients makes it the timed step)."""
@@ -860,6 +883,11 @@ def main():
                 line["evaluator"] = evaluator_leg(torch, dev)
             except Exception as e:                                     # noqa: BLE001
                 line["evaluator"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if not a.no_side and wl == "pairs":
+            try:
+                line["with_user_high_table"] = user_high_leg(torch, eng, users, items, cats, C, E)
+            except Exception as e:                                     # noqa: BLE001
+                line["with_user_high_table"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not a.no_side and wl == "pairs":
             try:
                 line["with_ingredient_table"] = ingredients_leg(torch, eng, users, items, cats, I, C, E, dev, a.ingredients)

@@ -81,6 +81,7 @@ void release(m2d_engine *h)
     if (h->mlp_w1x3) (void)hipFree(h->mlp_w1x3);
     if (h->mlp_w1pc) (void)hipFree(h->mlp_w1pc);
     if (h->mlp_pg) (void)hipFree(h->mlp_pg);
+    if (h->user_high) (void)hipFree(h->user_high);
     if (h->dish_high) (void)hipFree(h->dish_high);
     if (h->own_ing) {
         if (h->ing) (void)hipFree((void *)h->ing);
@@ -484,6 +485,7 @@ int m2d_tables_updated(m2d_engine *h)
 {
     if (!h) return M2D_ERR_INVALID_ARG;
     h->dish_vec_valid = false;      // factored dish vectors (Recipe_Embedding, Category_Embedding)
+    h->user_high_valid = false;     // <U_high, CE_c> (Personal_Memory, Category_Embedding)
     h->grp_valid = false;           // pattern-grouped retrieval tables (Recipe_Embedding)
     return M2D_OK;
 }
@@ -550,6 +552,7 @@ int m2d_set_option(m2d_engine *h, const char *name, int64_t value)
     else if (!strcmp(name, "mlp_bf16x3")) h->opt_mlp_bf16x3 = (int)value;
     else if (!strcmp(name, "mlp_form")) h->opt_mlp_form = (int)value;
     else if (!strcmp(name, "skip_masked")) h->opt_skip_masked = (int)value;
+    else if (!strcmp(name, "user_high_table")) h->opt_user_high = (int)value;
     else return fail(h, M2D_ERR_INVALID_ARG, "m2d_set_option: unknown option");
     return M2D_OK;
 }
@@ -567,6 +570,7 @@ int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value)
     else if (!strcmp(name, "mlp_bf16x3")) *value = h->opt_mlp_bf16x3;
     else if (!strcmp(name, "mlp_form")) *value = h->opt_mlp_form;
     else if (!strcmp(name, "skip_masked")) *value = h->opt_skip_masked;
+    else if (!strcmp(name, "user_high_table")) *value = h->opt_user_high;
     else if (!strcmp(name, "num_cu")) *value = h->num_cu;
     else return M2D_ERR_INVALID_ARG;
     return M2D_OK;

@@ -48,6 +48,11 @@ struct m2d_engine {
     int32_t *mlp_pg = nullptr;          // per-launch pair grouping of that kernel: histogram | tile count | tile blocks | slot -> pair
     size_t mlp_pg_cap = 0;              // ints
 
+    // derived table for pair scoring: <U_high[u], CE_c> per user and category (built lazily by large m2d_score_pairs calls;
+    // stale after any write to Personal_Memory / Category_Embedding: the engine's own writers and m2d_tables_updated reset it)
+    float *user_high = nullptr;  // [U, 4]
+    bool user_high_valid = false;
+
     // factored dish vectors for catalogue retrieval (built lazily by m2d_topk_users)
     float *dish_vec = nullptr;  // [I_pad, (C+1)*E]
     int64_t dish_vec_rows = 0;
@@ -79,6 +84,7 @@ struct m2d_engine {
     int opt_nt = 1;
     int opt_blocks_per_cu = 8;
     int opt_variant = 0;
+    int opt_user_high = 0;              // opt-in: batches of >= 2^18 pairs take the high-level sum from the derived <U_high, CE_c> table
     int opt_skip_masked = 1;            // pair kernels: rows of categories with mask weight 0 are not fetched (their products are 0)
     int opt_mlp_form = 0;               // split-bf16 MLP head: 0 = matrix waves fed by gather / DMA waves (m2d_mlp_pc), 1 = every wave gathers its own rows
     int opt_mlp_bf16x3 = 1;             // MLP head layer 1 (build-defined) on split-bf16 MFMA; 0 = exact-f32 MFMA
@@ -126,6 +132,7 @@ int m2d_launch_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *i
                            bool by_dish, int64_t B, float *out, hipStream_t stream,
                            bool use_ingredients = false);
 int m2d_launch_build_dish_high(m2d_engine *h, hipStream_t stream);
+int m2d_ensure_user_high(m2d_engine *h, hipStream_t stream);
 int m2d_launch_check_csr(m2d_engine *h, hipStream_t stream);
 int m2d_ensure_dish_vectors(m2d_engine *h, hipStream_t stream);
 int m2d_launch_write_memory(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,

@@ -39,6 +39,7 @@ struct ScoreArgs {
     float b;
     int32_t *err;
     int32_t skip_masked;   // do not fetch the Personal_Memory rows of categories whose mask weight is 0 (their products are 0)
+    const float *uh;       // [U, 4] derived table <U_high[u], CE_c> (m2d_build_user_high), or null: read U_high and multiply
 };
 
 __device__ __forceinline__ void latch_error(int32_t *err, int code, int64_t value, int64_t index)
@@ -85,7 +86,7 @@ __device__ __forceinline__ float group_sum(float v)
 // HV (build-defined extension): the high-level operand sum_c m_c CE_c / n of
 // Model_Recommender.py:67-79 is replaced by a resident per-dish vector H[d] (the normalised multi-hot
 // ingredient sum), i.e. high = <U_high, H[d]>; the low-level path is unchanged.
-template <int LPP, int PF, bool BYDISH, bool NT, bool FULL, bool HV>
+template <int LPP, int PF, bool BYDISH, bool NT, bool FULL, bool HV, bool UH = false>
 __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
 {
     constexpr int C = 4;
@@ -138,6 +139,11 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
         // categories whose weight is exactly 0 contribute 0 * U_low[c] = 0 to :82-:90: their rows are not fetched
         // (a NaN weight compares unequal to 0 and keeps its row)
         const int32_t act = p.skip_masked ? ((m.x != 0.f ? 1 : 0) | (m.y != 0.f ? 2 : 0) | (m.z != 0.f ? 4 : 0) | (m.w != 0.f ? 8 : 0)) : 15;
+        // high-level part from the derived table: sum_c m_c <U_high, CE_c> (the U_high row is then not fetched at all)
+        // (UH is its own instantiation: the literal kernel's code, and with it its bits, stay what they were)
+        constexpr bool use_uh = UH && !HV;
+        v4f uhv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (use_uh) uhv = reinterpret_cast<const v4f *>(p.uh)[ul];
 
         v4f ub[PF][C + 1];
         v4f ib[PF];
@@ -149,7 +155,8 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
             const int32_t ds = __shfl(did, s, LPP);
             const int32_t as = __shfl(act, s, LPP);
             const v4f *pu = pm4 + (size_t)us * urow4 + jc;
-            ub[slot][0] = ld4<NT>(pu);
+            if constexpr (use_uh) ub[slot][0] = v4f{0.f, 0.f, 0.f, 0.f};
+            else ub[slot][0] = ld4<NT>(pu);
 #pragma unroll
             for (int r = 1; r <= C; ++r) {
                 ub[slot][r] = v4f{0.f, 0.f, 0.f, 0.f};
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
                 float hs = 0.f, ls = 0.f;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    if constexpr (!HV) {
+                    if constexpr (!HV && !use_uh) {
                         const v4f dish_category = scale4(mc[c], cef[c]);    // :67
                         hs = dot4(ub[k][0], dish_category, hs);                // :71, :75
                     }
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
                     if (HV) hs = 0.f;
                 }
                 if (s + PF < LPP) issue(s + PF, k);
-                hs = group_sum<LPP>(hs);
+                if constexpr (HV || !use_uh) hs = group_sum<LPP>(hs);
                 ls = group_sum<LPP>(ls);
                 if (j == s) {
                     my_high = hs;
@@ -197,12 +204,39 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
         }
         if (valid) {
             const float n = (m.x + m.y) + (m.z + m.w);                         // :77
+            if constexpr (use_uh) my_high = fmaf(m.w, uhv.w, fmaf(m.z, uhv.z, fmaf(m.y, uhv.y, m.x * uhv.x)));
             const float high = HV ? my_high : my_high / n;                     // :79 (H[d] is already normalised)
             const float low = my_low / n;                                      // :92
             float score = __fadd_rn(__fmul_rn(p.a, high), __fmul_rn(p.b, low));     // :95-96, no fma contraction
             if (bad) score = __builtin_nanf("");
             p.out[pi] = score;
         }
+    }
+}
+
+// Derived table for serving: uh[u][c] = <U_high[u], CE_c>, c < 4.  The high-level sum of Model_Recommender.py:67-79 is
+// sum_c m_c uh[u][c] / n -- the same products in another order -- so a pair reads 16 bytes of this table (16 B x U: it
+// lives in L2 / the Infinity Cache) instead of the E x 4-byte U_high row from HBM.  One group of E/4 lanes per user.
+template <int LPP>
+__global__ __launch_bounds__(256) void m2d_build_user_high(const float *pm, const float *ce, int64_t U, int32_t E, float *out)
+{
+    constexpr int C = 4;
+    const int lane = threadIdx.x & 63, j = lane & (LPP - 1), E4 = E >> 2;
+    const bool col_ok = j < E4;
+    const int jc = col_ok ? j : 0;
+    const v4f *ce4 = reinterpret_cast<const v4f *>(ce);
+    v4f cef[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) cef[c] = col_ok ? ce4[(size_t)c * E4 + jc] : v4f{0.f, 0.f, 0.f, 0.f};
+    const int64_t gpw = 64 / LPP;
+    const int64_t g0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * gpw + lane / LPP;
+    for (int64_t u = g0; u < ((U + gpw - 1) / gpw) * gpw; u += (int64_t)gridDim.x * 4 * gpw) {   // whole groups: full-wave shuffles
+        const bool ok = u < U;
+        const v4f x = reinterpret_cast<const v4f *>(pm)[(size_t)(ok ? u : 0) * (C + 1) * E4 + jc];
+        float h[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) h[c] = group_sum<LPP>(dot4(x, cef[c], 0.f));
+        if (ok && j == 0) reinterpret_cast<v4f *>(out)[u] = v4f{h[0], h[1], h[2], h[3]};
     }
 }
 
@@ -364,6 +398,12 @@ void launch_c4(const ScoreArgs &a, int pf, bool nt, bool small, dim3 grid, hipSt
         return;
     }
     *name = "m2d_score_pairs_c4";
+    if (a.uh) {   // high-level sum from the derived table: one configuration (PF 2, non-temporal user rows), as the default
+        *name = "m2d_score_pairs_c4_uh";
+        if (pf == 4) hipLaunchKernelGGL((m2d_score_pairs_c4<LPP, 4, BYDISH, true, FULL, false, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((m2d_score_pairs_c4<LPP, 2, BYDISH, true, FULL, false, true>), grid, dim3(256), 0, st, a);
+        return;
+    }
     M2D_CASE(1, false) M2D_CASE(1, true) M2D_CASE(2, false) M2D_CASE(2, true)
     M2D_CASE(4, false) M2D_CASE(4, true)
 #undef M2D_CASE
@@ -414,6 +454,25 @@ int launch_any(m2d_engine *h, const ScoreArgs &a, hipStream_t st)
 
 }  // namespace
 
+int m2d_ensure_user_high(m2d_engine *h, hipStream_t stream)
+{
+    if (h->user_high_valid) return M2D_OK;
+    if (!h->user_high) M2D_HIP_TRY(h, hipMalloc((void **)&h->user_high, (size_t)h->U * 4 * sizeof(float)));
+    const int E4 = h->E >> 2;
+    const int lpp = E4 <= 8 ? 8 : E4 <= 16 ? 16 : E4 <= 32 ? 32 : 64;
+    int64_t blocks = (h->U * lpp / 64 + 3) / 4 + 1;
+    const int64_t cap = (int64_t)h->num_cu * 16;
+    if (blocks > cap) blocks = cap;
+    dim3 grid((unsigned)blocks);
+    if (lpp == 8) hipLaunchKernelGGL((m2d_build_user_high<8>), grid, dim3(256), 0, stream, h->pm, h->ce, h->U, h->E, h->user_high);
+    else if (lpp == 16) hipLaunchKernelGGL((m2d_build_user_high<16>), grid, dim3(256), 0, stream, h->pm, h->ce, h->U, h->E, h->user_high);
+    else if (lpp == 32) hipLaunchKernelGGL((m2d_build_user_high<32>), grid, dim3(256), 0, stream, h->pm, h->ce, h->U, h->E, h->user_high);
+    else hipLaunchKernelGGL((m2d_build_user_high<64>), grid, dim3(256), 0, stream, h->pm, h->ce, h->U, h->E, h->user_high);
+    M2D_HIP_TRY(h, hipGetLastError());
+    h->user_high_valid = true;
+    return M2D_OK;
+}
+
 int m2d_launch_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
                            bool by_dish, int64_t B, float *out, hipStream_t stream, bool use_ingredients)
 {
@@ -425,5 +484,15 @@ int m2d_launch_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *i
     a.B = B; a.U = h->U; a.I = h->I; a.user_base = h->user_base;
     a.E = h->E; a.C = h->C; a.a = h->a; a.b = h->b; a.err = h->err_dev;
     a.skip_masked = h->opt_skip_masked;
+    a.uh = nullptr;
+    // opt-in ("user_high_table"): batches large enough to pay for a pass over U_high take the high-level sum from the derived
+    // table (rebuilt when Personal_Memory / Category_Embedding changed); smaller ones never do, so a call's scores depend
+    // on its inputs and its size only, not on what ran before
+    if (!use_ingredients && h->opt_user_high && h->C == 4 && h->E % 4 == 0 && h->E <= 256 && h->opt_variant != 9 &&
+        (h->opt_prefetch == 2 || h->opt_prefetch == 4) && h->opt_nt != 0 && B >= (1 << 18)) {
+        int rc = m2d_ensure_user_high(h, stream);
+        if (rc != M2D_OK) return rc;
+        a.uh = h->user_high;
+    }
     return by_dish ? launch_any<true>(h, a, stream) : launch_any<false>(h, a, stream);
 }

@@ -507,6 +507,7 @@ int m2d_launch_train_step(m2d_engine *h, const int32_t *users, const int32_t *it
     // everything derived from Recipe_Embedding / Category_Embedding is stale now
     h->dish_vec_valid = false;
     h->grp_valid = false;
+    h->user_high_valid = false;
     return M2D_OK;
 }
 

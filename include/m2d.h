@@ -219,6 +219,10 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
  * The one input on which it shows is a non-finite value inside such a row (0 x inf = NaN in the literal graph); 0
  * restores the literal fetch-and-multiply.  m2d_score_pairs_mlp uses the same fact per tile: it groups a launch's pairs by
  * the dish's pattern of non-zero weights and does not multiply the k-blocks a pattern lacks (0 = pairs as they come).
+ * "user_high_table" (default 0, a serving option): calls of >= 2^18 pairs take the high-level sum from a derived table
+ * uh[u][c] = <U_high[u], CE_c> (16 B per user, built by a pass over Personal_Memory and rebuilt after the engine's own
+ * writers or m2d_tables_updated) as sum_c m_c uh[u][c] / n -- the same products in another order, scores within 1e-6 --
+ * so that a pair reads 16 bytes of it instead of the U_high row.  Off, every call multiplies the gathered row.
  * Kernel-selection knobs for benchmarking ("prefetch", "nt_loads", "blocks_per_cu", "variant"): results
  * never depend on them.  Two numerical switches, both for build-defined paths: "topk_bf16x3" (default 1) lets
  * m2d_topk_users contract on split-bf16 MFMA (x = hi + lo, three bf16 products, fp32 accumulation; score error

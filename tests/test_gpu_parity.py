@@ -277,3 +277,35 @@ def test_rows_of_weight_zero_categories_are_not_needed(E, B):
         eng2.set_option("skip_masked", 0)
         lit = eng2.score_pairs(ut[:1], it[:1], ct[:1]).cpu().numpy(); eng2.check()
         assert np.isnan(lit[0]) and np.isnan(oracle.inference_f64(PM2, RE, CE, users[:1], items[:1], cats[:1])[0])
+
+
+def test_user_high_table_option(torch_cuda):
+    """Serving option "user_high_table": batches of >= 2^18 pairs take the high-level sum from the derived table
+    <U_high[u], CE_c>.  Same scores within rounding; the table follows the engine's tables (its own writers reset it,
+    in-place edits from outside are announced with tables_updated() as for the retrieval tables)."""
+    torch = torch_cuda
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    U, I, C, E, B = 700, 300, 4, 64, (1 << 18) + 77
+    PM, RE, CE, users, items, cats = random_case(U, I, C, E, B, seed=21)
+    pmt = torch.as_tensor(PM, device="cuda")
+    eng = ScoringEngine(pmt, RE, CE)
+    ut, it, ct = (torch.as_tensor(x, device="cuda") for x in (users, items, cats))
+    lit = eng.score_pairs(ut, it, ct).cpu().numpy(); eng.check()
+    assert eng.last_kernel() == "m2d_score_pairs_c4"
+    eng.set_option("user_high_table", 1)
+    tab = eng.score_pairs(ut, it, ct).cpu().numpy(); eng.check()
+    assert eng.last_kernel() == "m2d_score_pairs_c4_uh"
+    ok = ~np.isnan(lit)
+    assert np.array_equal(np.isnan(tab), np.isnan(lit))
+    assert np.max(np.abs(tab[ok] - lit[ok]) / np.maximum(1.0, np.abs(lit[ok]))) < 2e-6
+    pick = np.arange(0, B, 97)
+    assert_scores_close(tab[pick], oracle.inference_f64(PM, RE, CE, users[pick], items[pick], cats[pick]))
+    small = eng.score_pairs(ut[:5000], it[:5000], ct[:5000]).cpu().numpy()       # below the threshold: the literal kernels
+    assert eng.last_kernel() == "m2d_score_pairs_c4_small" and np.array_equal(small, lit[:5000], equal_nan=True)
+    # the tables change under the engine: announced -> the derived table is rebuilt
+    pmt[:, 0, :] *= 2.0
+    eng.tables_updated()
+    PM2 = PM.copy(); PM2[:, 0, :] *= 2.0
+    tab2 = eng.score_pairs(ut, it, ct).cpu().numpy(); eng.check()
+    assert_scores_close(tab2[pick], oracle.inference_f64(PM2, RE, CE, users[pick], items[pick], cats[pick]))
