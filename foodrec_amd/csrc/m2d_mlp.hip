@@ -1058,7 +1058,8 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
     const bool mfma_ok = a.H1 == MH1 && a.H2 == MH2 && a.K % 64 == 0 && h->opt_variant != 9;
     const int kch = a.K / 64;
     const bool pc_ok = (uint64_t)h->U * a.K * 4 < (1ull << 36) && (uint64_t)h->I * a.K * 4 < (1ull << 36) &&   // 32-bit row offsets in 16-B units
-                       h->E % 32 == 0 && ((h->E / 32) & (h->E / 32 - 1)) == 0 && h->C <= 6 && h->dish_cats;       // k-blocks of whole periods
+                       h->E % 32 == 0 && ((h->E / 32) & (h->E / 32 - 1)) == 0 && h->C <= 6 && h->dish_cats &&      // k-blocks of whole periods
+                       B < (1ll << 31) - (1 << 16);                                                             // 32-bit pair slots
     if (mfma_ok && (kch == 5 || kch == 10 || kch == 20 || kch == 3) && h->opt_mlp_bf16x3 != 0 && h->opt_mlp_form == 0 && pc_ok) {
         // producer / consumer form: its own image of W1 | W2, (2 kch + 2) ring stages of 32 KiB, built once per head
         if (!h->mlp_w1pc) {
