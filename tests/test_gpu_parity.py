@@ -309,3 +309,33 @@ def test_user_high_table_option(torch_cuda):
     PM2 = PM.copy(); PM2[:, 0, :] *= 2.0
     tab2 = eng.score_pairs(ut, it, ct).cpu().numpy(); eng.check()
     assert_scores_close(tab2[pick], oracle.inference_f64(PM2, RE, CE, users[pick], items[pick], cats[pick]))
+
+
+def test_unusual_mask_weights_with_and_without_row_skipping(torch_cuda):
+    """-0.0 counts as a zero weight (its products are zeros of either sign), NaN and inf weights keep their rows: the
+    default and the literal fetch-and-multiply agree on every such mask, NaNs included."""
+    torch = torch_cuda
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    U, I, C, E, B = 50, 40, 4, 64, 4096 + 33
+    PM, RE, CE, users, items, cats = random_case(U, I, C, E, B, seed=5)
+    rng = np.random.default_rng(6)
+    cats = rng.integers(0, 2, (B, C)).astype(np.float32)
+    cats[cats.sum(1) == 0, 2] = 1
+    cats[5::50, 0] = -0.0
+    cats[7::50, 1] = np.nan
+    cats[9::50, 3] = np.inf
+    cats[11::50, 2] = -1.5
+    eng = ScoringEngine(PM, RE, CE)
+    ut, it, ct = (torch.as_tensor(x, device="cuda") for x in (users, items, cats))
+    for n in (B, 300):                                       # throughput form and latency form
+        on = eng.score_pairs(ut[:n], it[:n], ct[:n]).cpu().numpy(); eng.check()
+        eng.set_option("skip_masked", 0)
+        off = eng.score_pairs(ut[:n], it[:n], ct[:n]).cpu().numpy(); eng.check()
+        eng.set_option("skip_masked", 1)
+        assert np.array_equal(on, off, equal_nan=True)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ref = oracle.inference_f64(PM, RE, CE, users[:n], items[:n], cats[:n])
+        assert np.array_equal(np.isnan(on), np.isnan(ref))
+        ok = np.isfinite(ref)
+        assert_scores_close(on[ok], ref[ok])
