@@ -495,6 +495,23 @@ def side_measurements(torch, eng, PM, U, I, C, E, dev, user_base):
                 "what": "no-reuse leg, bytes that must come from HBM only: Personal_Memory blocks + id/mask/score streams%s"
                         % (" (dish rows excluded: the %.0f MB dish table is Infinity-Cache resident)" % (I * E * 4 / 1e6)
                            if re_cached else " + dish rows (the dish table does not fit the Infinity Cache)")}
+    # the same with the benchmark's masks (random non-empty subsets): rows of absent categories are not fetched, so the
+    # bytes that must come from HBM are U_high + the active rows
+    g2 = torch.Generator(device=dev); g2.manual_seed(8)
+    pat = torch.randint(1, 2 ** C, (Bn,), generator=g2, device=dev, dtype=torch.int32)
+    cats2 = ((pat[:, None] >> torch.arange(C, device=dev, dtype=torch.int32)[None, :]) & 1).to(torch.float32).contiguous()
+    skip = eng.get_option("skip_masked") != 0
+    act = float(cats2.sum(1).mean().item()) if skip else float(C)
+    time_steps(torch, eng, users, items, cats2, out, 3)
+    _, per2 = time_steps(torch, eng, users, items, cats2, out, 20)
+    t2 = median(per2)
+    pm2 = Bn * (1.0 + act) * E * 4
+    hb2 = (pm2 + stream_bytes + (0 if re_cached else Bn * E * 4)) / t2 / 1e6
+    hbm_only["masked"] = {"achieved": hb2, "unit": "GB/s", "frac_of_spec_peak": hb2 / HBM_PEAK_GBS,
+                          "frac_of_stream_probe": hb2 / probe["GBps"], "mean_active_categories": act,
+                          "kernel_median_ms": t2, "pairs_per_s": Bn / t2 * 1e3,
+                          "what": "the same no-reuse batch with the benchmark's masks (uniform non-empty subsets): HBM bytes = "
+                                  "U_high + the rows of the active categories + streams"}
     return nr, probe, hbm_only
 
 
