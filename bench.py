@@ -748,7 +748,10 @@ def main():
             "config": {"workload": "BASELINE configs[1]: synthetic %d users x %d dishes per GPU, C=%d categories, "
                                    "E=%d, uniform random (user,dish) pairs with per-pair category masks; reference "
                                    "forward Model_Recommender.py:56-97 (ingredient table / MLP head are "
-                                   "build-defined extensions, not in this step)" % (U, I, C, E),
+                                   "build-defined extensions, not in this step)%s" %
+                                   (U, I, C, E, "; Personal_Memory rows of categories with mask weight 0 are not fetched -- "
+                                    "the reference graph multiplies them by 0 (option skip_masked = 1, same scores to the bit)"
+                                    if skip else ""),
                        "users_per_gpu": U, "dishes": I, "categories": C, "embed_size": E, "pairs_per_step_per_gpu": B,
                        "sharding": "user-range shard per GPU, dishes replicated, no data-path collective",
                        "kernel": kernel_used, "options": opts_used},
