@@ -1074,7 +1074,9 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
         // pairs bucketed by the dish's pattern of non-zero mask weights; every bucket padded to whole tiles
         const int npat = 1 << h->C;
         a.pshift = __builtin_ctz((unsigned)(h->E / 32));
-        const bool group = h->opt_skip_masked != 0 && a.pshift >= 1;      // E = 32: a block is one period, keep every block
+        // E = 32: a block is one period, keep every block; small batches: three more launches and mostly-empty tiles
+        // cost more than the skipped periods save
+        const bool group = h->opt_skip_masked != 0 && a.pshift >= 1 && B >= 16384;
         int64_t tiles_max = (B + PC_PAIRS - 1) / PC_PAIRS;
         if (group) {
             tiles_max += npat;
