@@ -1,4 +1,4 @@
-"""BASELINE configs[3] and configs[4] at their full table sizes on ONE GPU (the 8-GPU aspect is the user-range shard:
+"""BASELINE configs[2], configs[3] and configs[4] at their full table sizes on ONE GPU (the 8-GPU aspect is the user-range shard:
 an engine with a non-zero user_base holding its slice).  The oracle cannot score tables of this size, so the checks
 are the size-independent ones: a random sample of pairs against the float64 restatement on the gathered rows,
 permutation invariance, exact linearity under power-of-two scaling, and -- for retrieval -- agreement of the returned
@@ -121,3 +121,40 @@ def test_config4_retrieval_e128_1M_dishes(torch_cuda):
     s, ids = eng.topk_users((big + base).to(torch.int32), 10); eng.check()
     s2, ids2 = eng.topk_users((big[:64] + base).to(torch.int32), 10); eng.check()
     assert torch.equal(ids[:64], ids2) and torch.equal(s[:64], s2)      # a user's list does not depend on the batch it is in
+
+
+def test_config2_mlp_head_1M_users_e128(torch_cuda):
+    """BASELINE configs[2] at its table sizes: 1 M users x 100 k dishes, E = 128, the 3-layer head on 2 M pairs.  Size-
+    independent checks of the producer / consumer kernel with its pairs regrouped by mask pattern: a sample against the
+    float64 restatement on gathered rows, permutation invariance (the grouping moves every pair), and a head that
+    contributes nothing reducing to the exact pair kernel."""
+    torch = torch_cuda
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    U, I, C, E, B = 1_000_000, 100_000, 4, 128, 1 << 21
+    g, PM, RE, CE, dish_cats = _tables(torch, U, I, C, E, seed=31)
+    K = (C + 1) * E
+    rn = lambda *shape: torch.randn(shape, generator=g, device="cuda")
+    head = (rn(K, 256) * (4 / K ** 0.5), rn(256) * 0.1, rn(256, 64) / 4, rn(64) * 0.1, rn(64) / 2, 0.125)
+    eng = ScoringEngine(PM, RE, CE); eng.set_dish_categories(dish_cats); eng.set_mlp_head(*head)
+    users = torch.randint(0, U, (B,), generator=g, device="cuda", dtype=torch.int32)
+    items = torch.randint(0, I, (B,), generator=g, device="cuda", dtype=torch.int32)
+    got = eng.score_pairs_mlp(users, items); eng.check()
+    assert eng.last_kernel() == "m2d_mlp_pc_bf16x3" and bool(torch.isfinite(got).all())
+    # (i) sample against the restatement, rows gathered on the device
+    pick = torch.randint(0, B, (4096,), generator=g, device="cuda")
+    pu, pd = users[pick].long(), items[pick].long()
+    hd = [x.cpu().numpy() if hasattr(x, "cpu") else x for x in head]
+    ref = oracle.inference_mlp(PM[pu].cpu().numpy(), RE[pd].cpu().numpy(), CE.cpu().numpy(), dish_cats[pd].cpu().numpy(), *hd,
+                               np.arange(4096), np.arange(4096))
+    assert_scores_close(got[pick].cpu().numpy(), ref, what="sample")
+    # (ii) permutation invariance
+    perm = torch.randperm(B, generator=g, device="cuda")
+    again = eng.score_pairs_mlp(users[perm].contiguous(), items[perm].contiguous()); eng.check()
+    d = (again - got[perm]).abs() / got[perm].abs().clamp(min=1.0)
+    assert float(d.max()) < 2e-6
+    # (iii) a head that contributes nothing: the reference score, as the exact pair kernel computes it
+    eng.set_mlp_head(head[0], head[1], head[2], head[3], torch.zeros_like(head[4]), 0.0)
+    base = eng.score_pairs_mlp(users[: 1 << 19], items[: 1 << 19]); eng.check()
+    exact = eng.score_pairs_bydish(users[: 1 << 19], items[: 1 << 19]); eng.check()
+    assert float(((base - exact).abs() / exact.abs().clamp(min=1.0)).max()) < 1e-5
