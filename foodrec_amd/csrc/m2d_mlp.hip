@@ -417,9 +417,10 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
 // for LDS at a period boundary.  The ring holds 7 half-stages of 16 KiB (3.5 periods: the stage two periods ahead can
 // be written while the current one and the next are live); z needs 2 sets (a consumer copies its z into registers
 // half a period before it uses it).
-// LDS: ring 7 x 16 KiB | z sets 2 x (4 consumers x 4 KiB f32) | reference-score sums 512 B | biases.
+// LDS: ring 7 x 16 KiB | z sets 2 x (4 consumers x 4 KiB f32) | reference-score sums 2 x 512 B (by tile parity: a
+// two-period tile's sums are written while the consumers may still be reading the previous tile's) | biases.
 constexpr int PC_HALF = 16384, PC_STAGE = 2 * PC_HALF, PC_NHB = 7, PC_ZSET = 16384;
-constexpr int PC_Z_OFF = PC_NHB * PC_HALF, PC_BASE_OFF = PC_Z_OFF + 2 * PC_ZSET, PC_B1_OFF = PC_BASE_OFF + 512;
+constexpr int PC_Z_OFF = PC_NHB * PC_HALF, PC_BASE_OFF = PC_Z_OFF + 2 * PC_ZSET, PC_B1_OFF = PC_BASE_OFF + 1024;
 constexpr int PC_LDS_BYTES = PC_B1_OFF + (MH1 + 2 * MH2) * 4;
 constexpr int PC_PAIRS = 128;             // pairs per tile
 typedef int v4i_pc __attribute__((ext_vector_type(4)));
@@ -583,7 +584,7 @@ template <int KCH>
 __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
 {
     extern __shared__ __align__(16) unsigned char pcs[];
-    float *sbase = reinterpret_cast<float *>(pcs + PC_BASE_OFF);        // [4 consumers][32]
+    float *sbase = reinterpret_cast<float *>(pcs + PC_BASE_OFF);        // [tile parity 2][4 consumers][32]
     float *sb1 = reinterpret_cast<float *>(pcs + PC_B1_OFF);            // [256]
     float *sb2 = sb1 + MH1, *sw3 = sb2 + MH2;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -681,6 +682,7 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
             hb = hb_add(hb, 2);
             zb ^= 1;
         };
+        unsigned tpar = 0;                                                // parity of this block's tile count
         pc_barrier();                                                     // period 0 is published
         MSTAMP(t0_);
 #if M2D_MLP_DIAG
@@ -748,7 +750,8 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
             o += __shfl_xor(o, 32, 64);
             const int64_t slot = tile * PC_PAIRS + wave * 32 + pl;
             const int32_t pi = p.perm ? p.perm[slot] : (slot < p.B ? (int32_t)slot : -1);   // -1: padding
-            if (h == 0 && pi >= 0) p.out[pi] = sbase[wave * 32 + pl] + (o + p.b3);
+            if (h == 0 && pi >= 0) p.out[pi] = sbase[tpar * 128 + wave * 32 + pl] + (o + p.b3);
+            tpar ^= 1;
 #if M2D_MLP_DIAG
             MACC(t_d); ++n_t;
 #endif
@@ -883,7 +886,7 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
                 __builtin_amdgcn_sched_barrier(0);                        // one pair of addresses live at a time
             }
         };
-        unsigned zb = 0;                                                  // z set being written
+        unsigned zb = 0, tpar = 0;                                        // z set being written; parity of this block's tile count
         // per 4 k-values of a pair: 2 packed multiplies, 2 packed adds into the reference score, one 16-byte store
         auto build = [&](int set) __attribute__((always_inline)) {
             if (M2D_MLP_DIAG & 2) return;                                 // diag bit 1: no z build
@@ -940,7 +943,7 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
                         b += __shfl_xor(b, 2, 64);
                         b += __shfl_xor(b, 4, 64);
                         if ((badmask >> i) & 1) b = __builtin_nanf("");
-                        if (s == 0) sbase[(2 * g + (i >> 2)) * 32 + 8 * (i & 3) + r8] = b;
+                        if (s == 0) sbase[tpar * 128 + (2 * g + (i >> 2)) * 32 + 8 * (i & 3) + r8] = b;
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -971,6 +974,7 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
 #pragma unroll
             for (int i = 0; i < 8; ++i) { cu[i] = nu[i]; cd[i] = nd[i]; }
             badmask = nbadmask;
+            tpar ^= 1;
             const int64_t t2 = next_of(next_of(tile));
             load_ids(t2);
             pc_barrier();
