@@ -71,9 +71,28 @@ __global__ __launch_bounds__(256) void m2d_write_memory_kernel(WriteArgs p)
         const float *y = p.labels + (size_t)b * L;
         float n = 0.f;
         for (int c = 0; c < C; ++c) n += m[c];                               // :130
+        // the labels of this pair with a non-zero weight, as lane masks (a user has a handful of its L = 95 labels):
+        // every loop over labels below visits those only.  Walking all L for each of the (C + 1) E elements -- L
+        // dependent loads per element -- was 200 us of latency for a single pair.
+        constexpr int MAXM = 4;                                              // masks for L <= 256; beyond that: every label
+        unsigned long long am[MAXM];
+#pragma unroll
+        for (int q = 0; q < MAXM; ++q) {
+            const int l = q * 64 + lane;
+            am[q] = (q * 64 < L && L <= 64 * MAXM) ? __ballot(l < L && y[l < L ? l : 0] != 0.f) : 0ull;
+        }
+        auto each_label = [&](auto &&f) __attribute__((always_inline)) {     // in label order, wave-uniform
+            if (L <= 64 * MAXM) {
+#pragma unroll
+                for (int q = 0; q < MAXM; ++q)
+                    for (unsigned long long bits = am[q]; bits; bits &= bits - 1) f(q * 64 + __builtin_ctzll(bits));
+            } else {
+                for (int l = 0; l < L; ++l)
+                    if (y[l] != 0.f) f(l);
+            }
+        };
         float ysum = 0.f;
-        if (PASS == 0)
-            for (int l = 0; l < L; ++l) ysum += y[l];                        // :180
+        if (PASS == 0) each_label([&](int l) { ysum += y[l]; });             // :180 -- the zero weights add nothing
         const float lo = p.beta_1 * s, hi = p.beta_2 * s;                    // :115, :141
         for (int r = 0; r <= C; ++r) {
             for (int e = lane; e < E; e += 64) {
@@ -88,16 +107,10 @@ __global__ __launch_bounds__(256) void m2d_write_memory_kernel(WriteArgs p)
                 const size_t k = (size_t)r * E + e;
                 if (PASS == 0) {
                     float g = 0.f;
-                    for (int l = 0; l < L; ++l) {
-                        const float w = y[l];
-                        if (w != 0.f) g = fmaf(w, p.gm[(size_t)l * (C + 1) * E + k], g);   // :172-176
-                    }
+                    each_label([&](int l) { g = fmaf(y[l], p.gm[(size_t)l * (C + 1) * E + k], g); });   // :172-176
                     atomicAdd(p.pm + (size_t)ul * (C + 1) * E + k, v + p.alpha * (g / ysum));   // :162, :184-198
                 } else {
-                    for (int l = 0; l < L; ++l) {
-                        const float w = y[l];
-                        if (w != 0.f) atomicAdd(p.gm + (size_t)l * (C + 1) * E + k, w * v);      // :200-215
-                    }
+                    each_label([&](int l) { atomicAdd(p.gm + (size_t)l * (C + 1) * E + k, y[l] * v); });   // :200-215
                 }
             }
         }
