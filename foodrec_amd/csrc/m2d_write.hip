@@ -95,6 +95,8 @@ __global__ __launch_bounds__(256) void m2d_write_memory_kernel(WriteArgs p)
         if (PASS == 0) each_label([&](int l) { ysum += y[l]; });             // :180 -- the zero weights add nothing
         const float lo = p.beta_1 * s, hi = p.beta_2 * s;                    // :115, :141
         for (int r = 0; r <= C; ++r) {
+            // General_Memory passes: the row of a category whose weight is 0 is a row of zeros -- nothing to add
+            if (PASS != 0 && r > 0 && m[r - 1] == 0.f) continue;
             for (int e = lane; e < E; e += 64) {
                 float v;
                 if (r == 0) {
