@@ -40,7 +40,8 @@ for name, (U, I, C, E, L, B) in {"reference sizes, the driver's batch (Train_rec
         us = per[len(per) // 2] * 1e3
         # bytes added: PM pass (C+1) E floats per pair; GM pass (C+1) E floats per (pair, label set) ~ labels per pair
         nlab = float(labels.sum(1).mean().item())
-        added = B * (C + 1) * E * 4 * ((1 if kw["write_pm"] else 0) + (nlab if kw["write_gm"] else 0))
+        act = float((cats != 0).sum(1).float().mean().item())            # the GM passes add U_high's row and the active categories' rows
+        added = B * E * 4 * ((C + 1) * (1 if kw["write_pm"] else 0) + (1 + act) * (nlab if kw["write_gm"] else 0))
         row[what] = {"median_us": us, "pairs_per_s": B / us * 1e6, "atomic_bytes_added": added, "added_GBps": added / us / 1e3}
     eng.check()
     out[name] = {"users": U, "dishes": I, "E": E, "labels": L, "batch": B, "mean_labels_per_pair": nlab, **row}
