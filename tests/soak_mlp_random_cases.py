@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""One-off randomized soak of the MLP head kernels against the float64 restatement (not a test: seeds from the clock)."""
+"""One-off randomized soak of the MLP head kernels against the float64 restatement (test infrastructure, not collected
+by pytest: seeds come from the clock).  Usage on the GPU box: python tests/soak_mlp_random_cases.py [cases]."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 from foodrec_amd import ScoringEngine
 from oracle import m2d_oracle as oracle
