@@ -694,6 +694,9 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
 #pragma unroll
         for (int c = 0; c < 4; ++c) split(c, bA);
         for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            // where this lane's score goes: requested now, needed after layer 3 (-1: a padding slot)
+            const int64_t slot = tile * PC_PAIRS + wave * 32 + pl;
+            const int32_t pi = p.perm ? p.perm[slot] : (slot < p.B ? (int32_t)slot : -1);
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
@@ -748,8 +751,6 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
                 for (int r = 0; r < 16; ++r)
                     o = fmaf(sw3[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h], fmaxf(acc2[mt][r], 0.f), o);
             o += __shfl_xor(o, 32, 64);
-            const int64_t slot = tile * PC_PAIRS + wave * 32 + pl;
-            const int32_t pi = p.perm ? p.perm[slot] : (slot < p.B ? (int32_t)slot : -1);   // -1: padding
             if (h == 0 && pi >= 0) p.out[pi] = sbase[tpar * 128 + wave * 32 + pl] + (o + p.b3);
             tpar ^= 1;
 #if M2D_MLP_DIAG

@@ -21,7 +21,10 @@ int main(int argc, char **argv)
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
     auto dev = [&](size_t n, float scale) { std::vector<float> v(n); for (auto &x : v) x = rnd() * scale; float *d; hipMalloc(&d, n * 4); hipMemcpy(d, v.data(), n * 4, hipMemcpyHostToDevice); return d; };
     h.pm = dev(U * K, 1.f); h.re = dev(I * E, 1.f); h.ce = dev(C * E, 1.f);
-    { std::vector<float> c(I * C, 1.0f); float *d; hipMalloc(&d, c.size() * 4); hipMemcpy(d, c.data(), c.size() * 4, hipMemcpyHostToDevice); h.dish_cats = d; }
+    { std::vector<float> c(I * C, 1.0f);
+      if (argc > 5 && atoi(argv[5]))                         // random non-empty category subsets per dish (the bench's masks)
+          for (int64_t i = 0; i < I; ++i) { s = s * 1664525u + 1013904223u; const int pat = 1 + (int)((s >> 8) % 15); for (int q = 0; q < C; ++q) c[i * C + q] = (pat >> q) & 1 ? 1.0f : 0.0f; }
+      float *d; hipMalloc(&d, c.size() * 4); hipMemcpy(d, c.data(), c.size() * 4, hipMemcpyHostToDevice); h.dish_cats = d; }
     h.mlp_w1 = dev(K * 256, 0.1f); h.mlp_b1 = dev(256, 0.1f); h.mlp_w2 = dev(256 * 64, 0.1f); h.mlp_b2 = dev(64, 0.1f);
     h.mlp_w3 = dev(64, 0.1f); h.mlp_b3 = 0.f; h.mlp_h1 = 256; h.mlp_h2 = 64;
     hipMalloc(&h.err_dev, 16); hipMemset(h.err_dev, 0, 16);
