@@ -15,7 +15,10 @@ def _close(got, ref, tol=2e-5):
     assert np.all(np.abs(got[ok] - ref[ok]) <= tol * np.maximum(1.0, np.abs(ref[ok]))), np.abs(got[ok] - ref[ok]).max()
 
 
-@pytest.mark.parametrize("U,I,C,E,L,B", [(50, 30, 4, 64, 95, 128), (20, 10, 4, 200, 7, 8), (9, 5, 3, 6, 4, 33), (300, 100, 4, 32, 95, 1000)])
+@pytest.mark.parametrize("U,I,C,E,L,B", [(50, 30, 4, 64, 95, 128), (20, 10, 4, 200, 7, 8), (9, 5, 3, 6, 4, 33), (300, 100, 4, 32, 95, 1000),
+                                         (40, 30, 4, 64, 95, 3000),       # > 2048 pairs: the General_Memory assign by atomics
+                                         (20, 10, 4, 32, 130, 2500),      # three label masks
+                                         (20, 10, 4, 32, 300, 64)])       # more labels than the masks hold: every label walked
 def test_write_memory_matches_restatement(U, I, C, E, L, B):
     import torch
     from foodrec_amd import ScoringEngine
