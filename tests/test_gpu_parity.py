@@ -301,6 +301,10 @@ def test_user_high_table_option(torch_cuda):
     assert np.max(np.abs(tab[ok] - lit[ok]) / np.maximum(1.0, np.abs(lit[ok]))) < 2e-6
     pick = np.arange(0, B, 97)
     assert_scores_close(tab[pick], oracle.inference_f64(PM, RE, CE, users[pick], items[pick], cats[pick]))
+    eng.set_option("prefetch", 4)                                               # the table kernel's other instantiation
+    tab4 = eng.score_pairs(ut, it, ct).cpu().numpy(); eng.check()
+    assert eng.last_kernel() == "m2d_score_pairs_c4_uh" and np.array_equal(tab4, tab, equal_nan=True)
+    eng.set_option("prefetch", 2)
     small = eng.score_pairs(ut[:5000], it[:5000], ct[:5000]).cpu().numpy()       # below the threshold: the literal kernels
     assert eng.last_kernel() == "m2d_score_pairs_c4_small" and np.array_equal(small, lit[:5000], equal_nan=True)
     # the tables change under the engine: announced -> the derived table is rebuilt
