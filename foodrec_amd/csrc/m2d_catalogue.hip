@@ -581,26 +581,29 @@ constexpr int GRP_KEYOFF = 64, GRP_STAT = 64 + GRP_KEYS, GRP_WORDS = GRP_STAT + 
 // keep their id order.
 __global__ __launch_bounds__(256) void m2d_grp_norm_stats(const float *re, int64_t I, int E, float *norm, double *acc)
 {
-    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // a wave takes 64 consecutive rows of the block's 256, one row at a time (coalesced); one pair of atomics per block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ double ssum[2][4];
     double s1 = 0.0, s2 = 0.0;
-    if (d < I) {
+    const int64_t d0 = (int64_t)blockIdx.x * 256 + wave * 64;
+    for (int r = 0; r < 64 && d0 + r < I; ++r) {
+        const int64_t d = d0 + r;
         float q = 0.f;
-        for (int e = 0; e < E; ++e) {
+        for (int e = lane; e < E; e += 64) {
             const float x = re[d * E + e];
             q = fmaf(x, x, q);
         }
-        const float nr = sqrtf(q);
-        norm[d] = nr;
-        if (nr == nr && nr < INFINITY) { s1 = nr; s2 = (double)nr * nr; }
-    }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        s1 += __shfl_xor(s1, off, 64);
-        s2 += __shfl_xor(s2, off, 64);
+        for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+        const float nr = sqrtf(q);
+        if (lane == 0) norm[d] = nr;
+        if (nr == nr && nr < INFINITY) { s1 += nr; s2 += (double)nr * nr; }
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(acc, s1);
-        atomicAdd(acc + 1, s2);
+    if (lane == 0) { ssum[0][wave] = s1; ssum[1][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(acc, ssum[0][0] + ssum[0][1] + ssum[0][2] + ssum[0][3]);
+        atomicAdd(acc + 1, ssum[1][0] + ssum[1][1] + ssum[1][2] + ssum[1][3]);
     }
 }
 
@@ -642,24 +645,43 @@ __global__ __launch_bounds__(256) void m2d_grp_hist(const float *cats, const flo
     blk_hist[(size_t)blockIdx.x * GRP_KEYS + threadIdx.x] = sh[threadIdx.x];
 }
 
-// one block of GRP_KEYS threads: per-key exclusive scan over the blocks (in place), padded group offsets, key offsets
-// inside the groups (no padding between buckets), and the tile table  info = pattern | (valid rows << 8)
-__global__ __launch_bounds__(GRP_KEYS) void m2d_grp_scan(int32_t *blk_hist, int nblk, int32_t *grp, int32_t *tile_info)
+// one block of 4 GRP_KEYS threads: per-key exclusive scan over the blocks (in place; four threads share a key, each
+// owning a contiguous quarter of the blocks), padded group offsets, key offsets inside the groups (no padding between
+// buckets), and the tile table  info = pattern | (valid rows << 8)
+constexpr int GRP_SCAN_SPLIT = 4;
+__global__ __launch_bounds__(GRP_KEYS * GRP_SCAN_SPLIT) void m2d_grp_scan(int32_t *blk_hist, int nblk, int32_t *grp,
+                                                                           int32_t *tile_info)
 {
+    __shared__ int part[GRP_SCAN_SPLIT][GRP_KEYS];
     __shared__ int total[GRP_KEYS];
-    const int key = threadIdx.x;
-    int run = 0;
-    for (int b = 0; b < nblk; ++b) {
-        const int c = blk_hist[(size_t)b * GRP_KEYS + key];
-        blk_hist[(size_t)b * GRP_KEYS + key] = run;
-        run += c;
-    }
-    total[key] = run;
+    __shared__ int tile0[GRP_MAXPAT], prow[GRP_MAXPAT];
+    const int key = threadIdx.x % GRP_KEYS, qt = threadIdx.x / GRP_KEYS;
+    const int per = (nblk + GRP_SCAN_SPLIT - 1) / GRP_SCAN_SPLIT;
+    const int b0 = min(nblk, qt * per), b1 = min(nblk, b0 + per);
+    int sum = 0;
+    for (int b = b0; b < b1; ++b) sum += blk_hist[(size_t)b * GRP_KEYS + key];
+    part[qt][key] = sum;
     __syncthreads();
-    if (key == 0) {
+    int run = 0;
+    for (int j = 0; j < qt; ++j) run += part[j][key];
+    if (qt == GRP_SCAN_SPLIT - 1) total[key] = run + sum;
+    for (int b = b0; b < b1; b += 8) {          // loads of a batch before its stores: the in-place update keeps them in order
+        int c[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = b + j < b1 ? blk_hist[(size_t)(b + j) * GRP_KEYS + key] : 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (b + j < b1) blk_hist[(size_t)(b + j) * GRP_KEYS + key] = run;
+            run += c[j];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         int off = 0, t = 0;
         grp[0] = -1;
         grp[40] = 0;
+        tile0[0] = 0;
+        prow[0] = 0;
         for (int b = 0; b < GRP_NB; ++b) grp[GRP_KEYOFF + b] = 0;                 // pattern 0 (empty mask) is not ranked
         for (int q = 1; q < GRP_MAXPAT; ++q) {
             grp[q] = off;
@@ -670,11 +692,18 @@ __global__ __launch_bounds__(GRP_KEYS) void m2d_grp_scan(int32_t *blk_hist, int 
             }
             grp[40 + q] = rows;                                                  // rows per pattern (pipelined kernel)
             const int nt = (rows + 31) / 32;
-            for (int i = 0; i < nt; ++i) tile_info[t++] = q | (min(32, rows - 32 * i) << 8);
+            tile0[q] = t;
+            prow[q] = rows;
+            t += nt;
             off += nt * 32;
         }
         grp[16] = t;
         grp[17] = off;
+    }
+    __syncthreads();
+    for (int q = 1; q < GRP_MAXPAT; ++q) {
+        const int rows = prow[q], nt = (rows + 31) / 32;
+        for (int i = threadIdx.x; i < nt; i += GRP_KEYS * GRP_SCAN_SPLIT) tile_info[tile0[q] + i] = q | (min(32, rows - 32 * i) << 8);
     }
 }
 
@@ -1657,7 +1686,7 @@ int ensure_grouped(m2d_engine *h, hipStream_t st)
     hipLaunchKernelGGL(m2d_grp_norm_stats, dim3(nblk), dim3(256), 0, st, h->dish_high ? h->dish_high : h->re, I, h->E, norm, acc);
     hipLaunchKernelGGL(m2d_grp_norm_params, dim3(1), dim3(1), 0, st, acc, I, stat);
     hipLaunchKernelGGL(m2d_grp_hist, dim3(nblk), dim3(256), 0, st, h->dish_cats, norm, stat, I, h->C, blk_hist, flags);
-    hipLaunchKernelGGL(m2d_grp_scan, dim3(1), dim3(GRP_KEYS), 0, st, blk_hist, nblk, grp, h->grp_tile_info);
+    hipLaunchKernelGGL(m2d_grp_scan, dim3(1), dim3(GRP_KEYS * GRP_SCAN_SPLIT), 0, st, blk_hist, nblk, grp, h->grp_tile_info);
     hipLaunchKernelGGL(m2d_grp_scatter, dim3(nblk), dim3(256), 0, st, h->dish_cats, norm, stat, I, h->C, blk_hist, grp, h->grp_perm);
     hipLaunchKernelGGL(m2d_grp_gather, dim3((unsigned)((cap_rows + 3) / 4)), dim3(256), 0, st, h->re, h->dish_high,
                        h->grp_perm, cap_rows, h->E, h->grp_rs, reinterpret_cast<__bf16 *>(h->grp_rs16));
