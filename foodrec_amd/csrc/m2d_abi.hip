@@ -204,6 +204,17 @@ int m2d_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *items, c
 // Host-buffer form of m2d_score_pairs: what the reference's own call site hands over (numpy / lists, 51 pairs per
 // sess.run, evaluate.py:55-59).  One pinned staging block [users | items | cats | out | err], one H2D copy, the
 // kernel, one D2H copy that brings the scores AND the id-error latch back, one synchronisation.
+namespace {
+__global__ void m2d_copy_latch(const int32_t *latch, int32_t *dst, int32_t *done, int32_t ticket)
+{
+    if (threadIdx.x < 4) dst[threadIdx.x] = latch[threadIdx.x];
+    if (done) {                         // host-visible completion word, written after the latch (and after the scores,
+        __threadfence_system();         // which the kernel before this one on the stream wrote)
+        if (threadIdx.x == 0) __hip_atomic_store(done, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+}  // namespace
+
 int m2d_score_pairs_host(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats, int64_t B,
                          float *out, void *stream)
 {
@@ -214,9 +225,9 @@ int m2d_score_pairs_host(m2d_engine *h, const int32_t *users, const int32_t *ite
     hipStream_t st = (hipStream_t)stream;
     M2D_HIP_TRY(h, hipSetDevice(h->device));
     const int C = h->C;
-    // layout (16-byte aligned sections): cats [B, C] | users [B] | items [B] || out [B] | err [4]
+    // layout (16-byte aligned sections): cats [B, C] | users [B] | items [B] || out [B] | err [4] | completion word
     const size_t nb = ((size_t)B + 3) & ~(size_t)3;
-    const size_t in_bytes = nb * C * 4 + 2 * nb * 4, out_bytes = nb * 4 + 16, total = in_bytes + out_bytes;
+    const size_t in_bytes = nb * C * 4 + 2 * nb * 4, out_bytes = nb * 4 + 16, total = in_bytes + out_bytes + 16;
     if (total > h->stage_bytes) {
         M2D_HIP_TRY(h, hipStreamSynchronize(st));
         if (h->stage_host) (void)hipHostFree(h->stage_host);
@@ -231,15 +242,36 @@ int m2d_score_pairs_host(m2d_engine *h, const int32_t *users, const int32_t *ite
     memcpy(hs, cats, (size_t)B * C * 4);
     memcpy(hs + nb * C * 4, users, (size_t)B * 4);
     memcpy(hs + nb * C * 4 + nb * 4, items, (size_t)B * 4);
-    M2D_HIP_TRY(h, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, st));
-    const int rc = m2d_launch_score_pairs(h, reinterpret_cast<const int32_t *>(ds + nb * C * 4),
-                                          reinterpret_cast<const int32_t *>(ds + nb * C * 4 + nb * 4),
-                                          reinterpret_cast<const float *>(ds), false, B, reinterpret_cast<float *>(ds + in_bytes), st);
+    // Small feeds (the reference's 51 pairs per call, evaluate.py:55-59): the kernel reads the pinned block and writes the
+    // scores into it over the host link -- two launches and one synchronisation, no copy engine round trips.
+    unsigned char *ws = ds;
+    if (h->opt_host_zero_copy && B <= 65536) {
+        void *mapped = nullptr;
+        M2D_HIP_TRY(h, hipHostGetDevicePointer(&mapped, hs, 0));
+        ws = static_cast<unsigned char *>(mapped);
+    } else {
+        M2D_HIP_TRY(h, hipMemcpyAsync(ds, hs, in_bytes, hipMemcpyHostToDevice, st));
+    }
+    const int rc = m2d_launch_score_pairs(h, reinterpret_cast<const int32_t *>(ws + nb * C * 4),
+                                          reinterpret_cast<const int32_t *>(ws + nb * C * 4 + nb * 4),
+                                          reinterpret_cast<const float *>(ws), false, B, reinterpret_cast<float *>(ws + in_bytes), st);
     if (rc != M2D_OK) return rc;
-    // the latch rides back behind the scores: copy it next to them on the device first (16 B, same stream)
-    M2D_HIP_TRY(h, hipMemcpyAsync(ds + in_bytes + nb * 4, h->err_dev, 16, hipMemcpyDeviceToDevice, st));
-    M2D_HIP_TRY(h, hipMemcpyAsync(hs + in_bytes, ds + in_bytes, out_bytes, hipMemcpyDeviceToHost, st));
-    M2D_HIP_TRY(h, hipStreamSynchronize(st));
+    // the latch rides back behind the scores: put it next to them first (16 B, same stream)
+    const bool poll = ws != ds && h->opt_host_zero_copy >= 2;
+    int32_t *done_dev = poll ? reinterpret_cast<int32_t *>(ws + in_bytes + nb * 4 + 16) : nullptr;
+    volatile int32_t *done_host = reinterpret_cast<volatile int32_t *>(hs + in_bytes + nb * 4 + 16);
+    const int32_t ticket = ++h->stage_ticket;
+    if (poll) *done_host = ticket - 1;
+    hipLaunchKernelGGL(m2d_copy_latch, dim3(1), dim3(64), 0, st, h->err_dev, reinterpret_cast<int32_t *>(ws + in_bytes + nb * 4),
+                       done_dev, ticket);
+    M2D_HIP_TRY(h, hipGetLastError());
+    if (ws == ds) M2D_HIP_TRY(h, hipMemcpyAsync(hs + in_bytes, ds + in_bytes, out_bytes, hipMemcpyDeviceToHost, st));
+    bool seen = false;
+    if (poll) {
+        // spin on the completion word for a while (a stream synchronisation costs more than the two kernels)
+        for (int spin = 0; spin < 200000 && !seen; ++spin) seen = __atomic_load_n(const_cast<const int32_t *>(done_host), __ATOMIC_ACQUIRE) == ticket;
+    }
+    if (!seen) M2D_HIP_TRY(h, hipStreamSynchronize(st));
     const int32_t *err = reinterpret_cast<const int32_t *>(hs + in_bytes + nb * 4);
     if (err[0] != 0) return m2d_check(h, stream, nullptr, nullptr);     // formats the message, clears the latch
     memcpy(out, hs + in_bytes, (size_t)B * 4);
@@ -553,6 +585,7 @@ int m2d_set_option(m2d_engine *h, const char *name, int64_t value)
     else if (!strcmp(name, "mlp_form")) h->opt_mlp_form = (int)value;
     else if (!strcmp(name, "skip_masked")) h->opt_skip_masked = (int)value;
     else if (!strcmp(name, "user_high_table")) h->opt_user_high = (int)value;
+    else if (!strcmp(name, "host_zero_copy")) h->opt_host_zero_copy = (int)value;
     else return fail(h, M2D_ERR_INVALID_ARG, "m2d_set_option: unknown option");
     return M2D_OK;
 }
@@ -571,6 +604,7 @@ int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value)
     else if (!strcmp(name, "mlp_form")) *value = h->opt_mlp_form;
     else if (!strcmp(name, "skip_masked")) *value = h->opt_skip_masked;
     else if (!strcmp(name, "user_high_table")) *value = h->opt_user_high;
+    else if (!strcmp(name, "host_zero_copy")) *value = h->opt_host_zero_copy;
     else if (!strcmp(name, "num_cu")) *value = h->num_cu;
     else return M2D_ERR_INVALID_ARG;
     return M2D_OK;

@@ -74,6 +74,7 @@ struct m2d_engine {
     // staging for m2d_score_pairs_host: one pinned block and its device twin
     unsigned char *stage_host = nullptr, *stage_dev = nullptr;
     size_t stage_bytes = 0;
+    int32_t stage_ticket = 0;
 
     // scratch for rank_candidates
     float *scratch = nullptr;
@@ -85,6 +86,8 @@ struct m2d_engine {
     int opt_blocks_per_cu = 8;
     int opt_variant = 0;
     int opt_user_high = 0;              // opt-in: batches of >= 2^18 pairs take the high-level sum from the derived <U_high, CE_c> table
+    int opt_host_zero_copy = 2;         // m2d_score_pairs_host, <= 65536 pairs: 1 = the kernel reads / writes the pinned staging block itself,
+                                        // 2 = and the host spins on a completion word in that block before falling back to a stream wait; 0 = staged copies
     int opt_skip_masked = 1;            // pair kernels: rows of categories with mask weight 0 are not fetched (their products are 0)
     int opt_mlp_form = 0;               // split-bf16 MLP head: 0 = matrix waves fed by gather / DMA waves (m2d_mlp_pc), 1 = every wave gathers its own rows
     int opt_mlp_bf16x3 = 1;             // MLP head layer 1 (build-defined) on split-bf16 MFMA; 0 = exact-f32 MFMA

@@ -22,6 +22,10 @@ def _stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _dev_f32(x, device) -> torch.Tensor:
     t = torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x)
     return t.to(device=device, dtype=torch.float32).contiguous()
@@ -58,6 +62,7 @@ class ScoringEngine:
                             ctypes.byref(handle))
         _native.raise_for(rc, None)
         self._h = handle
+        self._host_fn = lib.m2d_score_pairs_host
         self.user_base = 0
         if user_base:
             self.set_user_base(user_base)
@@ -288,10 +293,16 @@ class ScoringEngine:
         if items.shape != (B,) or cats.shape != (B, self.C):
             raise ValueError("users [B], items [B], cats [B, %d] expected" % self.C)
         out = np.empty(B, dtype=np.float32)
-        with torch.cuda.device(self.device):
-            rc = _native.lib().m2d_score_pairs_host(self._h, users.ctypes.data, items.ctypes.data, cats.ctypes.data, B,
-                                                    out.ctypes.data, _stream_ptr())
-        _native.raise_for(rc, self._h)
+        ptr = lambda a: a.__array_interface__["data"][0]
+        idx = self.device.index
+        if _raw_stream is not None and _cur_device is not None and idx is not None and _cur_device() == idx:
+            # a 51-pair call is a few tens of microseconds: skip the device guard and the Stream object when nothing needs them
+            rc = self._host_fn(self._h, ptr(users), ptr(items), ptr(cats), B, ptr(out), _raw_stream(idx))
+        else:
+            with torch.cuda.device(self.device):
+                rc = self._host_fn(self._h, ptr(users), ptr(items), ptr(cats), B, ptr(out), _stream_ptr())
+        if rc:
+            _native.raise_for(rc, self._h)
         return out
 
     def score_pairs_bydish(self, users: torch.Tensor, items: torch.Tensor,

@@ -72,8 +72,11 @@ int m2d_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *items, c
                     int64_t B, float *out, void *stream);
 
 /* m2d_score_pairs for HOST buffers -- what the reference's call site actually hands over (lists / numpy, 51 pairs
- * per call, evaluate.py:39-59).  users, items, cats and out are host pointers; the call stages them through one
- * pinned block (one copy in, one copy out), SYNCHRONISES `stream` and returns the scores in `out`.  An out-of-range
+ * per call, evaluate.py:39-59).  users, items, cats and out are host pointers; the call puts them in one pinned
+ * block, WAITS for the work it enqueued on `stream` and returns the scores in `out`.  Up to 65 536 pairs the kernel
+ * reads and writes that block over the host link and the call spins on a completion word behind the scores before it
+ * falls back to a stream wait; larger feeds (or option "host_zero_copy" = 0) take one copy in and one copy out
+ * (1 = pinned block without the spin).  Same kernels, same bits either way.  An out-of-range
  * id is returned directly as M2D_ERR_BAD_USER_ID / M2D_ERR_BAD_ITEM_ID (text in m2d_last_error), `out` untouched.
  * This is the latency path; its rate includes PCIe and is never what bench.py reports as `value`. */
 int m2d_score_pairs_host(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
@@ -223,6 +226,7 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
  * uh[u][c] = <U_high[u], CE_c> (16 B per user, built by a pass over Personal_Memory and rebuilt after the engine's own
  * writers or m2d_tables_updated) as sum_c m_c uh[u][c] / n -- the same products in another order, scores within 1e-6 --
  * so that a pair reads 16 bytes of it instead of the U_high row.  Off, every call multiplies the gathered row.
+ * "host_zero_copy" (default 2): see m2d_score_pairs_host.
  * Kernel-selection knobs for benchmarking ("prefetch", "nt_loads", "blocks_per_cu", "variant"): results
  * never depend on them.  Two numerical switches, both for build-defined paths: "topk_bf16x3" (default 1) lets
  * m2d_topk_users contract on split-bf16 MFMA (x = hi + lo, three bf16 products, fp32 accumulation; score error

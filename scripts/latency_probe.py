@@ -14,6 +14,8 @@ CE = (rng.standard_normal((C, E)) / 8).astype(np.float32)
 args = types.SimpleNamespace(num_categories=C, num_users=U, embed_size=E, high_level_score_coefficient=0.99)
 model = foodrec_amd.Model(args, PM, RE, CE, None)
 sess = foodrec_amd.Session(model)
+if len(sys.argv) > 2:
+    model.engine.set_option("host_zero_copy", int(sys.argv[2]))
 d2c = {str(i): [[float(x)] for x in rng.integers(0, 2, C)] for i in range(I)}
 for k in d2c:
     if sum(v[0] for v in d2c[k]) == 0:

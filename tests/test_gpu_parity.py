@@ -227,13 +227,16 @@ def test_full_size_properties(torch_cuda):
     assert torch.equal(out2, out * 2)
 
 
-@pytest.mark.parametrize("B", [1, 51, 5000, 20000])
-def test_host_buffer_call_equals_the_device_op(torch_cuda, B):
-    """m2d_score_pairs_host (what Model.predict uses for host feeds) against the torch custom op: same kernel, same bits."""
+@pytest.mark.parametrize("zero_copy", [2, 1, 0])
+@pytest.mark.parametrize("B", [1, 51, 5000, 65536, 65537])
+def test_host_buffer_call_equals_the_device_op(torch_cuda, B, zero_copy):
+    """m2d_score_pairs_host (what Model.predict uses for host feeds) against the torch custom op: same kernel, same bits,
+    whether the kernel works on the pinned block itself (feeds of up to 65 536 pairs) or on a staged copy of it."""
     import torch
     from foodrec_amd import ScoringEngine
     PM, RE, CE, users, items, cats = random_case(400, 300, 4, 64, B, seed=B)
     eng = ScoringEngine(PM, RE, CE)
+    eng.set_option("host_zero_copy", zero_copy)
     dev = lambda a: torch.as_tensor(a, device="cuda")
     ref = eng.score_pairs(dev(users), dev(items), dev(cats)).cpu().numpy(); eng.check()
     got = eng.score_pairs_host(users, items, cats)
