@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One-off randomized soak of pair scoring, candidate ranking, catalogue retrieval and Write_Memory against the
+"""One-off randomized soak of pair scoring, candidate ranking, catalogue retrieval, Write_Memory, the training step and the
+ingredient table against the
 restatements (test infrastructure, not collected by pytest: seeds come from the clock).
 Usage on the GPU box: python tests/soak_random_cases.py [cases]."""
 import os, sys, time
@@ -133,11 +134,60 @@ def write_case(rng, what):
     return "write C%d E%d L%d B%d" % (C, E, L, B)
 
 
-kinds = [pairs_case, rank_case, topk_case, write_case]
+def train_case(rng, what):
+    from oracle import train_oracle as T
+    C = int(rng.choice([4, 3])); E = int(rng.choice([32, 64, 200, 6, 128]))
+    U = int(rng.integers(2, 3000)); I = int(rng.integers(2, 600)); B = int(rng.choice([256, int(rng.integers(1, 300)), int(rng.integers(300, 9000))]))
+    learner = str(rng.choice(["adam", "sgd", "adagrad", "rmsprop"])); lr = 0.01
+    PM, RE, CE = tables(rng, U, I, C, E)
+    PM, RE, CE = PM * 3, RE * 3, CE * 3
+    eng = ScoringEngine(PM.copy(), RE.copy(), CE.copy()); eng.train_begin(learner, lr)
+    st = T.TrainState(PM, RE, CE, learner, lr)
+    steps = 2
+    for _ in range(steps):
+        users = rng.integers(0, U, B).astype(np.int32); items = rng.integers(0, I, B).astype(np.int32)
+        users[: B // 4] = users[0]
+        cats = rng.integers(0, 2, (B, C)).astype(np.float32)
+        cats[cats.sum(1) == 0, rng.integers(0, C)] = 1.0
+        if rng.integers(0, 2): cats *= rng.uniform(0.5, 2.0, (B, C)).astype(np.float32)
+        labels = rng.integers(0, 2, B).astype(np.float32)
+        ref_loss, ref_norm = st.step(users, items, cats, labels)
+        loss, norm, _, _ = eng.train_step(dev(users), dev(items), dev(cats), dev(labels)).cpu().numpy(); eng.check()
+        assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (what, loss, ref_loss)
+        assert abs(norm - ref_norm) <= 2e-5 * max(1.0, ref_norm), (what, norm, ref_norm)
+    tol = 1e-3 * lr * steps if learner in ("adam", "rmsprop") else 1e-5
+    for got, ref in ((eng.pm, st.PM), (eng.re, st.RE), (eng.ce, st.CE)):
+        err = np.abs(got.cpu().numpy().astype(np.float64) - ref)
+        bound = tol * np.maximum(1.0, np.abs(ref)) if learner in ("sgd", "adagrad") else tol
+        assert np.all(err <= bound), (what, learner, err.max())
+    eng.train_end()
+    return "train %s C%d E%d B%d" % (learner, C, E, B)
+
+
+def ingredients_case(rng, what):
+    C = 4; E = int(rng.choice([6, 32, 64, 128, 200, 320]))
+    U = int(rng.integers(1, 500)); I = int(rng.integers(1, 400)); R = int(rng.integers(1, 600)); B = int(rng.integers(1, 20000))
+    PM, RE, CE = tables(rng, U, I, C, E)
+    ING = (rng.standard_normal((R, E)) / np.sqrt(E)).astype(np.float32)
+    lens = rng.integers(0 if rng.integers(0, 2) else 1, int(rng.integers(1, 40)) + 1, I)
+    off = np.zeros(I + 1, np.int32); off[1:] = np.cumsum(lens)
+    ids = rng.integers(0, R, off[-1]).astype(np.int32)
+    w = rng.uniform(0.5, 2.0, len(ids)).astype(np.float32) if rng.integers(0, 2) else None
+    dc = masks(rng, I, C, rng.integers(0, 2), rng.integers(0, 2))
+    users = rng.integers(0, U, B).astype(np.int32); items = rng.integers(0, I, B).astype(np.int32)
+    eng = ScoringEngine(PM, RE, CE); eng.set_ingredients(ING, off, ids, w); eng.set_dish_categories(dc)
+    got = eng.score_pairs_ingredients(dev(users), dev(items)); eng.check()
+    pick = rng.integers(0, B, min(B, 3000))
+    ref = oracle.inference_ingredients(PM, RE, ING, off, ids, w, users[pick], items[pick], dc[items[pick]])
+    assert_scores_close(got.cpu().numpy()[pick], ref, what=what)
+    return "ingredients E%d I%d R%d B%d %s" % (E, I, R, B, eng.last_kernel())
+
+
+kinds = [pairs_case, rank_case, topk_case, write_case, train_case, ingredients_case]
 for it in range(n):
     rng = np.random.default_rng(seed0 + it)
     fn = kinds[it % len(kinds)]
     msg = fn(rng, "case %d seed %d" % (it, seed0 + it))
-    if it % 8 < 4:
+    if it % 12 < 6:
         print("ok", it, msg, flush=True)
 print("all", n, "cases agree")
