@@ -731,17 +731,16 @@ __global__ __launch_bounds__(256) void m2d_grp_scatter(const float *cats, const 
 // With the ingredient extension (hv = H[d]) a slot's row is [H[d] | RE[d]], EW = 2 E: the high-level
 // term <a U_high, H[d]> then rides in the same contraction as the low-level one (see GroupedArgs::hv).
 __global__ __launch_bounds__(256) void m2d_grp_gather(const float *re, const float *hv, const int32_t *perm, int64_t slots,
-                                                      int E, float *rs, __bf16 *rs16)
+                                                      int E, int EW, float *rs, __bf16 *rs16)
 {
     const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= slots) return;
-    const int32_t d = perm[slot];
-    const int EW = hv ? 2 * E : E;
+    const int32_t d = perm[slot];                 // EW = 2 E with hv, else E or E zero-padded to the kernel's width
     __bf16 *hi = rs16 + ((slot >> 5) * 64 + (slot & 31)) * (size_t)EW;
     __bf16 *lo = hi + 32 * (size_t)EW;
     for (int e = threadIdx.x & 63; e < EW; e += 64) {
         float x = 0.f;
-        if (d >= 0) x = hv ? (e < E ? hv[(size_t)d * E + e] : re[(size_t)d * E + e - E]) : re[(size_t)d * E + e];
+        if (d >= 0) x = hv ? (e < E ? hv[(size_t)d * E + e] : re[(size_t)d * E + e - E]) : (e < E ? re[(size_t)d * E + e] : 0.f);
         rs[slot * EW + e] = x;
         const __bf16 xh = (__bf16)x;
         hi[e] = xh;
@@ -767,14 +766,21 @@ struct GroupedArgs {
     int32_t *out_ids;
     int32_t *err;
     unsigned long long *dbg;   // scripts/diag only
+    int32_t e_real;            // padded form only: the tables' E (rows of `rs` are zero-padded to the kernel's E)
 };
 
-template <int E8, int WAVES, int KR>
+constexpr int grouped_tiles_per_stage(int E) { return E <= 32 ? 16 : (E == 64 ? 8 : (E == 128 ? 4 : 2)); }   // 64 KiB stages
+
+// PAD: the tables' embedding size is p.e_real <= E (a multiple of 4): the sorted dish rows are zero-padded to E floats
+// when the table is built, the user operand is zero beyond e_real -- the extra products are exact zeros, so the scores
+// are those of an unpadded contraction.  This is what takes the reference's own size (embed_size 200,
+// Train_recommender.py) off the one-block-per-user kernel.
+template <int E8, int WAVES, int KR, bool PAD = false>
 __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
 {
     constexpr int E = E8 * 8, C = 4;
     constexpr int S = E / 4;                               // 16-B slots per row
-    constexpr int TPS = E <= 32 ? 16 : (E == 64 ? 8 : 4);  // tiles per stage: 64 KiB stages
+    constexpr int TPS = grouped_tiles_per_stage(E);        // tiles per stage
     constexpr int STAGE_FLOATS = TPS * 32 * E;
     constexpr int PIECES = TPS * 32 * S / 64;              // 1-KiB DMA pieces per stage
     constexpr int SW = S < 16 ? S : 16;                    // XOR-swizzle modulus (bank row = 16 slots)
@@ -799,18 +805,19 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
             ul = 0;
         }
     }
-    const v4f *pmu = reinterpret_cast<const v4f *>(p.pm) + (size_t)ul * ((C + 1) * S);
+    const int Sr = PAD ? p.e_real / 4 : S;                 // 16-B slots per row of the tables
+    const v4f *pmu = reinterpret_cast<const v4f *>(p.pm) + (size_t)ul * ((C + 1) * Sr);
     float hc[C];                                           // <U_high, CE_c>   Model_Recommender.py:67-75
     {
         const v4f *ce4 = reinterpret_cast<const v4f *>(p.ce);
 #pragma unroll
         for (int c = 0; c < C; ++c) hc[c] = 0.f;
 #pragma unroll 1
-        for (int q = 0; q < S; ++q) {
+        for (int q = 0; q < Sr; ++q) {
             const v4f u = pmu[q];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const v4f w = ce4[c * S + q];
+                const v4f w = ce4[c * Sr + q];
                 hc[c] += (u.x * w.x + u.y * w.y) + (u.z * w.z + u.w * w.w);
             }
         }
@@ -870,9 +877,11 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
 #pragma unroll 1
                 for (int c = 0; c < C; ++c) {           // rolled: E8 loads in flight, not C * E8
                     if (!((pat >> c) & 1)) continue;
-                    const v4f *row = pmu + (c + 1) * S + h;
+                    const v4f *row = pmu + (c + 1) * Sr + h;
 #pragma unroll
-                    for (int T = 0; T < E8; ++T) wP[T] += row[2 * T];
+                    for (int T = 0; T < E8; ++T) {
+                        if (!PAD || 2 * T + h < Sr) wP[T] += row[2 * T];
+                    }
                 }
 #pragma unroll
                 for (int T = 0; T < E8; ++T) wP[T] *= beta;
@@ -888,6 +897,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
             const float *img = smem + (size_t)buf * STAGE_FLOATS + (size_t)(tl * 32 + j) * E;
 #pragma unroll
             for (int T = 0; T < E8; ++T) {
+                if (PAD && 8 * T >= p.e_real) break;       // wave-uniform: the rest of the row is padding
                 const int q = (2 * T + h) ^ (j & (SW - 1));
                 const v4f av = *reinterpret_cast<const v4f *>(img + q * 4);
                 const v4f bv = wP[T];
@@ -1654,6 +1664,15 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     }
 }
 
+// row width of the sorted dish table: E itself where a kernel is instantiated for it, else the next such width
+// (multiples of 4 up to 256 only; 0 = no grouped kernel serves this E)
+int grouped_row_width(int E)
+{
+    if (E == 32 || E == 64 || E == 128) return E;
+    if (E < 4 || E > 256 || E % 4 != 0) return 0;
+    return E < 32 ? 32 : (E < 64 ? 64 : (E < 128 ? 128 : 256));
+}
+
 int ensure_grouped(m2d_engine *h, hipStream_t st)
 {
     if (h->grp_valid) return M2D_OK;
@@ -1661,7 +1680,7 @@ int ensure_grouped(m2d_engine *h, hipStream_t st)
     const int nblk = (int)((I + 255) / 256);
     const int64_t max_tiles = (I + 31) / 32 + GRP_MAXPAT;
     const int64_t cap_rows = (max_tiles + 16) * 32;          // + one stage of zero rows past the last tile
-    const int EW = h->dish_high ? 2 * h->E : h->E;           // ingredient extension: rows are [H[d] | RE[d]]
+    const int EW = h->dish_high ? 2 * h->E : grouped_row_width(h->E);   // ingredient extension: rows are [H[d] | RE[d]]
     if (h->grp_cap_rows != cap_rows || h->grp_ew != EW || !h->grp_rs) {
         for (void *q : {(void *)h->grp_rs, (void *)h->grp_rs16, (void *)h->grp_perm, (void *)h->grp_tile_info, (void *)h->grp_work})
             if (q) M2D_HIP_TRY(h, hipFree(q));
@@ -1689,7 +1708,7 @@ int ensure_grouped(m2d_engine *h, hipStream_t st)
     hipLaunchKernelGGL(m2d_grp_scan, dim3(1), dim3(GRP_KEYS * GRP_SCAN_SPLIT), 0, st, blk_hist, nblk, grp, h->grp_tile_info);
     hipLaunchKernelGGL(m2d_grp_scatter, dim3(nblk), dim3(256), 0, st, h->dish_cats, norm, stat, I, h->C, blk_hist, grp, h->grp_perm);
     hipLaunchKernelGGL(m2d_grp_gather, dim3((unsigned)((cap_rows + 3) / 4)), dim3(256), 0, st, h->re, h->dish_high,
-                       h->grp_perm, cap_rows, h->E, h->grp_rs, reinterpret_cast<__bf16 *>(h->grp_rs16));
+                       h->grp_perm, cap_rows, h->E, EW, h->grp_rs, reinterpret_cast<__bf16 *>(h->grp_rs16));
     M2D_HIP_TRY(h, hipGetLastError());
     int32_t host[3] = {0, 0, 0};   // tiles, slots, flags  (a table build may synchronise)
     M2D_HIP_TRY(h, hipMemcpyAsync(host, grp + 16, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1758,20 +1777,21 @@ int pick_splits(m2d_engine *h, int64_t ublocks, int64_t tiles, int64_t min_tiles
     return nsplit;
 }
 
-template <int E8, int WAVES, int KR, bool BF16X3, bool HV = false>
+template <int E8, int WAVES, int KR, bool BF16X3, bool HV = false, bool PAD = false>
 int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, float *final_s, int32_t *final_i,
                    hipStream_t st)
 {
     static_assert(!HV || BF16X3, "the ingredient form exists for the pipelined split-bf16 kernel only");
+    static_assert(!PAD || !BF16X3, "zero-padded rows are served by the exact-f32 kernel");
     constexpr int E = E8 * 8;
-    constexpr int TPS = E <= 32 ? 16 : (E == 64 ? 8 : 4);
+    constexpr int TPS = grouped_tiles_per_stage(E);
     const size_t lds = (size_t)2 * TPS * 32 * E * sizeof(float);
     GroupedArgs a;
     a.pm = h->pm; a.ce = h->ce; a.rs = h->grp_rs; a.rs16 = reinterpret_cast<const __bf16 *>(h->grp_rs16);
     a.perm = h->grp_perm; a.tile_info = h->grp_tile_info;
     a.grp = h->grp_work + (size_t)((h->I + 255) / 256) * GRP_KEYS;
     a.users = users; a.nU = nU; a.U = h->U; a.user_base = h->user_base; a.k = k; a.tiles = h->grp_tiles;
-    a.a = h->a; a.b = h->b; a.err = h->err_dev; a.dbg = g_m2d_diag_buffer;
+    a.a = h->a; a.b = h->b; a.err = h->err_dev; a.dbg = g_m2d_diag_buffer; a.e_real = h->E;
     const int64_t ublocks = (nU + 32 * WAVES - 1) / (32 * WAVES);
     const int nsplit = pick_splits(h, ublocks, a.tiles, 2 * TPS, 512);
     a.nsplit = nsplit;
@@ -1811,7 +1831,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
             hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(512), lds, st, a);
         }
     } else {
-        auto kern = m2d_topk_grouped<E8, WAVES, KR>;
+        auto kern = m2d_topk_grouped<E8, WAVES, KR, PAD>;
         M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(WAVES * 64), lds, st, a);
     }
@@ -1890,7 +1910,9 @@ int m2d_launch_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32
     // scores of dishes with DIFFERENT mask patterns also resolve to the lower id -- see include/m2d.h)
     // ingredient extension: rows [H[d] | RE[d]] of width 2 E on the pipelined split-bf16 kernel (E = 32 / 64)
     const bool hv_ok = h->dish_high && h->opt_topk_bf16x3 != 0 && (h->E == 32 || h->E == 64);
-    if (h->C == 4 && (!h->dish_high || hv_ok) && k <= 16 && (h->E == 32 || h->E == 64 || h->E == 128) &&
+    const int roww = grouped_row_width(h->E);
+    const bool padded = !(h->E == 32 || h->E == 64 || h->E == 128);   // e.g. the reference's embed_size 200: rows padded to 256
+    if (h->C == 4 && (!h->dish_high || (hv_ok && !padded)) && k <= 16 && roww != 0 &&
         h->opt_topk_grouped != 0 && h->opt_variant != 7 && h->opt_variant != 8 && h->opt_variant != 9) {
         if ((rc = ensure_grouped(h, stream)) != M2D_OK) return rc;
         if (hv_ok && h->grp_binary && h->grp_tiles > 0) {
@@ -1909,6 +1931,12 @@ int m2d_launch_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32
                        : launch_grouped<EV / 8, 8, 16, X3>(h, users, nU, k, out_scores, out_ids, stream);
             M2D_GRP(32, false) M2D_GRP(64, false) M2D_GRP(128, false) M2D_GRP(64, true) M2D_GRP(128, true)
 #undef M2D_GRP
+#define M2D_GRP_PAD(EV)                                                                                                   \
+    if (padded && roww == EV)                                                                                             \
+        return k <= 10 ? launch_grouped<EV / 8, 8, 10, false, false, true>(h, users, nU, k, out_scores, out_ids, stream)  \
+                       : launch_grouped<EV / 8, 8, 16, false, false, true>(h, users, nU, k, out_scores, out_ids, stream);
+            M2D_GRP_PAD(32) M2D_GRP_PAD(64) M2D_GRP_PAD(128) M2D_GRP_PAD(256)
+#undef M2D_GRP_PAD
         }
     }
     rc = m2d_ensure_dish_vectors(h, stream);

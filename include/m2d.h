@@ -103,6 +103,10 @@ int m2d_rank_candidates(m2d_engine *h, const int32_t *users, const int32_t *item
  * dish id, NaN scores last.  out_scores f32[nU, k], out_ids i32[nU, k].  1 <= k <= 64.
  * Scores agree with m2d_score_pairs_bydish within the 1e-4 bar, not bit for bit (factored form; see the
  * "topk_bf16x3" option below).
+ * Kernels: 0/1 masks, C = 4, k <= 16 and E a multiple of 4 up to 256 run the pattern-grouped MFMA kernels (E = 64 / 128
+ * on split bf16 by default; other sizes, e.g. the reference's embed_size 200, exact f32 on dish rows zero-padded to
+ * 32 / 64 / 128 / 256 floats); other masks or k run the dense MFMA kernel where (C + 1) E / 8 is 20, 40 or 80, and a
+ * one-block-per-user kernel otherwise.
  * With the ingredient table set (m2d_set_ingredients) the high-level term uses H[d]; E = 32 / 64 stay on the
  * pattern-grouped split-bf16 kernel (rows [H[d] | RE[d]]), other shapes use the dense kernel.
  * Tie rule, precisely: with 0/1 masks, C = 4, k <= 16 the pattern-grouped kernels scan the dishes grouped by mask

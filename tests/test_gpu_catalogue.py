@@ -53,7 +53,7 @@ def _check(eng, PM, RE, CE, cats, users, k, user_base=0):
                 assert got_ids[a] < got_ids[a + 1], (u, got_ids[a], got_ids[a + 1])
 
 
-@pytest.mark.parametrize("E,C", [(32, 4), (64, 4), (128, 4), (200, 4), (16, 3), (20, 4)])
+@pytest.mark.parametrize("E,C", [(32, 4), (64, 4), (128, 4), (200, 4), (16, 3), (20, 4), (100, 4), (48, 4), (256, 4), (260, 4), (22, 4)])
 @pytest.mark.parametrize("k", [1, 10, 16, 17, 64])
 def test_topk_users_shapes(E, C, k):
     from foodrec_amd import ScoringEngine
@@ -64,9 +64,17 @@ def test_topk_users_shapes(E, C, k):
     users = np.random.default_rng(1).integers(0, U, 45)
     _check(eng, PM, RE, CE, cats, users, k)
     mfma = (C, E) in ((4, 32), (4, 64), (4, 128))
+    padded = C == 4 and not mfma and E % 4 == 0 and E <= 256     # sorted dish rows zero-padded to 32 / 64 / 128 / 256 floats
     grouped = "m2d_topk_grouped_bf16x3" if E in (64, 128) else "m2d_topk_grouped"      # default: split-bf16
-    want = "m2d_topk_generic" if not mfma else (grouped if k <= 16 else "m2d_topk_mfma")
+    if padded:
+        want = "m2d_topk_grouped" if k <= 16 else "m2d_topk_generic"
+    else:
+        want = "m2d_topk_generic" if not mfma else (grouped if k <= 16 else "m2d_topk_mfma")
     assert eng.last_kernel() == want
+    if padded and k <= 16:
+        eng.set_option("topk_grouped", 0)             # the one-block-per-user kernel on the same data
+        _check(eng, PM, RE, CE, cats, users, k)
+        assert eng.last_kernel() == "m2d_topk_generic"
     if mfma and k <= 16:
         eng.set_option("topk_bf16x3", 0)              # exact-f32 MFMA, pattern-grouped
         _check(eng, PM, RE, CE, cats, users, k)
@@ -74,6 +82,24 @@ def test_topk_users_shapes(E, C, k):
         eng.set_option("variant", 7)                  # the dense (C+1)E contraction on the same data
         _check(eng, PM, RE, CE, cats, users, k)
         assert eng.last_kernel() == "m2d_topk_mfma"
+
+
+@pytest.mark.parametrize("E", [200, 100, 24])
+def test_topk_padded_rows_many_dishes(E):
+    """Embedding sizes without a kernel of their own (the reference's default is 200): dish rows zero-padded to the next
+    instantiated width.  More dishes than one stage holds, group tails, dish splits, weighted masks fall back."""
+    from foodrec_amd import ScoringEngine
+    U, I = 70, 5000
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=E, n_nan=5, dup=40)
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    users = np.arange(0, U, 3)
+    for k in (10, 16):
+        _check(eng, PM, RE, CE, cats, users, k)
+        assert eng.last_kernel() == "m2d_topk_grouped"
+    eng.set_dish_categories(cats * 0.5)
+    _check(eng, PM, RE, CE, cats * 0.5, users, 10)
+    assert eng.last_kernel() == "m2d_topk_generic"
 
 
 def test_topk_dish_splits_and_tail_tiles():
