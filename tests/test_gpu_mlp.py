@@ -18,13 +18,17 @@ def _head(K, H1, H2, rng, scale=1.0):
     return W1, b1, W2, b2, w3, 0.25
 
 
-@pytest.mark.parametrize("E,C,H1,H2,kernel", [(128, 4, 256, 64, "m2d_mlp_mfma"), (64, 4, 256, 64, "m2d_mlp_mfma"),
-                                              (256, 4, 256, 64, "m2d_mlp_mfma"), (32, 5, 256, 64, "m2d_mlp_mfma"),
-                                              (200, 4, 256, 64, "m2d_mlp_generic"), (64, 4, 128, 32, "m2d_mlp_generic"),
-                                              (6, 3, 10, 7, "m2d_mlp_generic")])
+_MLP_SHAPES = [(128, 4, 256, 64, "m2d_mlp_mfma"), (64, 4, 256, 64, "m2d_mlp_mfma"), (256, 4, 256, 64, "m2d_mlp_mfma"),
+               (32, 5, 256, 64, "m2d_mlp_mfma"), (200, 4, 256, 64, "m2d_mlp_generic"), (64, 4, 128, 32, "m2d_mlp_generic"),
+               (6, 3, 10, 7, "m2d_mlp_generic")]
+# split-bf16 MFMA: producer / consumer kernel (default), every-wave-gathers kernel; exact-f32 MFMA.  The generic kernel
+# has one form.
+_MLP_CASES = [shape + form for shape in _MLP_SHAPES
+              for form in ([(1, 0), (1, 1), (0, 0)] if shape[4] != "m2d_mlp_generic" else [(1, 0)])]
+
+
+@pytest.mark.parametrize("E,C,H1,H2,kernel,x3,form", _MLP_CASES)
 @pytest.mark.parametrize("B", [1, 127, 128, 129, 255, 256, 257, 3000])
-@pytest.mark.parametrize("x3,form", [(1, 0), (1, 1), (0, 0)])   # split-bf16 MFMA: producer / consumer kernel (default),
-                                                                  # every-wave-gathers kernel; exact-f32 MFMA
 def test_mlp_scores_match_restatement(E, C, H1, H2, kernel, B, x3, form):
     import torch
     from foodrec_amd import ScoringEngine
@@ -43,8 +47,6 @@ def test_mlp_scores_match_restatement(E, C, H1, H2, kernel, B, x3, form):
         eng.score_pairs_mlp(ut, it)
     eng.set_dish_categories(dish_cats)
     eng.set_mlp_head(*head)
-    if kernel == "m2d_mlp_generic" and (not x3 or form):
-        pytest.skip("the generic kernel has one form")
     eng.set_option("mlp_bf16x3", x3)
     eng.set_option("mlp_form", form)
     got = eng.score_pairs_mlp(ut, it); eng.check()
