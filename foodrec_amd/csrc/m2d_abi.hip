@@ -260,8 +260,8 @@ int m2d_score_pairs_host(m2d_engine *h, const int32_t *users, const int32_t *ite
     const bool poll = ws != ds && h->opt_host_zero_copy >= 2;
     int32_t *done_dev = poll ? reinterpret_cast<int32_t *>(ws + in_bytes + nb * 4 + 16) : nullptr;
     volatile int32_t *done_host = reinterpret_cast<volatile int32_t *>(hs + in_bytes + nb * 4 + 16);
-    const int32_t ticket = ++h->stage_ticket;
-    if (poll) *done_host = ticket - 1;
+    const int32_t ticket = (int32_t)++h->stage_ticket;
+    if (poll) *done_host = (int32_t)(h->stage_ticket - 1u);
     hipLaunchKernelGGL(m2d_copy_latch, dim3(1), dim3(64), 0, st, h->err_dev, reinterpret_cast<int32_t *>(ws + in_bytes + nb * 4),
                        done_dev, ticket);
     M2D_HIP_TRY(h, hipGetLastError());

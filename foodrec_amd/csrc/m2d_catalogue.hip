@@ -897,7 +897,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
             const float *img = smem + (size_t)buf * STAGE_FLOATS + (size_t)(tl * 32 + j) * E;
 #pragma unroll
             for (int T = 0; T < E8; ++T) {
-                if (PAD && 8 * T >= p.e_real) break;       // wave-uniform: the rest of the row is padding
+                if (PAD && 8 * T >= p.e_real) continue;    // wave-uniform: the rest of the row is padding
                 const int q = (2 * T + h) ^ (j & (SW - 1));
                 const v4f av = *reinterpret_cast<const v4f *>(img + q * 4);
                 const v4f bv = wP[T];
