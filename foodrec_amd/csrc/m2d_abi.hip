@@ -79,6 +79,7 @@ void release(m2d_engine *h)
             if (q) (void)hipFree((void *)q);
     }
     if (h->mlp_w1x3) (void)hipFree(h->mlp_w1x3);
+    if (h->mlp_w1pad) (void)hipFree(h->mlp_w1pad);
     if (h->mlp_w1pc) (void)hipFree(h->mlp_w1pc);
     if (h->mlp_pg) (void)hipFree(h->mlp_pg);
     if (h->user_high) (void)hipFree(h->user_high);
@@ -432,6 +433,8 @@ int m2d_clear_mlp_head(m2d_engine *h)
     }
     if (h->mlp_w1x3) (void)hipFree(h->mlp_w1x3);
     h->mlp_w1x3 = nullptr;
+    if (h->mlp_w1pad) (void)hipFree(h->mlp_w1pad);
+    h->mlp_w1pad = nullptr;
     if (h->mlp_w1pc) (void)hipFree(h->mlp_w1pc);
     h->mlp_w1pc = nullptr;
     h->mlp_w1 = h->mlp_b1 = h->mlp_w2 = h->mlp_b2 = h->mlp_w3 = nullptr;

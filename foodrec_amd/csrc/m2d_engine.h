@@ -44,6 +44,7 @@ struct m2d_engine {
     int32_t mlp_h1 = 0, mlp_h2 = 0;
     bool own_mlp = false;
     void *mlp_w1x3 = nullptr;           // split-bf16 image of W1 for the bf16x3 layer-1 path (built lazily)
+    float *mlp_w1pad = nullptr;         // W1 zero-padded to a multiple of 64 rows, for K = (C + 1) E that is not one (built lazily)
     void *mlp_w1pc = nullptr;           // W1 | W2 image of the producer / consumer kernel (built lazily)
     int32_t *mlp_pg = nullptr;          // per-launch pair grouping of that kernel: histogram | tile count | tile blocks | slot -> pair
     size_t mlp_pg_cap = 0;              // ints

@@ -122,7 +122,9 @@ __global__ __launch_bounds__(256) void m2d_mlp_split_w2(const float *w2, __bf16 
 // products, fp32 accumulation; per-product relative error <= ~1.2e-5, see m2d_topk_grouped_bf16) -- layer 1 is
 // 91 % of the head's flops and f32 MFMA runs at 1/16 of the bf16 rate.  Layer 2 takes the same form (its f32
 // MFMAs would otherwise cost as much as all of split-bf16 layer 1); layer 3 and the reference score stay f32.
-template <int KCH /* K / 64 */, bool X3>
+// PADK: the tables' K = (C + 1) E = p.K is not a multiple of 64 (the reference's embed_size 200 gives 1000): the kernel runs
+// KCH = ceil(K / 64) chunks on a W1 copy zero-padded to 64 KCH rows and reads zeros for the k-values past the end of a row.
+template <int KCH /* K / 64 */, bool X3, bool PADK = false>
 __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
 {
     extern __shared__ __align__(16) float smem[];
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
     const int pl = lane & 31, h = lane >> 5;
     constexpr int K = KCH * 64;
     constexpr int NST = KCH + 1;              // stages per tile: KCH chunks of W1, then W2
+    const int K4 = PADK ? p.K / 4 : K / 4;    // 16-byte units per table row
 
     for (int i = threadIdx.x; i < MH1; i += MWAVES * 64) sb1[i] = p.b1[i];
     if (threadIdx.x < MH2) {
@@ -185,16 +188,21 @@ __global__ __launch_bounds__(MWAVES * 64) void m2d_mlp_mfma(MlpArgs p)
         if (did < 0 || (int64_t)did >= p.I) { latch(p.err, M2D_ERR_BAD_ITEM_ID, did, pi); did = 0; bad = true; }
         if (M2D_MLP_DIAG & 8) { ul = 0; did = 0; }          // diag bit 3: every pair reads row 0 (loads issue, no HBM traffic)
         // f32 form: the lane owns k = 64 kc + 32 h + t; bf16 form: k = 64 kc + 16 ks + 8 h + j (fragment order)
-        pu = reinterpret_cast<const v4f *>(p.pm) + (size_t)ul * (K / 4) + (X3 ? 2 : 8) * h;
-        pd = reinterpret_cast<const v4f *>(p.dt) + (size_t)did * (K / 4) + (X3 ? 2 : 8) * h;
+        pu = reinterpret_cast<const v4f *>(p.pm) + (size_t)ul * K4 + (X3 ? 2 : 8) * h;
+        pd = reinterpret_cast<const v4f *>(p.dt) + (size_t)did * K4 + (X3 ? 2 : 8) * h;
     };
     v4f ra[4], rb[4];
     auto load_raw = [&](int g) {                            // g = 2 kc + half
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f4 = X3 ? (g >> 1) * 16 + (g & 1) * 8 + 4 * (i >> 1) + (i & 1) : (g >> 1) * 16 + (g & 1) * 4 + i;
-            ra[i] = pu[f4];
-            rb[i] = pd[f4];
+            if (!PADK || f4 + (X3 ? 2 : 8) * h < K4) {
+                ra[i] = pu[f4];
+                rb[i] = pd[f4];
+            } else {
+                ra[i] = v4f{0.f, 0.f, 0.f, 0.f};
+                rb[i] = v4f{0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
     if ((int64_t)blockIdx.x < ntiles) {
@@ -1062,6 +1070,11 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
     a.perm = nullptr; a.tile_blocks = nullptr; a.ntiles_dev = nullptr; a.pshift = 0;
     const bool mfma_ok = a.H1 == MH1 && a.H2 == MH2 && a.K % 64 == 0 && h->opt_variant != 9;
     const int kch = a.K / 64;
+    int pad_kch = 0;                          // K % 64 != 0: chunks of the zero-padded form (0 = none instantiated)
+    if (a.H1 == MH1 && a.H2 == MH2 && a.K % 64 != 0 && a.K % 4 == 0 && h->opt_variant != 9) {
+        const int need = (a.K + 63) / 64;
+        pad_kch = need <= 5 ? 5 : (need <= 10 ? 10 : (need <= 16 ? 16 : (need <= 20 ? 20 : 0)));
+    }
     const bool pc_ok = (uint64_t)h->U * a.K * 4 < (1ull << 36) && (uint64_t)h->I * a.K * 4 < (1ull << 36) &&   // 32-bit row offsets in 16-B units
                        h->E % 32 == 0 && ((h->E / 32) & (h->E / 32 - 1)) == 0 && h->C <= 6 && h->dish_cats &&      // k-blocks of whole periods
                        B < (1ll << 31) - (1 << 16);                                                             // 32-bit pair slots
@@ -1146,6 +1159,45 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
     }
         M2D_MLP_CASE(3) M2D_MLP_CASE(5) M2D_MLP_CASE(10) M2D_MLP_CASE(20)
 #undef M2D_MLP_CASE
+        h->last_kernel = x3 ? "m2d_mlp_mfma_bf16x3" : "m2d_mlp_mfma";
+    } else if (pad_kch != 0) {
+        // K not a multiple of 64 (e.g. the reference's embed_size 200: K = 1000): the every-wave-gathers kernel on a W1 copy
+        // zero-padded to 64 pad_kch rows; a lane reads zeros for the k-values past the end of its rows
+        const int Kp = pad_kch * 64;
+        const size_t lds = (size_t)(2 * RING_FLOATS + MH1 + 2 * MH2) * sizeof(float);
+        const int64_t ntiles = (B + 32 * MWAVES - 1) / (32 * MWAVES);
+        const unsigned grid = (unsigned)(ntiles < h->num_cu ? ntiles : h->num_cu);
+        const bool x3 = h->opt_mlp_bf16x3 != 0;
+        if (!h->mlp_w1pad) {               // built once per head (m2d_set_mlp_head resets it)
+            M2D_HIP_TRY(h, hipMalloc((void **)&h->mlp_w1pad, (size_t)Kp * MH1 * sizeof(float)));
+            M2D_HIP_TRY(h, hipMemsetAsync(h->mlp_w1pad, 0, (size_t)Kp * MH1 * sizeof(float), stream));
+            M2D_HIP_TRY(h, hipMemcpyAsync(h->mlp_w1pad, h->mlp_w1, (size_t)a.K * MH1 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        }
+        a.w1 = h->mlp_w1pad;
+        if (x3 && !h->mlp_w1x3) {
+            M2D_HIP_TRY(h, hipMalloc((void **)&h->mlp_w1x3, (size_t)Kp * MH1 * 4 + (size_t)MH1 * MH2 * 4));
+            hipLaunchKernelGGL(m2d_mlp_split_w1, dim3((unsigned)(((int64_t)Kp * MH1 + 255) / 256)), dim3(256), 0, stream,
+                               h->mlp_w1pad, Kp, reinterpret_cast<__bf16 *>(h->mlp_w1x3));
+            hipLaunchKernelGGL(m2d_mlp_split_w2, dim3(MH1 * MH2 / 256), dim3(256), 0, stream, h->mlp_w2,
+                               reinterpret_cast<__bf16 *>(h->mlp_w1x3) + (size_t)Kp * MH1 * 2);
+            M2D_HIP_TRY(h, hipGetLastError());
+        }
+        a.w1x3 = reinterpret_cast<const __bf16 *>(h->mlp_w1x3);
+        a.w2x3 = a.w1x3 ? a.w1x3 + (size_t)Kp * MH1 * 2 : nullptr;
+#define M2D_MLP_PAD_CASE(N)                                                                                 \
+    if (pad_kch == N) {                                                                                     \
+        if (x3) {                                                                                           \
+            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_mlp_mfma<N, true, true>,                   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+            hipLaunchKernelGGL((m2d_mlp_mfma<N, true, true>), dim3(grid), dim3(MWAVES * 64), lds, stream, a); \
+        } else {                                                                                            \
+            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_mlp_mfma<N, false, true>,                  \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+            hipLaunchKernelGGL((m2d_mlp_mfma<N, false, true>), dim3(grid), dim3(MWAVES * 64), lds, stream, a); \
+        }                                                                                                   \
+    }
+        M2D_MLP_PAD_CASE(5) M2D_MLP_PAD_CASE(10) M2D_MLP_PAD_CASE(16) M2D_MLP_PAD_CASE(20)
+#undef M2D_MLP_PAD_CASE
         h->last_kernel = x3 ? "m2d_mlp_mfma_bf16x3" : "m2d_mlp_mfma";
     } else {
         const size_t lds = (size_t)4 * (a.K + a.H1 + a.H2) * sizeof(float);

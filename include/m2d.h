@@ -205,8 +205,9 @@ int m2d_score_pairs_ingredients(m2d_engine *h, const int32_t *users, const int32
  * (sum_k z[k] is the reference score, Model_Recommender.py:67-96 in factored form):
  *     score = sum_k z[k] + w3 . relu(W2^T relu(W1^T z + b1) + b2) + b3
  * W1 f32[K, H1], b1 f32[H1], W2 f32[H1, H2], b2 f32[H2], w3 f32[H2].  H1 = 256, H2 = 64 with K % 64 == 0
- * run on the MFMA kernel (split-bf16 layers 1-2 by default, exact f32 with option "mlp_bf16x3" = 0); other
- * sizes run a generic kernel.  Dish masks must be resident
+ * run on the MFMA kernels (split-bf16 layers 1-2 by default, exact f32 with option "mlp_bf16x3" = 0), and so do
+ * K % 4 == 0, K <= 1280 on a W1 copy zero-padded to whole 64-row chunks (the reference's embed_size 200 gives
+ * K = 1000); other sizes run a generic kernel.  Dish masks must be resident
  * (m2d_set_dish_categories); the ingredient table, when set, feeds Dt's high-level part. */
 int m2d_set_mlp_head(m2d_engine *h, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *w3, float b3, int32_t H1, int32_t H2, int table_flags);

@@ -19,12 +19,15 @@ def _head(K, H1, H2, rng, scale=1.0):
 
 
 _MLP_SHAPES = [(128, 4, 256, 64, "m2d_mlp_mfma"), (64, 4, 256, 64, "m2d_mlp_mfma"), (256, 4, 256, 64, "m2d_mlp_mfma"),
-               (32, 5, 256, 64, "m2d_mlp_mfma"), (200, 4, 256, 64, "m2d_mlp_generic"), (64, 4, 128, 32, "m2d_mlp_generic"),
-               (6, 3, 10, 7, "m2d_mlp_generic")]
-# split-bf16 MFMA: producer / consumer kernel (default), every-wave-gathers kernel; exact-f32 MFMA.  The generic kernel
-# has one form.
-_MLP_CASES = [shape + form for shape in _MLP_SHAPES
-              for form in ([(1, 0), (1, 1), (0, 0)] if shape[4] != "m2d_mlp_generic" else [(1, 0)])]
+               (32, 5, 256, 64, "m2d_mlp_mfma"),
+               # K = (C + 1) E not a multiple of 64 (200 is the reference's default embed_size): zero-padded chunks
+               (200, 4, 256, 64, "padded"), (100, 4, 256, 64, "padded"), (40, 4, 256, 64, "padded"), (240, 4, 256, 64, "padded"),
+               (36, 3, 256, 64, "padded"),
+               (64, 4, 128, 32, "m2d_mlp_generic"), (6, 3, 10, 7, "m2d_mlp_generic"), (30, 4, 256, 64, "m2d_mlp_generic")]
+# split-bf16 MFMA: producer / consumer kernel (default), every-wave-gathers kernel; exact-f32 MFMA.  The padded form
+# exists for the every-wave-gathers kernel only (either arithmetic), the generic kernel has one form.
+_MLP_FORMS = {"m2d_mlp_mfma": [(1, 0), (1, 1), (0, 0)], "padded": [(1, 0), (0, 0)], "m2d_mlp_generic": [(1, 0)]}
+_MLP_CASES = [shape + form for shape in _MLP_SHAPES for form in _MLP_FORMS[shape[4]]]
 
 
 @pytest.mark.parametrize("E,C,H1,H2,kernel,x3,form", _MLP_CASES)
@@ -50,7 +53,10 @@ def test_mlp_scores_match_restatement(E, C, H1, H2, kernel, B, x3, form):
     eng.set_option("mlp_bf16x3", x3)
     eng.set_option("mlp_form", form)
     got = eng.score_pairs_mlp(ut, it); eng.check()
-    want = kernel if kernel == "m2d_mlp_generic" or not x3 else ("m2d_mlp_mfma_bf16x3" if form else "m2d_mlp_pc_bf16x3")
+    if kernel == "padded":
+        want = "m2d_mlp_mfma_bf16x3" if x3 else "m2d_mlp_mfma"
+    else:
+        want = kernel if kernel == "m2d_mlp_generic" or not x3 else ("m2d_mlp_mfma_bf16x3" if form else "m2d_mlp_pc_bf16x3")
     assert eng.last_kernel() == want
     ref = oracle.inference_mlp(PM, RE, CE, dish_cats, *head, users, items)
     base = oracle.inference_f64(PM, RE, CE, users, items, dish_cats[items])
