@@ -346,3 +346,45 @@ def test_unusual_mask_weights_with_and_without_row_skipping(torch_cuda):
         assert np.array_equal(np.isnan(on), np.isnan(ref))
         ok = np.isfinite(ref)
         assert_scores_close(on[ok], ref[ok])
+
+
+def test_two_engines_on_two_streams(torch_cuda):
+    """include/m2d.h: distinct engines / streams are independent.  Two engines fed from two side streams, launches
+    interleaved, against the same calls on the default stream; and one engine moved between streams with a synchronise."""
+    torch = torch_cuda
+    from foodrec_amd import ScoringEngine
+    cases = [random_case(900, 700, 4, E, 60000, seed=E) for E in (64, 128)]
+    engs, refs, feeds = [], [], []
+    for PM, RE, CE, users, items, cats in cases:
+        eng = ScoringEngine(PM, RE, CE)
+        dc = np.random.default_rng(5).integers(0, 2, (700, 4)).astype(np.float32); dc[dc.sum(1) == 0, 0] = 1
+        eng.set_dish_categories(dc)
+        u, d, m = (torch.as_tensor(x, device=eng.device) for x in (users, items, cats))
+        tk = torch.arange(0, 900, dtype=torch.int32, device=eng.device)
+        refs.append((eng.score_pairs(u, d, m).clone(), eng.score_pairs_bydish(u, d).clone(), [t.clone() for t in eng.topk_users(tk, 10)]))
+        eng.check()
+        engs.append(eng); feeds.append((u, d, m, tk))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for rep in range(6):
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                u, d, m, tk = feeds[i]
+                outs[i].append((engs[i].score_pairs(u, d, m), engs[i].score_pairs_bydish(u, d), engs[i].topk_users(tk, 10)))
+    for st in streams:
+        st.synchronize()
+    for i in (0, 1):
+        engs[i].check()
+        for a, b, (ts, ti) in outs[i]:
+            assert torch.equal(a.nan_to_num(3.0), refs[i][0].nan_to_num(3.0))
+            assert torch.equal(b.nan_to_num(3.0), refs[i][1].nan_to_num(3.0))
+            assert torch.equal(ti, refs[i][2][1]) and torch.equal(ts.nan_to_num(3.0), refs[i][2][0].nan_to_num(3.0))
+    # one engine, the other stream, after a synchronise; host feeds go through the stream that is current
+    with torch.cuda.stream(streams[1]):
+        u, d, m, tk = feeds[0]
+        a = engs[0].score_pairs(u, d, m)
+        host = engs[0].score_pairs_host(cases[0][3][:51], cases[0][4][:51], cases[0][5][:51])
+    streams[1].synchronize()
+    assert torch.equal(a.nan_to_num(3.0), refs[0][0].nan_to_num(3.0))
+    assert np.array_equal(host, refs[0][0][:51].cpu().numpy(), equal_nan=True)
