@@ -10,92 +10,107 @@
 // the pair kernel then reads one extra E-float row per pair (m2d_score_pairs_c4<..., HV = true>).
 //
 // Kernel: one wave per block of DB consecutive dishes = one contiguous run of the CSR stream, so no
-// dish is split between waves and the result is deterministic.  Ingredient rows are staged BR at a
-// time into LDS with coalesced row reads (all BR row loads in flight together), then consumed with
-// lanes-as-columns: lane l accumulates columns l, l+64, ... while the wave walks the entries; segment
-// (dish) boundaries are wave-uniform, so the segment sum needs no cross-lane traffic at all.
+// dish is split between waves and the result is deterministic.  Lanes are columns: lane l accumulates
+// columns l, l + 64, ... while the wave walks the entries, BR rows requested together (coalesced row
+// reads, all in flight before the first is used) and the next batch's entry list requested under
+// them; segment (dish) boundaries are wave-uniform, so the segment sum needs no cross-lane traffic.
+// (The first form staged each batch of rows in LDS between the load and the accumulation.  With lanes
+// as columns every staged float is read back by the lane that wrote it, exactly once: the LDS hop only
+// added a write, a wave barrier and a read to each batch's latency chain -- 116 us for the benchmark's
+// 100 k dishes x 10.5 ingredients at E = 64, against what is measured below.)
 #include "m2d_engine.h"
 
 namespace {
 
 constexpr int DB = 16;   // dishes per wave
-constexpr int BR = 8;    // ingredient rows staged per batch (4 waves x 8 rows x <=256 floats = 32 KB of LDS)
-constexpr int CBMAX = 256;
 
 // Wave-uniform values are carried in SGPRs (readfirstlane) so every loop below is scalar control flow:
 // no shuffle ever executes under a partial EXEC mask.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+template <int NQ /* columns per lane: E <= 64 NQ per column block */>
 __global__ __launch_bounds__(256) void m2d_dish_high_from_ingredients(const float *ing, const int32_t *off,
                                                                       const int32_t *ids, const float *w,
                                                                       int64_t I, int64_t R, int E, float *H,
                                                                       int32_t *err)
 {
-    extern __shared__ __align__(16) float smem[];
+    constexpr int BR = NQ >= 4 ? 8 : 16;   // ingredient rows requested per batch (BR * NQ row registers)
     const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int64_t d0 = ((int64_t)blockIdx.x * 4 + wave) * DB;
     if (d0 >= I) return;   // wave-uniform; no block-level barrier is used below
     const int dn = (int)min<int64_t>(DB, I - d0);
-    const int cbw = E < CBMAX ? E : CBMAX;
-    float *stage = smem + (size_t)wave * BR * cbw;
-    const int32_t *offw = off + d0;            // offw[0..dn]: this wave's slice of the row pointer
-    const int e_begin = uni(offw[0]), e_end = uni(offw[dn]);
+    // this wave's slice of the row pointer, offw[0..dn], one entry per lane: a dish boundary is a v_readlane away
+    const int32_t offl = off[d0 + (lane <= dn ? lane : dn)];
+    const int e_begin = __builtin_amdgcn_readlane(offl, 0), e_end = __builtin_amdgcn_readlane(offl, dn);
 
-    for (int cb0 = 0; cb0 < E; cb0 += CBMAX) {
-        const int ncol = min(CBMAX, E - cb0);
+    for (int cb0 = 0; cb0 < E; cb0 += 64 * NQ) {
+        const int ncol = min(64 * NQ, E - cb0);
         int cur = 0;                           // dish being accumulated (scalar)
-        int next_off = uni(offw[1]);           // first entry of dish cur + 1
-        float acc[CBMAX / 64] = {0.f, 0.f, 0.f, 0.f};
+        int next_off = __builtin_amdgcn_readlane(offl, 1);   // first entry of dish cur + 1
+        float acc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = 0.f;
         float wtot = 0.f;
         auto flush = [&]() {
             float *row = H + (size_t)(d0 + cur) * E + cb0;
 #pragma unroll
-            for (int q = 0; q < CBMAX / 64; ++q) {
+            for (int q = 0; q < NQ; ++q) {
                 const int c = lane + 64 * q;
                 if (c < ncol) row[c] = acc[q] / wtot;          // empty list: 0/0 = NaN
                 acc[q] = 0.f;
             }
             wtot = 0.f;
             ++cur;
-            next_off = cur < dn ? uni(offw[cur + 1]) : 0x7fffffff;
+            next_off = cur < dn ? __builtin_amdgcn_readlane(offl, cur + 1) : 0x7fffffff;
         };
-        for (int pos = e_begin; pos < e_end; pos += BR) {
-            const int nb = min(BR, e_end - pos);
-            int32_t id = 0;
-            float wt = 0.f;
-            if (lane < nb) {
+        auto fetch_entries = [&](int pos, int32_t &id, float &wt) {
+            id = 0;
+            wt = 0.f;
+            if (lane < BR && pos + lane < e_end) {
                 id = ids[pos + lane];
                 wt = w ? w[pos + lane] : 1.0f;
-                if (id < 0 || id >= R) {
-                    if (atomicCAS(&err[0], 0, M2D_ERR_BAD_INGREDIENT) == 0) {
-                        err[1] = id;
-                        err[2] = pos + lane;
-                        err[3] = 0;
-                    }
-                    id = 0;
-                    wt = __builtin_nanf("");
+            }
+        };
+        int32_t id_next;
+        float wt_next;
+        fetch_entries(e_begin, id_next, wt_next);
+        for (int pos = e_begin; pos < e_end; pos += BR) {
+            const int nb = min(BR, e_end - pos);
+            int32_t id = id_next;
+            float wt = wt_next;
+            if (lane < nb && (id < 0 || id >= R)) {
+                if (atomicCAS(&err[0], 0, M2D_ERR_BAD_INGREDIENT) == 0) {
+                    err[1] = id;
+                    err[2] = pos + lane;
+                    err[3] = 0;
                 }
+                id = 0;
+                wt = __builtin_nanf("");
             }
-            // stage nb rows x ncol floats: one row at a time, lanes along the row (coalesced)
-            for (int r = 0; r < nb; ++r) {
-                const int rid = uni(__shfl(id, r, 64));
-                const float *src = ing + (size_t)rid * E + cb0;
-                for (int c = lane; c < ncol; c += 64) stage[r * ncol + c] = src[c];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (int r = 0; r < nb; ++r) {
-                while (pos + r >= next_off) flush();            // crossed into the next dish (scalar test)
-                const float wr = __shfl(wt, r, 64);
-                wtot += wr;
+            float v[BR][NQ];
 #pragma unroll
-                for (int q = 0; q < CBMAX / 64; ++q) {
-                    const int c = lane + 64 * q;
-                    if (c < ncol) acc[q] = fmaf(wr, stage[r * ncol + c], acc[q]);
+            for (int r = 0; r < BR; ++r) {
+                if (r < nb) {                                   // wave-uniform
+                    const int rid = __builtin_amdgcn_readlane(id, r);       // r is a constant after unrolling: v_readlane
+                    const float *src = ing + (size_t)rid * E + cb0;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int c = lane + 64 * q;
+                        v[r][q] = c < ncol ? src[c] : 0.f;
+                    }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            fetch_entries(pos + BR, id_next, wt_next);
+#pragma unroll
+            for (int r = 0; r < BR; ++r) {
+                if (r < nb) {
+                    while (pos + r >= next_off) flush();        // crossed into the next dish (scalar test)
+                    const float wr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wt), r));
+                    wtot += wr;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) acc[q] = fmaf(wr, v[r][q], acc[q]);
+                }
+            }
         }
         while (cur < dn) flush();
     }
@@ -129,13 +144,15 @@ int m2d_launch_check_csr(m2d_engine *h, hipStream_t stream)
 
 int m2d_launch_build_dish_high(m2d_engine *h, hipStream_t stream)
 {
-    const int cbw = h->E < CBMAX ? h->E : CBMAX;
-    const size_t lds = (size_t)4 * BR * cbw * sizeof(float);
     const int64_t waves = (h->I + DB - 1) / DB;
-    M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_dish_high_from_ingredients,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(m2d_dish_high_from_ingredients, dim3((unsigned)((waves + 3) / 4)), dim3(256), lds, stream,
-                       h->ing, h->ing_off, h->ing_ids, h->ing_w, h->I, h->ing_rows, h->E, h->dish_high, h->err_dev);
+    const dim3 grid((unsigned)((waves + 3) / 4));
+#define M2D_DISH_HIGH(NQ)                                                                                          \
+    hipLaunchKernelGGL(m2d_dish_high_from_ingredients<NQ>, grid, dim3(256), 0, stream, h->ing, h->ing_off, h->ing_ids, \
+                       h->ing_w, h->I, h->ing_rows, h->E, h->dish_high, h->err_dev)
+    if (h->E <= 64) M2D_DISH_HIGH(1);
+    else if (h->E <= 128) M2D_DISH_HIGH(2);
+    else M2D_DISH_HIGH(4);
+#undef M2D_DISH_HIGH
     M2D_HIP_TRY(h, hipGetLastError());
     return M2D_OK;
 }
