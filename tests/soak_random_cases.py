@@ -81,7 +81,7 @@ def rank_case(rng, what):
 
 def topk_case(rng, what):
     C = 4; E = int(rng.choice([32, 64, 128, 200, 16]))
-    U = int(rng.integers(1, 400)); I = int(rng.integers(1, 6000)); k = int(rng.integers(1, 65))
+    U = int(rng.integers(1, 400)); I = int(rng.integers(1, 6000)); k = int(rng.integers(1, min(64, I) + 1))     # the call needs k <= I
     PM, RE, CE = tables(rng, U, I, C, E)
     dc = masks(rng, I, C, rng.integers(0, 4) == 0, rng.integers(0, 2))
     eng = ScoringEngine(PM, RE, CE); eng.set_dish_categories(dc)
