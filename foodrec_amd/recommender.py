@@ -85,6 +85,20 @@ def _mask(categories, C: int, B: int):
     return m
 
 
+def _float_rows(x, B: int, width) -> np.ndarray:
+    """[B][width] nested lists (the driver's label / one-hot / write-sign feeds) or arrays -> float32 ndarray.  Lists of
+    lists go through one flat iterator (a third faster than np.asarray on two levels of nesting)."""
+    if isinstance(x, list) and len(x) == B and B > 0 and isinstance(x[0], list):
+        try:
+            a = np.fromiter(itertools.chain.from_iterable(x), dtype=np.float32, count=-1)
+            w_ = a.size // B
+            if a.size == B * w_ and (width is None or w_ == width) and set(map(len, x)) == {w_}:
+                return a.reshape(B, w_)
+        except (ValueError, TypeError):
+            pass
+    return np.asarray(x, dtype=np.float32)
+
+
 class Model:
     """``Model(args, Personal_Memory, Recipe_Embedding, Category_Embedding, General_Memory)``.
 
@@ -173,6 +187,47 @@ class Model:
         mt = m.to(dev) if isinstance(m, torch.Tensor) else torch.from_numpy(m).to(dev)
         return ut, dt, mt
 
+    def _device_batch(self, user_input, item_input, categories, floats):
+        """Host feeds of one driver batch (Train_recommender.py:189-194) -> device tensors through ONE staged copy:
+        users | items | masks | each entry of `floats` (name -> (feed, width)) packed into a single buffer.  Returns
+        (users, items, masks, {name: tensor [B, width]}); feeds that are already tensors take `_feeds`."""
+        extras = [(k, v, wd) for k, (v, wd) in floats.items()]
+        if any(isinstance(x, torch.Tensor) for x in (user_input, item_input, categories)) or \
+                any(isinstance(v, torch.Tensor) for _, v, _ in extras):
+            ut, dt, mt = self._feeds(user_input, item_input, categories)
+            B = ut.numel()
+            out = {}
+            for k, v, wd in extras:
+                t = v if isinstance(v, torch.Tensor) else torch.as_tensor(_float_rows(v, B, wd))
+                out[k] = t.to(self.device, torch.float32).reshape(B, -1)
+            return ut, dt, mt, out
+        u, d = _ids(user_input, "user"), _ids(item_input, "item")
+        B = len(u)
+        if len(d) != B:
+            raise ValueError("user_input and item_input differ in length")
+        m = _mask(categories, self.num_categories, B)
+        C = self.num_categories
+        rows = [_float_rows(v, B, wd) for _, v, wd in extras]
+        up = lambda n: (n + 3) & ~3                            # every section starts on a 16-byte boundary
+        Bp = up(B)
+        o_m = 2 * Bp
+        pos = o_m + up(B * C)
+        spans = []
+        for r in rows:
+            spans.append((pos, r.size))
+            pos += up(r.size)
+        buf = np.zeros(pos, dtype=np.float32)
+        ib = buf.view(np.int32)
+        ib[:B] = u
+        ib[Bp:Bp + B] = d
+        buf[o_m:o_m + B * C] = m.reshape(-1)
+        for r, (a, n) in zip(rows, spans):
+            buf[a:a + n] = r.reshape(-1)
+        t = torch.from_numpy(buf).to(self.device)
+        it = t.view(torch.int32)
+        out = {k: t[a:a + n].reshape(B, -1) for (k, _, _), (a, n) in zip(extras, spans)}
+        return it[:B], it[Bp:Bp + B], t[o_m:o_m + B * C].reshape(B, C), out
+
     def train_step(self, user_input, item_input, categories, labels, apply: bool = True):
         """``sess.run([model.loss_value, model.learning_rate, model.train_op], feed_dict)``
         (Train_recommender.py:189-199): returns ``(loss, learning_rate)`` as Python floats; with ``apply=False``
@@ -181,8 +236,8 @@ class Model:
             self.engine.train_begin(self.learner or "sgd", float(self.learning_rate), 5.0)
             self._train_started = True
         ut, dt, mt = self._feeds(user_input, item_input, categories)
-        y = torch.as_tensor(np.asarray(labels, dtype=np.float32) if not isinstance(labels, torch.Tensor) else labels)
-        out = self.engine.train_step(ut, dt, mt, y, apply=apply)
+        y = labels if isinstance(labels, torch.Tensor) else torch.as_tensor(np.asarray(labels, dtype=np.float32))
+        out = self.engine.train_step(ut, dt, mt, y.reshape(-1), apply=apply)
         self.engine.check()
         loss, _norm, _scale, lr = (float(v) for v in out.cpu().numpy())
         return loss, lr
@@ -199,8 +254,9 @@ class Model:
             self._gm_dev = torch.as_tensor(np.asarray(self.General_Memory, dtype=np.float32)).to(self.device).contiguous()
         ut, dt, mt = self._feeds(user_input, item_input, categories)
         B = ut.numel()
-        sign = torch.as_tensor(np.asarray(write_sign, dtype=np.float32)).reshape(B)
-        y = torch.as_tensor(np.asarray(user_one_hot_label, dtype=np.float32)).reshape(B, -1)
+        as_t = lambda v, wd: v if isinstance(v, torch.Tensor) else torch.as_tensor(_float_rows(v, B, wd))
+        sign = as_t(write_sign, 1).reshape(B)
+        y = as_t(user_one_hot_label, None).reshape(B, -1)
         return self.engine.write_memory(ut, dt, mt, sign, y, self._gm_dev, float(self.beta_1), float(self.beta_2),
                                         float(self.alpha), want_means=True, write_pm=personal, write_gm=general)
 
@@ -349,16 +405,25 @@ class Session:
         if has(m.logits):
             res[id(m.logits)] = m.predict(feed(m.user_input, m.user_input), feed(m.item_input, m.item_input),
                                           feed(m.categories, m.categories))
-        if has(m.train_op) or has(m.loss_value):
-            loss, lr = m.train_step(feed(m.user_input, m.user_input), feed(m.item_input, m.item_input),
-                                    feed(m.categories, m.categories), feed(m.labels, m.labels), apply=has(m.train_op))
+        need_train = has(m.train_op) or has(m.loss_value)
+        need_write = has(m.personal) or has(m.general)
+        if need_train or need_write:
+            # the batch crosses to the device once, whatever is fetched (Train_recommender.py:189-199 feeds six lists)
+            floats = {}
+            if need_train:
+                floats["labels"] = (feed(m.labels, m.labels), 1)
+            if need_write:
+                floats["sign"] = (feed(m.write_sign, m.write_sign), 1)
+                floats["onehot"] = (feed(m.user_one_hot_label, m.user_one_hot_label), None)
+            ut, dt, mt, ex = m._device_batch(feed(m.user_input, m.user_input), feed(m.item_input, m.item_input),
+                                             feed(m.categories, m.categories), floats)
+        if need_train:
+            loss, lr = m.train_step(ut, dt, mt, ex["labels"], apply=has(m.train_op))
             res[id(m.loss_value)] = np.float32(loss)
             res[id(m.train_op)] = None
             res["lr"] = np.float32(lr)
-        if has(m.personal) or has(m.general):
-            pmean, gmean = m.write_memory(feed(m.user_input, m.user_input), feed(m.item_input, m.item_input),
-                                          feed(m.categories, m.categories), feed(m.write_sign, m.write_sign),
-                                          feed(m.user_one_hot_label, m.user_one_hot_label),
+        if need_write:
+            pmean, gmean = m.write_memory(ut, dt, mt, ex["sign"], ex["onehot"],
                                           personal=has(m.personal), general=has(m.general))
             res[id(m.personal)] = None if pmean is None else np.float32(pmean)
             res[id(m.general)] = None if gmean is None else np.float32(gmean)
