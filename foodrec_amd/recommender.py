@@ -199,7 +199,7 @@ class Model:
             out = {}
             for k, v, wd in extras:
                 t = v if isinstance(v, torch.Tensor) else torch.as_tensor(_float_rows(v, B, wd))
-                out[k] = t.to(self.device, torch.float32).reshape(B, -1)
+                out[k] = t.to(self.device, torch.float32).reshape(B, t.numel() // B if B else 0)
             return ut, dt, mt, out
         u, d = _ids(user_input, "user"), _ids(item_input, "item")
         B = len(u)
@@ -225,7 +225,7 @@ class Model:
             buf[a:a + n] = r.reshape(-1)
         t = torch.from_numpy(buf).to(self.device)
         it = t.view(torch.int32)
-        out = {k: t[a:a + n].reshape(B, -1) for (k, _, _), (a, n) in zip(extras, spans)}
+        out = {k: t[a:a + n].reshape(B, n // B if B else 0) for (k, _, _), (a, n) in zip(extras, spans)}
         return it[:B], it[Bp:Bp + B], t[o_m:o_m + B * C].reshape(B, C), out
 
     def train_step(self, user_input, item_input, categories, labels, apply: bool = True):
