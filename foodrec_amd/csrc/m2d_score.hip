@@ -329,8 +329,134 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4_small(ScoreArgs p)
     }
 }
 
+// The throughput form for category counts other than 4 (1 <= C <= 8, E % 4 == 0, E / 4 <= LPP): the layout of
+// m2d_score_pairs_c4 -- a group of LPP lanes walks its LPP pairs, a float4 of every row per lane, two pairs' rows in
+// flight -- with the category loop unrolled to 8 and every c >= C step skipped by a wave-uniform branch (no 0 * row
+// products are added for categories the model does not have).  Mask weights are read as scalars (a pair's C weights
+// are not a float4).  One wave per pair, as m2d_score_pairs_generic does it, reaches 1.3-2.1 G pairs/s on config-2
+// sized tables where this form reaches the rate of the C = 4 kernel.
+template <int LPP, bool BYDISH, bool NT>
+__global__ __launch_bounds__(256) void m2d_score_pairs_cn(ScoreArgs p)
+{
+    constexpr int CM = 8, PF = 2;
+    const int C = p.C;
+    const int lane = threadIdx.x & 63;
+    const int j = lane & (LPP - 1);
+    const int E4 = p.E >> 2;
+    const bool col_ok = j < E4;
+    const int jc = col_ok ? j : 0;  // idle lanes re-read column 0 (in bounds), contribution zeroed
+    const int64_t nchunks = (p.B + 63) >> 6;
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+
+    const v4f *pm4 = reinterpret_cast<const v4f *>(p.pm);
+    const v4f *re4 = reinterpret_cast<const v4f *>(p.re);
+    const v4f *ce4 = reinterpret_cast<const v4f *>(p.ce);
+    const size_t urow4 = (size_t)(C + 1) * E4;  // float4 per user block
+
+    v4f cef[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        cef[c] = v4f{0.f, 0.f, 0.f, 0.f};
+        if (c < C && col_ok) cef[c] = ce4[(size_t)c * E4 + jc];
+    }
+
+    for (int64_t chunk = wave0; chunk < nchunks; chunk += nwaves) {
+        const int64_t pi = (chunk << 6) + lane;
+        const bool valid = pi < p.B;
+        int32_t uid = valid ? p.users[pi] : (int32_t)p.user_base;
+        int32_t did = valid ? p.items[pi] : 0;
+        int64_t ul = (int64_t)uid - p.user_base;
+        bool bad = false;
+        if (ul < 0 || ul >= p.U) {
+            latch_error(p.err, M2D_ERR_BAD_USER_ID, uid, pi);
+            ul = 0;
+            bad = true;
+        }
+        if (did < 0 || (int64_t)did >= p.I) {
+            latch_error(p.err, M2D_ERR_BAD_ITEM_ID, did, pi);
+            did = 0;
+            bad = true;
+        }
+        float mk[CM];
+        int32_t act = 0;
+        float n = 0.f;
+        {
+            const float *mrow = p.cats + (BYDISH ? (size_t)did : (size_t)pi) * C;
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                mk[c] = 0.f;
+                if (c < C) {
+                    if (valid) mk[c] = mrow[c];
+                    n += mk[c];                                                // :77
+                    // weight exactly 0: 0 * U_low[c] = 0 at :82-:90, the row is not fetched (a NaN weight keeps its row)
+                    act |= (!p.skip_masked || mk[c] != 0.f) ? (1 << c) : 0;
+                }
+            }
+        }
+        const int32_t ul32 = (int32_t)ul;
+
+        v4f ub[PF][CM + 1];
+        v4f ib[PF];
+        float my_high = 0.f, my_low = 0.f;
+
+        auto issue = [&](int s, int slot) {
+            const int32_t us = __shfl(ul32, s, LPP);
+            const int32_t ds = __shfl(did, s, LPP);
+            const int32_t as = __shfl(act, s, LPP);
+            const v4f *pu = pm4 + (size_t)us * urow4 + jc;
+            ub[slot][0] = ld4<NT>(pu);
+#pragma unroll
+            for (int r = 1; r <= CM; ++r) {
+                ub[slot][r] = v4f{0.f, 0.f, 0.f, 0.f};
+                if ((as >> (r - 1)) & 1) ub[slot][r] = ld4<NT>(pu + (size_t)r * E4);     // bits >= C are never set
+            }
+            ib[slot] = re4[(size_t)ds * E4 + jc];
+        };
+
+#pragma unroll
+        for (int k = 0; k < PF; ++k) issue(k, k);
+
+        for (int s0 = 0; s0 < LPP; s0 += PF) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k) {
+                const int s = s0 + k;
+                float hs = 0.f, ls = 0.f;
+#pragma unroll
+                for (int c = 0; c < CM; ++c) {
+                    if (c < C) {                                               // wave-uniform
+                        const float mc = __shfl(mk[c], s, LPP);
+                        const v4f dish_category = scale4(mc, cef[c]);       // :67
+                        hs = dot4(ub[k][0], dish_category, hs);             // :71, :75
+                        const v4f dish_memory = scale4(mc, ub[k][c + 1]);   // :82
+                        ls = dot4(ib[k], dish_memory, ls);                  // :86, :90
+                    }
+                }
+                if (!col_ok) {
+                    hs = 0.f;
+                    ls = 0.f;
+                }
+                if (s + PF < LPP) issue(s + PF, k);
+                hs = group_sum<LPP>(hs);
+                ls = group_sum<LPP>(ls);
+                if (j == s) {
+                    my_high = hs;
+                    my_low = ls;
+                }
+            }
+        }
+        if (valid) {
+            const float high = my_high / n;                                    // :79
+            const float low = my_low / n;                                      // :92
+            float score = __fadd_rn(__fmul_rn(p.a, high), __fmul_rn(p.b, low));     // :95-96, no fma contraction
+            if (bad) score = __builtin_nanf("");
+            p.out[pi] = score;
+        }
+    }
+}
+
 // Any C (<= 64), any E: one wave per pair, lanes stride over e.  Slow path for shapes the
-// vectorised kernel does not cover (E % 4 != 0, E > 256, C != 4).
+// vectorised kernels do not cover (E % 4 != 0, E > 256, C > 8) and the latency path of C != 4.
 template <bool BYDISH>
 __global__ __launch_bounds__(256) void m2d_score_pairs_generic(ScoreArgs p)
 {
@@ -437,6 +563,21 @@ int launch_any(m2d_engine *h, const ScoreArgs &a, hipStream_t st)
         else if (E4 < 16) launch_c4<16, false, BYDISH>(a, pf, nt, small, grid, st, nm);
         else if (E4 < 32) launch_c4<32, false, BYDISH>(a, pf, nt, small, grid, st, nm);
         else launch_c4<64, false, BYDISH>(a, pf, nt, small, grid, st, nm);
+    } else if (a.C <= 8 && (a.E % 4 == 0) && E4 <= 64 && !a.hv && a.B > 8192 && h->opt_variant != 9) {
+        blocks = (nchunks + 3) / 4;
+        if (blocks > cap) blocks = cap;
+        dim3 grid((unsigned)blocks);
+        h->last_kernel = "m2d_score_pairs_cn";
+#define M2D_CN(L)                                                                                        \
+    do {                                                                                                 \
+        if (nt) hipLaunchKernelGGL((m2d_score_pairs_cn<L, BYDISH, true>), grid, dim3(256), 0, st, a);    \
+        else hipLaunchKernelGGL((m2d_score_pairs_cn<L, BYDISH, false>), grid, dim3(256), 0, st, a);      \
+    } while (0)
+        if (E4 <= 8) M2D_CN(8);
+        else if (E4 <= 16) M2D_CN(16);
+        else if (E4 <= 32) M2D_CN(32);
+        else M2D_CN(64);
+#undef M2D_CN
     } else {
         if (a.C > 64) {
             h->last_error = "num_categories > 64 is not supported";

@@ -388,3 +388,45 @@ def test_two_engines_on_two_streams(torch_cuda):
     streams[1].synchronize()
     assert torch.equal(a.nan_to_num(3.0), refs[0][0].nan_to_num(3.0))
     assert np.array_equal(host, refs[0][0][:51].cpu().numpy(), equal_nan=True)
+
+
+@pytest.mark.parametrize("C,E", [(1, 64), (2, 128), (3, 64), (5, 32), (6, 64), (7, 200), (8, 16), (3, 36), (6, 256), (5, 4)])
+def test_vectorised_kernel_for_other_category_counts(torch_cuda, C, E):
+    """C != 4 (up to 8), E % 4 == 0, more than 8192 pairs: m2d_score_pairs_cn, the C = 4 kernel's layout with the category
+    loop unrolled to 8 -- against the restatement, against the one-wave-per-pair kernel, per-pair and resident masks, with
+    and without row skipping and non-temporal loads; bad ids latch as everywhere."""
+    torch = torch_cuda
+    from oracle import m2d_oracle as oracle
+    B = 20011
+    PM, RE, CE, users, items, cats = random_case(700, 300, C, E, B, seed=C * 100 + E)
+    cats[7] = np.linspace(0.25, 1.75, C)
+    cats[9] = 0.0                                         # 0/0 -> NaN
+    ref = oracle.inference_f64(PM, RE, CE, users, items, cats)
+    eng = _engine(PM, RE, CE)
+    outs = []
+    for skip in (1, 0):
+        for nt in (1, 0):
+            eng.set_option("skip_masked", skip); eng.set_option("nt_loads", nt)
+            got = _run(eng, torch, users, items, cats)
+            assert eng.last_kernel() == "m2d_score_pairs_cn"
+            assert_scores_close(got, ref, what="cn C%d E%d skip%d nt%d" % (C, E, skip, nt))
+            outs.append(got)
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0], equal_nan=True)              # finite tables: the skipped rows only added zeros
+    eng.set_option("variant", 9)
+    gen = _run(eng, torch, users, items, cats)
+    assert eng.last_kernel() == "m2d_score_pairs_generic"
+    assert_scores_close(gen, ref, what="generic C%d E%d" % (C, E))
+    eng.set_option("variant", 0)
+    assert _run(eng, torch, users[:100], items[:100], cats[:100]).shape == (100,)
+    assert eng.last_kernel() == "m2d_score_pairs_generic"             # small batches keep the one-wave-per-pair kernel
+    dish_cats = np.random.default_rng(C).integers(0, 2, (300, C)).astype(np.float32)
+    eng.set_dish_categories(dish_cats)
+    u, d = torch.as_tensor(users, device=eng.device), torch.as_tensor(items, device=eng.device)
+    byd = eng.score_pairs_bydish(u, d); eng.check()
+    assert eng.last_kernel() == "m2d_score_pairs_cn"
+    assert_scores_close(byd.cpu().numpy(), oracle.inference_f64(PM, RE, CE, users, items, dish_cats[items]), what="by dish")
+    bad = items.copy(); bad[12345] = 300
+    eng.score_pairs(u, torch.as_tensor(bad, device=eng.device), torch.as_tensor(cats, device=eng.device))
+    with pytest.raises(IndexError, match="item id 300 at position 12345"):
+        eng.check()
