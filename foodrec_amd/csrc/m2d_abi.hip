@@ -61,6 +61,8 @@ int adopt_table(m2d_engine *h, const float *src, size_t count, int flags, const 
 
 void release(m2d_engine *h)
 {
+    for (hipEvent_t e : h->stage_ev)
+        if (e) (void)hipEventDestroy(e);
     if (h->stage_host) (void)hipHostFree(h->stage_host);
     if (h->stage_dev) (void)hipFree(h->stage_dev);
     m2d_train_release(h);
@@ -216,6 +218,90 @@ __global__ void m2d_copy_latch(const int32_t *latch, int32_t *dst, int32_t *done
 }
 }  // namespace
 
+namespace {
+constexpr int64_t HOST_CHUNK = 1 << 18;
+
+int ensure_stage(m2d_engine *h, size_t total, hipStream_t st)
+{
+    if (total <= h->stage_bytes) return M2D_OK;
+    M2D_HIP_TRY(h, hipStreamSynchronize(st));
+    if (h->stage_host) (void)hipHostFree(h->stage_host);
+    if (h->stage_dev) (void)hipFree(h->stage_dev);
+    h->stage_host = h->stage_dev = nullptr; h->stage_bytes = 0;
+    const size_t cap = total * 2;
+    M2D_HIP_TRY(h, hipHostMalloc((void **)&h->stage_host, cap, hipHostMallocDefault));
+    M2D_HIP_TRY(h, hipMalloc((void **)&h->stage_dev, cap));
+    h->stage_bytes = cap;
+    return M2D_OK;
+}
+
+// Feeds of more than HOST_CHUNK pairs: chunks through two pinned blocks, so that the host's copy of chunk k + 1 into its
+// block runs while chunk k is on the link and in the kernel (one block: the five steps of a call run one after another
+// and the host-side copies are the longest of them).  Chunks retire in order; an id error is reported with the position
+// in the whole feed, and the scores of the chunks before the offending one have then been delivered.
+int score_pairs_host_chunked(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats, int64_t B,
+                             float *out, hipStream_t st)
+{
+    const int C = h->C;
+    const size_t in_b = (size_t)HOST_CHUNK * C * 4 + 2 * (size_t)HOST_CHUNK * 4, out_b = (size_t)HOST_CHUNK * 4 + 16;
+    const size_t blk = in_b + out_b;
+    int rc = ensure_stage(h, 2 * blk, st);
+    if (rc != M2D_OK) return rc;
+    for (hipEvent_t &e : h->stage_ev)
+        if (!e) M2D_HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const int64_t nch = (B + HOST_CHUNK - 1) / HOST_CHUNK;
+    auto retire = [&](int64_t k) -> int {
+        unsigned char *hs = h->stage_host + (size_t)(k & 1) * blk;
+        M2D_HIP_TRY(h, hipEventSynchronize(h->stage_ev[k & 1]));
+        const int32_t *err = reinterpret_cast<const int32_t *>(hs + in_b + (size_t)HOST_CHUNK * 4);
+        if (err[0] != 0) {
+            // the kernel latched a position inside its chunk: put the position in the feed there before reporting it
+            const int64_t idx = (((int64_t)(uint32_t)err[3] << 32) | (uint32_t)err[2]) + k * HOST_CHUNK;
+            int32_t *fixed = reinterpret_cast<int32_t *>(hs);                   // pinned; the block is not in use any more
+            fixed[0] = err[0]; fixed[1] = err[1]; fixed[2] = (int32_t)(idx & 0xffffffff); fixed[3] = (int32_t)(idx >> 32);
+            M2D_HIP_TRY(h, hipMemcpyAsync(h->err_dev, fixed, 16, hipMemcpyHostToDevice, st));
+            return m2d_check(h, (void *)st, nullptr, nullptr);                  // synchronises, formats, clears the latch
+        }
+        const int64_t n = B - k * HOST_CHUNK < HOST_CHUNK ? B - k * HOST_CHUNK : HOST_CHUNK;
+        memcpy(out + k * HOST_CHUNK, hs + in_b, (size_t)n * 4);
+        return M2D_OK;
+    };
+    for (int64_t k = 0; k < nch; ++k) {
+        if (k >= 2 && (rc = retire(k - 2)) != M2D_OK) {
+            (void)hipStreamSynchronize(st);
+            return rc;
+        }
+        unsigned char *hs = h->stage_host + (size_t)(k & 1) * blk, *ds = h->stage_dev + (size_t)(k & 1) * blk;
+        const int64_t o = k * HOST_CHUNK, n = B - o < HOST_CHUNK ? B - o : HOST_CHUNK;
+        const size_t o_u = (size_t)HOST_CHUNK * C * 4, o_i = o_u + (size_t)HOST_CHUNK * 4;
+        memcpy(hs, cats + o * C, (size_t)n * C * 4);
+        memcpy(hs + o_u, users + o, (size_t)n * 4);
+        memcpy(hs + o_i, items + o, (size_t)n * 4);
+        M2D_HIP_TRY(h, hipMemcpyAsync(ds, hs, (size_t)n * C * 4, hipMemcpyHostToDevice, st));
+        M2D_HIP_TRY(h, hipMemcpyAsync(ds + o_u, hs + o_u, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        M2D_HIP_TRY(h, hipMemcpyAsync(ds + o_i, hs + o_i, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        rc = m2d_launch_score_pairs(h, reinterpret_cast<const int32_t *>(ds + o_u), reinterpret_cast<const int32_t *>(ds + o_i),
+                                    reinterpret_cast<const float *>(ds), false, n, reinterpret_cast<float *>(ds + in_b), st);
+        if (rc != M2D_OK) {
+            (void)hipStreamSynchronize(st);
+            return rc;
+        }
+        hipLaunchKernelGGL(m2d_copy_latch, dim3(1), dim3(64), 0, st, h->err_dev,
+                           reinterpret_cast<int32_t *>(ds + in_b + (size_t)HOST_CHUNK * 4), (int32_t *)nullptr, 0);
+        M2D_HIP_TRY(h, hipGetLastError());
+        M2D_HIP_TRY(h, hipMemcpyAsync(hs + in_b, ds + in_b, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        M2D_HIP_TRY(h, hipMemcpyAsync(hs + in_b + (size_t)HOST_CHUNK * 4, ds + in_b + (size_t)HOST_CHUNK * 4, 16, hipMemcpyDeviceToHost, st));
+        M2D_HIP_TRY(h, hipEventRecord(h->stage_ev[k & 1], st));
+    }
+    for (int64_t k = nch >= 2 ? nch - 2 : 0; k < nch; ++k)
+        if ((rc = retire(k)) != M2D_OK) {
+            (void)hipStreamSynchronize(st);
+            return rc;
+        }
+    return M2D_OK;
+}
+}  // namespace
+
 int m2d_score_pairs_host(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats, int64_t B,
                          float *out, void *stream)
 {
@@ -225,19 +311,14 @@ int m2d_score_pairs_host(m2d_engine *h, const int32_t *users, const int32_t *ite
     if (!users || !items || !cats || !out) return fail(h, M2D_ERR_INVALID_ARG, "m2d_score_pairs_host: null buffer");
     hipStream_t st = (hipStream_t)stream;
     M2D_HIP_TRY(h, hipSetDevice(h->device));
+    if (B > HOST_CHUNK && h->opt_host_zero_copy != 0) return score_pairs_host_chunked(h, users, items, cats, B, out, st);
     const int C = h->C;
     // layout (16-byte aligned sections): cats [B, C] | users [B] | items [B] || out [B] | err [4] | completion word
     const size_t nb = ((size_t)B + 3) & ~(size_t)3;
     const size_t in_bytes = nb * C * 4 + 2 * nb * 4, out_bytes = nb * 4 + 16, total = in_bytes + out_bytes + 16;
-    if (total > h->stage_bytes) {
-        M2D_HIP_TRY(h, hipStreamSynchronize(st));
-        if (h->stage_host) (void)hipHostFree(h->stage_host);
-        if (h->stage_dev) (void)hipFree(h->stage_dev);
-        h->stage_host = h->stage_dev = nullptr; h->stage_bytes = 0;
-        const size_t cap = total * 2;
-        M2D_HIP_TRY(h, hipHostMalloc((void **)&h->stage_host, cap, hipHostMallocDefault));
-        M2D_HIP_TRY(h, hipMalloc((void **)&h->stage_dev, cap));
-        h->stage_bytes = cap;
+    {
+        const int rc_stage = ensure_stage(h, total, st);
+        if (rc_stage != M2D_OK) return rc_stage;
     }
     unsigned char *hs = h->stage_host, *ds = h->stage_dev;
     memcpy(hs, cats, (size_t)B * C * 4);

@@ -75,6 +75,7 @@ struct m2d_engine {
     // staging for m2d_score_pairs_host: one pinned block and its device twin
     unsigned char *stage_host = nullptr, *stage_dev = nullptr;
     size_t stage_bytes = 0;
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};   // chunked host feeds: a block's chunk has been delivered
     uint32_t stage_ticket = 0;          // completion word of the last m2d_score_pairs_host call (wraps)
 
     // scratch for rank_candidates

@@ -228,7 +228,7 @@ def test_full_size_properties(torch_cuda):
 
 
 @pytest.mark.parametrize("zero_copy", [2, 1, 0])
-@pytest.mark.parametrize("B", [1, 51, 5000, 65536, 65537])
+@pytest.mark.parametrize("B", [1, 51, 5000, 65536, 65537, 262144, 262145, 700001])      # > 262144: chunks through two pinned blocks
 def test_host_buffer_call_equals_the_device_op(torch_cuda, B, zero_copy):
     """m2d_score_pairs_host (what Model.predict uses for host feeds) against the torch custom op: same kernel, same bits,
     whether the kernel works on the pinned block itself (feeds of up to 65 536 pairs) or on a staged copy of it."""
