@@ -28,6 +28,42 @@ __global__ __launch_bounds__(256) void m2d_stream_read(const v4f *p, int64_t n4,
     if (s == 123456.789f) sink[0] = s;   // keeps the loads live; practically never true
 }
 
+// x * 0 is 0 for every finite x and NaN for inf / NaN: one fma per value, the lane's sum is NaN iff it met one
+__global__ __launch_bounds__(256) void m2d_scan_nonfinite(const float *p, int64_t n, int32_t *flag)
+{
+    const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+    const v4f *p4 = reinterpret_cast<const v4f *>(p);
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const v4f a = __builtin_nontemporal_load(p4 + i);
+        const v4f b = __builtin_nontemporal_load(p4 + i + stride);
+        const v4f c = __builtin_nontemporal_load(p4 + i + 2 * stride);
+        const v4f d = __builtin_nontemporal_load(p4 + i + 3 * stride);
+        acc += (a * 0.f + b * 0.f) + (c * 0.f + d * 0.f);
+    }
+    for (; i < n4; i += stride) acc += __builtin_nontemporal_load(p4 + i) * 0.f;
+    float s = (acc.x + acc.y) + (acc.z + acc.w);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) s += p[(n4 << 2) + threadIdx.x] * 0.f;
+    if (s != s) *flag = 1;
+}
+
+// the Personal_Memory blocks of a batch's users (after a writer that adds into them with atomics)
+__global__ __launch_bounds__(256) void m2d_rows_nonfinite(const float *pm, const int32_t *users, int64_t B, int64_t U, int64_t user_base,
+                                                          int32_t W, int32_t *flag)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    float s = 0.f;
+    for (int64_t b = wave0; b < B; b += nwaves) {
+        const int64_t ul = (int64_t)users[b] - user_base;
+        if (ul < 0 || ul >= U) continue;                     // reported by the writer itself
+        const float *row = pm + (size_t)ul * W;
+        for (int e = lane; e < W; e += 64) s += row[e] * 0.f;
+    }
+    if (s != s) *flag = 1;
+}
+
 std::string g_create_error;
 
 int fail(m2d_engine *h, int code, const char *msg)
@@ -99,6 +135,36 @@ void release(m2d_engine *h)
 
 }  // namespace
 
+// The scan queued by m2d_create / m2d_tables_updated: one streaming pass over the three tables on the caller's stream, in
+// front of the launch that needs its answer (1.28 GB of Personal_Memory: 0.2 ms, once per table change).
+int m2d_ensure_finite_scan(m2d_engine *h, hipStream_t st)
+{
+    if (!h->finite_scan_pending) return M2D_OK;
+    M2D_HIP_TRY(h, hipMemsetAsync(h->nonfinite_dev, 0, sizeof(int32_t), st));
+    const int64_t n[3] = {h->U * (int64_t)(h->C + 1) * h->E, h->I * (int64_t)h->E, (int64_t)h->C * h->E};
+    const float *t[3] = {h->pm, h->re, h->ce};
+    for (int i = 0; i < 3; ++i) {
+        int64_t blocks = (n[i] / 4 + 1023) / 1024;
+        if (blocks > (int64_t)h->num_cu * 8) blocks = (int64_t)h->num_cu * 8;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(m2d_scan_nonfinite, dim3((unsigned)blocks), dim3(256), 0, st, t[i], n[i], h->nonfinite_dev);
+    }
+    M2D_HIP_TRY(h, hipGetLastError());
+    h->finite_scan_pending = false;
+    return M2D_OK;
+}
+
+int m2d_launch_rows_finite_check(m2d_engine *h, const int32_t *users, int64_t B, hipStream_t st)
+{
+    if (B <= 0) return M2D_OK;
+    int64_t blocks = (B + 3) / 4;
+    if (blocks > (int64_t)h->num_cu * 8) blocks = (int64_t)h->num_cu * 8;
+    hipLaunchKernelGGL(m2d_rows_nonfinite, dim3((unsigned)blocks), dim3(256), 0, st, h->pm, users, B, h->U, h->user_base,
+                       (h->C + 1) * h->E, h->nonfinite_dev);
+    M2D_HIP_TRY(h, hipGetLastError());
+    return M2D_OK;
+}
+
 extern "C" {
 
 int m2d_abi_version(void) { return 2; }
@@ -143,12 +209,14 @@ int m2d_create(const float *pm, const float *re, const float *ce, int64_t U, int
         h->last_error = "m2d_create: device tables must be 16-byte aligned";
         return bail(M2D_ERR_INVALID_ARG);
     }
-    if (hipMalloc((void **)&h->err_dev, 4 * sizeof(int32_t)) != hipSuccess ||
-        hipMemset(h->err_dev, 0, 4 * sizeof(int32_t)) != hipSuccess ||
+    if (hipMalloc((void **)&h->err_dev, 8 * sizeof(int32_t)) != hipSuccess ||       // id-error latch [4] | non-finite word | pad
+        hipMemset(h->err_dev, 0, 8 * sizeof(int32_t)) != hipSuccess ||
         hipHostMalloc((void **)&h->err_host, 4 * sizeof(int32_t)) != hipSuccess) {
         h->last_error = "m2d_create: could not allocate the error latch";
         return bail(M2D_ERR_HIP);
     }
+    h->nonfinite_dev = h->err_dev + 4;
+    h->finite_scan_pending = true;      // the first scoring call scans the tables on its stream
     *out = h;
     return M2D_OK;
 }
@@ -603,6 +671,7 @@ int m2d_tables_updated(m2d_engine *h)
     h->dish_vec_valid = false;      // factored dish vectors (Recipe_Embedding, Category_Embedding)
     h->user_high_valid = false;     // <U_high, CE_c> (Personal_Memory, Category_Embedding)
     h->grp_valid = false;           // pattern-grouped retrieval tables (Recipe_Embedding)
+    h->finite_scan_pending = true;  // "every table value is finite" has to be established again
     return M2D_OK;
 }
 

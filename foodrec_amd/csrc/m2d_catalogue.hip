@@ -1710,12 +1710,16 @@ int ensure_grouped(m2d_engine *h, hipStream_t st)
     hipLaunchKernelGGL(m2d_grp_gather, dim3((unsigned)((cap_rows + 3) / 4)), dim3(256), 0, st, h->re, h->dish_high,
                        h->grp_perm, cap_rows, h->E, EW, h->grp_rs, reinterpret_cast<__bf16 *>(h->grp_rs16));
     M2D_HIP_TRY(h, hipGetLastError());
-    int32_t host[3] = {0, 0, 0};   // tiles, slots, flags  (a table build may synchronise)
+    int32_t host[4] = {0, 0, 0, 0};   // tiles, slots, flags, "a table value is not finite"  (a table build may synchronise)
     M2D_HIP_TRY(h, hipMemcpyAsync(host, grp + 16, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     M2D_HIP_TRY(h, hipMemcpyAsync(host + 2, flags, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    M2D_HIP_TRY(h, hipMemcpyAsync(host + 3, h->nonfinite_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     M2D_HIP_TRY(h, hipStreamSynchronize(st));
     h->grp_tiles = host[0];
     h->grp_binary = host[2] == 0;
+    // w_P = sum of the pattern's U_low rows leaves out the 0 * U_low[c] products of the other categories: with inf / NaN in
+    // a table those are NaN in the reference formula, and the dense kernel (which multiplies them) serves the call
+    h->grp_nonfinite = host[3] != 0;
     h->grp_valid = true;
     return M2D_OK;
 }
@@ -1905,6 +1909,7 @@ int m2d_launch_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32
                           int32_t *out_ids, hipStream_t stream)
 {
     int rc;
+    if ((rc = m2d_ensure_finite_scan(h, stream)) != M2D_OK) return rc;
     // 0/1 category masks, no ingredient table: contraction over E after sorting dishes by mask pattern
     // ("topk_grouped" = 0 keeps the dense kernel: dishes then arrive in id order whatever their masks, so exactly tied
     // scores of dishes with DIFFERENT mask patterns also resolve to the lower id -- see include/m2d.h)
@@ -1915,14 +1920,14 @@ int m2d_launch_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32
     if (h->C == 4 && (!h->dish_high || (hv_ok && !padded)) && k <= 16 && roww != 0 &&
         h->opt_topk_grouped != 0 && h->opt_variant != 7 && h->opt_variant != 8 && h->opt_variant != 9) {
         if ((rc = ensure_grouped(h, stream)) != M2D_OK) return rc;
-        if (hv_ok && h->grp_binary && h->grp_tiles > 0) {
+        if (hv_ok && h->grp_binary && h->grp_tiles > 0 && !h->grp_nonfinite) {
             if (h->E == 32)
                 return k <= 10 ? launch_grouped<8, 8, 10, true, true>(h, users, nU, k, out_scores, out_ids, stream)
                                : launch_grouped<8, 8, 16, true, true>(h, users, nU, k, out_scores, out_ids, stream);
             return k <= 10 ? launch_grouped<16, 8, 10, true, true>(h, users, nU, k, out_scores, out_ids, stream)
                            : launch_grouped<16, 8, 16, true, true>(h, users, nU, k, out_scores, out_ids, stream);
         }
-        if (!h->dish_high && h->grp_binary && h->grp_tiles > 0) {
+        if (!h->dish_high && h->grp_binary && h->grp_tiles > 0 && !h->grp_nonfinite) {
             // "topk_bf16x3" option: 1 = split-bf16 MFMA (E = 64 / 128), 0 = exact-f32 MFMA
             const bool x3 = h->opt_topk_bf16x3 != 0 && (h->E == 64 || h->E == 128);
 #define M2D_GRP(EV, X3)                                                                                       \

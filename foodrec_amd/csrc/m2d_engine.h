@@ -29,6 +29,15 @@ struct m2d_engine {
     int32_t *err_dev = nullptr;
     int32_t *err_host = nullptr;  // pinned
 
+    // "some value of Personal_Memory / Recipe_Embedding / Category_Embedding is not finite" (device word, sticky until the
+    // next full scan).  Model_Recommender.py:82-90 multiplies the row of a category a dish does not have by 0, and
+    // 0 * inf = NaN: every kernel that leaves such rows out (option skip_masked, the pattern-grouped forms) reads this
+    // word and fetches / multiplies everything when it is set.  Set by m2d_scan_tables (queued by m2d_create and
+    // m2d_tables_updated, run by the next scoring call on its stream) and by the engine's own writers (training step,
+    // Write_Memory) on the values they write.
+    int32_t *nonfinite_dev = nullptr;
+    bool finite_scan_pending = true;
+
     // build-defined extension: multi-hot ingredient table
     const float *ing = nullptr;        // [R, E]
     const int32_t *ing_off = nullptr;  // [I+1] CSR offsets per dish
@@ -68,6 +77,7 @@ struct m2d_engine {
     int64_t grp_tiles = 0, grp_cap_rows = 0;
     int grp_ew = 0;                     // row width of grp_rs: E, or 2 E with the ingredient extension ([H[d] | RE[d]])
     bool grp_valid = false, grp_binary = false;
+    bool grp_nonfinite = false;         // *nonfinite_dev as read when the tables were built (every writer invalidates them)
 
     // training step: optimizer slots and gradient scratch, created by m2d_train_begin
     m2d_train_state *train = nullptr;
@@ -136,6 +146,8 @@ static __device__ __forceinline__ void lds_dma16(const void *src, const void *ld
 int m2d_launch_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
                            bool by_dish, int64_t B, float *out, hipStream_t stream,
                            bool use_ingredients = false);
+int m2d_ensure_finite_scan(m2d_engine *h, hipStream_t stream);   // m2d_abi.hip: runs the queued table scan, if any
+int m2d_launch_rows_finite_check(m2d_engine *h, const int32_t *users, int64_t B, hipStream_t stream);   // Personal_Memory rows of a batch
 int m2d_launch_build_dish_high(m2d_engine *h, hipStream_t stream);
 int m2d_ensure_user_high(m2d_engine *h, hipStream_t stream);
 int m2d_launch_check_csr(m2d_engine *h, hipStream_t stream);

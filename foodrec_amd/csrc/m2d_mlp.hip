@@ -473,20 +473,29 @@ __global__ __launch_bounds__(256) void m2d_mlp_image_pc_w2(const float *w2, __bf
 // share of the W1 stream and their row requests.  So a launch first buckets its pairs by the dish's pattern of
 // non-zero weights (a histogram, a scan that pads every bucket to whole tiles, a scatter of pair indices) and the
 // kernel walks tiles of one pattern each; scores go back to out[pair].  With uniform non-empty subsets of 4
-// categories a tile runs (1 + 2.13) / 5 of the periods on average.  group = 0 (option skip_masked = 0, or blocks that
-// are not a power-of-two number of periods): one bucket, every block.
+// categories a tile runs (1 + 2.13) / 5 of the periods on average.  Without grouping (option skip_masked = 0, or blocks
+// that are not a power-of-two number of periods): the pairs as they come, every block.
 constexpr int PG_MAXPAT = 64;             // C <= 6: up to 7 blocks fit the nibbles of a word beside their count
 
-__device__ __forceinline__ int pg_pattern(const float *cats, int C, int64_t I, int32_t did, int group)
+// `group` points at the engine's "a table value is not finite" word: while it is set nothing is left out (0 * inf = NaN in
+// the literal z), every pair goes to the all-blocks bucket.  So does a dish whose weights sum to 0 or NaN: its dish-vector
+// blocks are (1 - a) m_c RE[d] / n = NaN even where m_c = 0 (with an ingredient table block 0 is finite, so the score
+// is not NaN for some other reason), and the ungrouped kernels return NaN for it.
+__device__ __forceinline__ int pg_pattern(const float *cats, int C, int64_t I, int32_t did, const int32_t *group)
 {
-    if (!group || did < 0 || (int64_t)did >= I) return (1 << C) - 1;      // bad ids: any bucket (the gatherer reports them)
+    if (*group != 0 || did < 0 || (int64_t)did >= I) return (1 << C) - 1;      // bad ids: any bucket (the gatherer reports them)
     int pat = 0;
-    for (int c = 0; c < C; ++c) pat |= (cats[(size_t)did * C + c] != 0.f ? 1 : 0) << c;
-    return pat;
+    float n = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float m = cats[(size_t)did * C + c];
+        n += m;
+        pat |= (m != 0.f ? 1 : 0) << c;
+    }
+    return (n == 0.f || n != n) ? (1 << C) - 1 : pat;
 }
 
 __global__ __launch_bounds__(256) void m2d_mlp_pg_hist(const int32_t *items, int64_t B, int64_t I, const float *cats, int C,
-                                                       int group, int32_t *hist)
+                                                       const int32_t *group, int32_t *hist)
 {
     // lane p of a wave counts pattern p in a register (one ballot + popcount per pattern and 64 pairs: no contended
     // atomics on a dozen addresses), then one LDS add and one global add per pattern and block
@@ -538,7 +547,7 @@ __global__ __launch_bounds__(256) void m2d_mlp_pg_scan(int32_t *hist, int C, uin
 
 // chunks of 4096 pairs: count per pattern in LDS, reserve each pattern's range with ONE global add per chunk, place
 __global__ __launch_bounds__(256) void m2d_mlp_pg_scatter(const int32_t *items, int64_t B, int64_t I, const float *cats, int C,
-                                                          int group, int32_t *cursor, int32_t *perm)
+                                                          const int32_t *group, int32_t *cursor, int32_t *perm)
 {
     __shared__ int32_t cnt[PG_MAXPAT], base[PG_MAXPAT];
     constexpr int CH = 4096;
@@ -1058,8 +1067,9 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
                                hipStream_t stream)
 {
     if (B == 0) return M2D_OK;
-    int rc = m2d_ensure_dish_vectors(h, stream);
+    int rc = m2d_ensure_finite_scan(h, stream);
     if (rc != M2D_OK) return rc;
+    if ((rc = m2d_ensure_dish_vectors(h, stream)) != M2D_OK) return rc;
     MlpArgs a;
     a.pm = h->pm; a.dt = h->dish_vec; a.w1 = h->mlp_w1; a.b1 = h->mlp_b1; a.w2 = h->mlp_w2; a.b2 = h->mlp_b2;
     a.w3 = h->mlp_w3; a.b3 = h->mlp_b3; a.users = users; a.items = items; a.out = out;
@@ -1113,10 +1123,10 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
             const unsigned gcap = (unsigned)h->num_cu * 8;
             const int64_t hb = (B + 255) / 256, sb = (B + 4095) / 4096;
             hipLaunchKernelGGL(m2d_mlp_pg_hist, dim3((unsigned)(hb < gcap ? hb : gcap)), dim3(256), 0, stream, items, B, h->I,
-                               h->dish_cats, h->C, 1, hist);
+                               h->dish_cats, h->C, h->nonfinite_dev, hist);
             hipLaunchKernelGGL(m2d_mlp_pg_scan, dim3(1), dim3(256), 0, stream, hist, h->C, tblocks, ntl);
             hipLaunchKernelGGL(m2d_mlp_pg_scatter, dim3((unsigned)(sb < gcap ? sb : gcap)), dim3(256), 0, stream, items, B, h->I,
-                               h->dish_cats, h->C, 1, hist, perm);
+                               h->dish_cats, h->C, h->nonfinite_dev, hist, perm);
             M2D_HIP_TRY(h, hipGetLastError());
             a.perm = perm; a.tile_blocks = tblocks; a.ntiles_dev = ntl;
         }

@@ -39,6 +39,7 @@ struct ScoreArgs {
     float b;
     int32_t *err;
     int32_t skip_masked;   // do not fetch the Personal_Memory rows of categories whose mask weight is 0 (their products are 0)
+    const int32_t *nonfinite;   // device word: some table value is inf / NaN -> 0 * row is not 0 (:82), every row is fetched
     const float *uh;       // [U, 4] derived table <U_high[u], CE_c> (m2d_build_user_high), or null: read U_high and multiply
 };
 
@@ -49,6 +50,13 @@ __device__ __forceinline__ void latch_error(int32_t *err, int code, int64_t valu
         err[2] = (int32_t)(index & 0xffffffff);
         err[3] = (int32_t)(index >> 32);
     }
+}
+
+// Rows of weight-0 categories may be left out only while every table value is finite: 0 * inf = NaN at
+// Model_Recommender.py:82-90.  One scalar load per wave (the word is set by the table scan / the engine's writers).
+__device__ __forceinline__ bool skip_rows(const ScoreArgs &p)
+{
+    return p.skip_masked != 0 && __builtin_amdgcn_readfirstlane(*p.nonfinite) == 0;
 }
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -100,6 +108,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
 
+    const bool skipm = skip_rows(p);
     const v4f *pm4 = reinterpret_cast<const v4f *>(p.pm);
     const v4f *re4 = reinterpret_cast<const v4f *>(p.re);
     const v4f *ce4 = reinterpret_cast<const v4f *>(p.ce);
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
         const int32_t ul32 = (int32_t)ul;
         // categories whose weight is exactly 0 contribute 0 * U_low[c] = 0 to :82-:90: their rows are not fetched
         // (a NaN weight compares unequal to 0 and keeps its row)
-        const int32_t act = p.skip_masked ? ((m.x != 0.f ? 1 : 0) | (m.y != 0.f ? 2 : 0) | (m.z != 0.f ? 4 : 0) | (m.w != 0.f ? 8 : 0)) : 15;
+        const int32_t act = skipm ? ((m.x != 0.f ? 1 : 0) | (m.y != 0.f ? 2 : 0) | (m.z != 0.f ? 4 : 0) | (m.w != 0.f ? 8 : 0)) : 15;
         // high-level part from the derived table: sum_c m_c <U_high, CE_c> (the U_high row is then not fetched at all)
         // (UH is its own instantiation: the literal kernel's code, and with it its bits, stay what they were)
         constexpr bool use_uh = UH && !HV;
@@ -260,6 +269,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4_small(ScoreArgs p)
     const v4f *ce4 = reinterpret_cast<const v4f *>(p.ce);
     const v4f *hv4 = reinterpret_cast<const v4f *>(p.hv);
     const size_t urow4 = (size_t)(C + 1) * E4;
+    const bool skipm = skip_rows(p);
     v4f cef[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -295,7 +305,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4_small(ScoreArgs p)
 #pragma unroll
         for (int r = 1; r <= C; ++r) {                     // a category of weight 0 contributes 0: its row is not fetched
             ub[r] = v4f{0.f, 0.f, 0.f, 0.f};
-            if (!p.skip_masked || mw[r - 1] != 0.f) ub[r] = pu[(size_t)r * E4];
+            if (!skipm || mw[r - 1] != 0.f) ub[r] = pu[(size_t)r * E4];
         }
         const v4f ib = re4[(size_t)did * E4 + jc];
         v4f hb = {0.f, 0.f, 0.f, 0.f};
@@ -353,6 +363,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_cn(ScoreArgs p)
     const v4f *re4 = reinterpret_cast<const v4f *>(p.re);
     const v4f *ce4 = reinterpret_cast<const v4f *>(p.ce);
     const size_t urow4 = (size_t)(C + 1) * E4;  // float4 per user block
+    const bool skipm = skip_rows(p);
 
     v4f cef[CM];
 #pragma unroll
@@ -390,7 +401,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_cn(ScoreArgs p)
                     if (valid) mk[c] = mrow[c];
                     n += mk[c];                                                // :77
                     // weight exactly 0: 0 * U_low[c] = 0 at :82-:90, the row is not fetched (a NaN weight keeps its row)
-                    act |= (!p.skip_masked || mk[c] != 0.f) ? (1 << c) : 0;
+                    act |= (!skipm || mk[c] != 0.f) ? (1 << c) : 0;
                 }
             }
         }
@@ -464,6 +475,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_generic(ScoreArgs p)
     const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int C = p.C, E = p.E;
+    const bool skipm = skip_rows(p);
     for (int64_t pi = wave0; pi < p.B; pi += nwaves) {
         int32_t uid = p.users[pi];
         int32_t did = p.items[pi];
@@ -486,7 +498,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_generic(ScoreArgs p)
         for (int c = 0; c < C; ++c) {
             const float mc = mrow[c];
             n += mc;
-            if (p.skip_masked && mc == 0.f) continue;      // 0 * row = 0: the row is not fetched
+            if (skipm && mc == 0.f) continue;      // 0 * row = 0: the row is not fetched
             for (int e = lane; e < E; e += 64) {
                 if (!p.hv) hs = fmaf(um[e], mc * p.ce[(size_t)c * E + e], hs);
                 ls = fmaf(it[e], mc * um[(size_t)(c + 1) * E + e], ls);
@@ -618,7 +630,12 @@ int m2d_launch_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *i
                            bool by_dish, int64_t B, float *out, hipStream_t stream, bool use_ingredients)
 {
     if (B == 0) return M2D_OK;
+    {
+        const int rc = m2d_ensure_finite_scan(h, stream);
+        if (rc != M2D_OK) return rc;
+    }
     ScoreArgs a;
+    a.nonfinite = h->nonfinite_dev;
     a.hv = use_ingredients ? h->dish_high : nullptr;
     a.pm = h->pm; a.re = h->re; a.ce = h->ce;
     a.users = users; a.items = items; a.cats = cats; a.out = out;

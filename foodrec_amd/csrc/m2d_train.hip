@@ -289,7 +289,8 @@ __device__ __forceinline__ void lane_set(float &v, int, float x) { v = x; }
 template <bool ALL, int VEC>
 __global__ __launch_bounds__(256) void m2d_train_apply(float *var, float *s0, float *s1, const float *G, const int32_t *map,
                                                        const int32_t *slot_row, const int32_t *count, int64_t R, int32_t W,
-                                                       const float *scal, RuleArgs r, const int32_t *err, const OptState *st)
+                                                       const float *scal, RuleArgs r, const int32_t *err, const OptState *st,
+                                                       int32_t *nonfinite)
 {
     typedef typename RowVec<VEC>::T vf;
     if (err[0] != 0) return;    // an id was out of range: like TF's InvalidArgumentError, the step applies nothing
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(256) void m2d_train_apply(float *var, float *s0, fl
     const float scale = scal[2];
     const int64_t n = ALL ? R : (int64_t)*count;
     const bool two = r.rule == M2D_LEARNER_ADAM || r.rule == M2D_LEARNER_RMSPROP, one = two || r.rule == M2D_LEARNER_ADAGRAD;
+    float fin = 0.f;                // x * 0 summed over the values written: NaN iff one of them is inf / NaN
     for (int64_t i = wave0; i < n; i += nwaves) {
         int64_t row, grow;
         if (ALL) { row = i; grow = map ? (int64_t)map[i] : i; }
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(256) void m2d_train_apply(float *var, float *s0, fl
             for (int j = 0; j < VEC; ++j) {
                 float vv = lane_get(v, j), aa = lane_get(a, j), bb = lane_get(b, j);
                 apply_one(r, lane_get(gg, j), vv, aa, bb);
+                fin = fmaf(vv, 0.f, fin);
                 lane_set(v, j, vv); lane_set(a, j, aa); lane_set(b, j, bb);
             }
             *reinterpret_cast<vf *>(var + base + e) = v;
@@ -327,6 +330,8 @@ __global__ __launch_bounds__(256) void m2d_train_apply(float *var, float *s0, fl
             if (two) *reinterpret_cast<vf *>(s1 + base + e) = b;
         }
     }
+    // a diverged run: the forward kernels stop leaving out the rows of weight-0 categories (0 * inf = NaN, :82)
+    if (fin != fin) *nonfinite = 1;
 }
 
 __global__ __launch_bounds__(256) void m2d_train_cleanup(int32_t *map, const int32_t *slot_row, const int32_t *count, float *G, int32_t W,
@@ -493,7 +498,7 @@ int m2d_launch_train_step(m2d_engine *h, const int32_t *users, const int32_t *it
         const bool v4 = tb.W % 4 == 0;
 #define M2D_APPLY(ALL, VEC)                                                                                               \
     hipLaunchKernelGGL((m2d_train_apply<ALL, VEC>), dim3(grid), dim3(256), 0, stream, tb.var, s0, s1, tb.G, tb.map, tb.slot_row, \
-                       tb.count, tb.R, tb.W, t->scal, r, h->err_dev, t->opt)
+                       tb.count, tb.R, tb.W, t->scal, r, h->err_dev, t->opt, h->nonfinite_dev)
         if (all) { if (v4) M2D_APPLY(true, 4); else M2D_APPLY(true, 1); }
         else { if (v4) M2D_APPLY(false, 4); else M2D_APPLY(false, 1); }
 #undef M2D_APPLY

@@ -196,6 +196,9 @@ int m2d_launch_write_memory(m2d_engine *h, const int32_t *users, const int32_t *
         if (which & M2D_WRITE_PERSONAL) {
             hipLaunchKernelGGL(m2d_write_memory_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
             M2D_HIP_TRY(h, hipGetLastError());
+            // the blocks just added into: an inf / NaN there ends the forward kernels' row skipping (0 * inf = NaN, :82)
+            const int rc = m2d_launch_rows_finite_check(h, users, B, stream);
+            if (rc != M2D_OK) return rc;
         }
         if (which & M2D_WRITE_GENERAL) {
             if (B <= 2048) {      // few pairs, all of them adding into the same L rows: owner-computes instead of atomics

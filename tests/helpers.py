@@ -25,6 +25,18 @@ def assert_scores_close(got, ref, tol=TOL, what=""):
     return float(err.max()) if err.size else 0.0
 
 
+def assert_scores_match_nonfinite(got, ref, tol=TOL, what=""):
+    """assert_scores_close for results that may hold +-inf as well (tables with inf in them): NaN at the same pairs, the
+    same infinities, the finite scores within the tolerance."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), "%s: NaN positions differ (%d vs %d)" % (what, np.isnan(got).sum(), np.isnan(ref).sum())
+    inf = np.isinf(ref)
+    assert np.array_equal(np.isinf(got), inf) and np.array_equal(got[inf], ref[inf]), "%s: infinities differ" % what
+    fin = np.isfinite(ref)
+    return assert_scores_close(got[fin], ref[fin], tol, what)
+
+
 def score_cases():
     return sorted(glob.glob(os.path.join(GOLDEN, "score_*.npz")))
 

@@ -8,7 +8,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from helpers import assert_scores_close, random_case, score_cases
+from helpers import assert_scores_close, assert_scores_match_nonfinite, random_case, score_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -253,8 +253,8 @@ def test_host_buffer_call_equals_the_device_op(torch_cuda, B, zero_copy):
 @pytest.mark.parametrize("E,B", [(64, 5000), (200, 700), (24, 300)])       # c4 kernel (full / partial groups) and the small-batch form
 def test_rows_of_weight_zero_categories_are_not_needed(E, B):
     """The Personal_Memory row of a category whose mask weight is 0 is multiplied by 0 (Model_Recommender.py:82): the
-    kernels do not fetch it (option skip_masked, default 1).  Same scores either way for finite tables; a non-finite
-    value in such a row is the one input on which the literal graph (0 * inf = NaN, option 0) and the default differ."""
+    kernels do not fetch it (option skip_masked, default 1) while every table value is finite.  Same scores either way
+    for finite tables; with a non-finite value in a table the rows are fetched whatever the option says."""
     import torch
     from foodrec_amd import ScoringEngine
     from oracle import m2d_oracle as oracle
@@ -270,16 +270,16 @@ def test_rows_of_weight_zero_categories_are_not_needed(E, B):
     off = eng.score_pairs(ut, it, ct).cpu().numpy(); eng.check()
     assert np.array_equal(on, off)                                          # the skipped terms are exact zeros
     assert_scores_close(on, oracle.inference_f64(PM, RE, CE, users, items, cats))
-    # poison the row of a category pair 0 does not have
+    # a non-finite value in the row of a category pair 0 does not have: 0 * inf = NaN in the graph (:82), and in the DEFAULT
+    # configuration here -- the table scan finds it and the kernels fetch every row (tests/test_gpu_nonfinite.py)
     c0 = int(np.flatnonzero(cats[0] == 0)[0]) if (cats[0] == 0).any() else None
     if c0 is not None:
         PM2 = PM.copy(); PM2[users[0], c0 + 1, :] = np.inf
         eng2 = ScoringEngine(PM2, RE, CE)
+        assert eng2.get_option("skip_masked") == 1
         got = eng2.score_pairs(ut[:1], it[:1], ct[:1]).cpu().numpy(); eng2.check()
-        assert got[0] == on[0]                                              # default: the row is never read
-        eng2.set_option("skip_masked", 0)
-        lit = eng2.score_pairs(ut[:1], it[:1], ct[:1]).cpu().numpy(); eng2.check()
-        assert np.isnan(lit[0]) and np.isnan(oracle.inference_f64(PM2, RE, CE, users[:1], items[:1], cats[:1])[0])
+        assert np.isnan(got[0]) and np.isnan(oracle.inference_f64(PM2, RE, CE, users[:1], items[:1], cats[:1])[0])
+        assert_scores_match_nonfinite(eng2.score_pairs(ut, it, ct).cpu().numpy(), oracle.inference_f64(PM2, RE, CE, users, items, cats))
 
 
 def test_user_high_table_option(torch_cuda):
