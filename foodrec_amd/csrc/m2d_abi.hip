@@ -1,6 +1,7 @@
 // extern "C" surface of libm2d.so -- see include/m2d.h for the contract and the reference
 // interfaces each entry point replaces.  No exceptions cross this boundary.
 #include <string.h>
+#include <time.h>
 
 #include <new>
 
@@ -129,6 +130,7 @@ void release(m2d_engine *h)
         if (h->ing_w) (void)hipFree((void *)h->ing_w);
     }
     if (h->scratch) (void)hipFree(h->scratch);
+    if (h->topk_flags) (void)hipFree(h->topk_flags);
     if (h->err_dev) (void)hipFree(h->err_dev);
     if (h->err_host) (void)hipHostFree(h->err_host);
 }
@@ -297,7 +299,9 @@ int ensure_stage(m2d_engine *h, size_t total, hipStream_t st)
     if (h->stage_dev) (void)hipFree(h->stage_dev);
     h->stage_host = h->stage_dev = nullptr; h->stage_bytes = 0;
     const size_t cap = total * 2;
-    M2D_HIP_TRY(h, hipHostMalloc((void **)&h->stage_host, cap, hipHostMallocDefault));
+    // the kernel writes scores, the id-error latch and the completion word into this block and the host polls the word:
+    // host-coherent (fine-grained) and mapped, stated rather than left to the runtime's default / HIP_HOST_COHERENT
+    M2D_HIP_TRY(h, hipHostMalloc((void **)&h->stage_host, cap, hipHostMallocCoherent | hipHostMallocMapped));
     M2D_HIP_TRY(h, hipMalloc((void **)&h->stage_dev, cap));
     h->stage_bytes = cap;
     return M2D_OK;
@@ -313,21 +317,35 @@ int score_pairs_host_chunked(m2d_engine *h, const int32_t *users, const int32_t 
     const int C = h->C;
     const size_t in_b = (size_t)HOST_CHUNK * C * 4 + 2 * (size_t)HOST_CHUNK * 4, out_b = (size_t)HOST_CHUNK * 4 + 16;
     const size_t blk = in_b + out_b;
-    int rc = ensure_stage(h, 2 * blk, st);
+    // an id error latched by an earlier, unchecked launch is reported as what it is -- with that call's position -- before
+    // anything of this feed is queued (the latch keeps the first error; a chunk's position arithmetic below must only
+    // ever see an error of its own chunk)
+    int rc = m2d_check(h, (void *)st, nullptr, nullptr);
     if (rc != M2D_OK) return rc;
+    if ((rc = ensure_stage(h, 2 * blk, st)) != M2D_OK) return rc;
+// a HIP error inside the loop: nothing may stay in flight on the two pinned blocks when the call returns
+#define M2D_CHUNK_TRY(expr)                                                                    \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            h->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                 \
+            (void)hipStreamSynchronize(st);                                                    \
+            return M2D_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
     for (hipEvent_t &e : h->stage_ev)
         if (!e) M2D_HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const int64_t nch = (B + HOST_CHUNK - 1) / HOST_CHUNK;
     auto retire = [&](int64_t k) -> int {
         unsigned char *hs = h->stage_host + (size_t)(k & 1) * blk;
-        M2D_HIP_TRY(h, hipEventSynchronize(h->stage_ev[k & 1]));
+        M2D_CHUNK_TRY(hipEventSynchronize(h->stage_ev[k & 1]));
         const int32_t *err = reinterpret_cast<const int32_t *>(hs + in_b + (size_t)HOST_CHUNK * 4);
         if (err[0] != 0) {
             // the kernel latched a position inside its chunk: put the position in the feed there before reporting it
             const int64_t idx = (((int64_t)(uint32_t)err[3] << 32) | (uint32_t)err[2]) + k * HOST_CHUNK;
             int32_t *fixed = reinterpret_cast<int32_t *>(hs);                   // pinned; the block is not in use any more
             fixed[0] = err[0]; fixed[1] = err[1]; fixed[2] = (int32_t)(idx & 0xffffffff); fixed[3] = (int32_t)(idx >> 32);
-            M2D_HIP_TRY(h, hipMemcpyAsync(h->err_dev, fixed, 16, hipMemcpyHostToDevice, st));
+            M2D_CHUNK_TRY(hipMemcpyAsync(h->err_dev, fixed, 16, hipMemcpyHostToDevice, st));
             return m2d_check(h, (void *)st, nullptr, nullptr);                  // synchronises, formats, clears the latch
         }
         const int64_t n = B - k * HOST_CHUNK < HOST_CHUNK ? B - k * HOST_CHUNK : HOST_CHUNK;
@@ -345,9 +363,9 @@ int score_pairs_host_chunked(m2d_engine *h, const int32_t *users, const int32_t 
         memcpy(hs, cats + o * C, (size_t)n * C * 4);
         memcpy(hs + o_u, users + o, (size_t)n * 4);
         memcpy(hs + o_i, items + o, (size_t)n * 4);
-        M2D_HIP_TRY(h, hipMemcpyAsync(ds, hs, (size_t)n * C * 4, hipMemcpyHostToDevice, st));
-        M2D_HIP_TRY(h, hipMemcpyAsync(ds + o_u, hs + o_u, (size_t)n * 4, hipMemcpyHostToDevice, st));
-        M2D_HIP_TRY(h, hipMemcpyAsync(ds + o_i, hs + o_i, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        M2D_CHUNK_TRY(hipMemcpyAsync(ds, hs, (size_t)n * C * 4, hipMemcpyHostToDevice, st));
+        M2D_CHUNK_TRY(hipMemcpyAsync(ds + o_u, hs + o_u, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        M2D_CHUNK_TRY(hipMemcpyAsync(ds + o_i, hs + o_i, (size_t)n * 4, hipMemcpyHostToDevice, st));
         rc = m2d_launch_score_pairs(h, reinterpret_cast<const int32_t *>(ds + o_u), reinterpret_cast<const int32_t *>(ds + o_i),
                                     reinterpret_cast<const float *>(ds), false, n, reinterpret_cast<float *>(ds + in_b), st);
         if (rc != M2D_OK) {
@@ -356,10 +374,10 @@ int score_pairs_host_chunked(m2d_engine *h, const int32_t *users, const int32_t 
         }
         hipLaunchKernelGGL(m2d_copy_latch, dim3(1), dim3(64), 0, st, h->err_dev,
                            reinterpret_cast<int32_t *>(ds + in_b + (size_t)HOST_CHUNK * 4), (int32_t *)nullptr, 0);
-        M2D_HIP_TRY(h, hipGetLastError());
-        M2D_HIP_TRY(h, hipMemcpyAsync(hs + in_b, ds + in_b, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-        M2D_HIP_TRY(h, hipMemcpyAsync(hs + in_b + (size_t)HOST_CHUNK * 4, ds + in_b + (size_t)HOST_CHUNK * 4, 16, hipMemcpyDeviceToHost, st));
-        M2D_HIP_TRY(h, hipEventRecord(h->stage_ev[k & 1], st));
+        M2D_CHUNK_TRY(hipGetLastError());
+        M2D_CHUNK_TRY(hipMemcpyAsync(hs + in_b, ds + in_b, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        M2D_CHUNK_TRY(hipMemcpyAsync(hs + in_b + (size_t)HOST_CHUNK * 4, ds + in_b + (size_t)HOST_CHUNK * 4, 16, hipMemcpyDeviceToHost, st));
+        M2D_CHUNK_TRY(hipEventRecord(h->stage_ev[k & 1], st));
     }
     for (int64_t k = nch >= 2 ? nch - 2 : 0; k < nch; ++k)
         if ((rc = retire(k)) != M2D_OK) {
@@ -367,6 +385,7 @@ int score_pairs_host_chunked(m2d_engine *h, const int32_t *users, const int32_t 
             return rc;
         }
     return M2D_OK;
+#undef M2D_CHUNK_TRY
 }
 }  // namespace
 
@@ -418,8 +437,17 @@ int m2d_score_pairs_host(m2d_engine *h, const int32_t *users, const int32_t *ite
     if (ws == ds) M2D_HIP_TRY(h, hipMemcpyAsync(hs + in_bytes, ds + in_bytes, out_bytes, hipMemcpyDeviceToHost, st));
     bool seen = false;
     if (poll) {
-        // spin on the completion word for a while (a stream synchronisation costs more than the two kernels)
-        for (int spin = 0; spin < 200000 && !seen; ++spin) seen = __atomic_load_n(const_cast<const int32_t *>(done_host), __ATOMIC_ACQUIRE) == ticket;
+        // spin on the completion word (a stream synchronisation costs more than the two kernels), for at most 250 us of
+        // wall time -- a 65 536-pair feed, the largest that takes this path, is done in ~0.1 ms -- then wait on the stream
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (;;) {
+            for (int spin = 0; spin < 256 && !seen; ++spin)
+                seen = __atomic_load_n(const_cast<const int32_t *>(done_host), __ATOMIC_ACQUIRE) == ticket;
+            if (seen) break;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 250000ll) break;
+        }
     }
     if (!seen) M2D_HIP_TRY(h, hipStreamSynchronize(st));
     const int32_t *err = reinterpret_cast<const int32_t *>(hs + in_bytes + nb * 4);

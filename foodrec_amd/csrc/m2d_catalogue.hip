@@ -158,6 +158,17 @@ __device__ __forceinline__ void sorted_insert_inplace(float (&ls)[N], int32_t (&
     sorted_insert_range<N, 0, N>(ls, li, x, id);
 }
 
+// Tie bookkeeping of the pattern-grouped kernels.  Their lists keep equal scores in SCAN order (mask pattern, row-norm
+// bucket, dish id), heapq.nlargest keeps them in id order (evaluate.py:63).  Which dishes are in a list differs between
+// the two only when a score that fell off the end of a list -- or was refused at its end -- EQUALS the list's new last
+// entry; that is noticed here (two VALU per insertion, candidate path only), the user is flagged, and
+// m2d_topk_repair_ties re-ranks flagged users in id order.  Ties that stay inside a list are put into id order when the
+// list is finished (m2d_topk_fill_absent).  Thresholds are compared with >= so that an equal score is a candidate.
+__device__ __forceinline__ bool tie_at_boundary(float x, float old_last, float new_last)
+{
+    return fminf(x, old_last) == new_last && new_last > -INFINITY;
+}
+
 // NB = K / 8: float4 registers of the user operand per lane.  One stage = 32 dishes x KC floats.
 // KR > 0: the lane's running list (KR >= k slots) lives in REGISTERS and an insertion is a branch-free
 // compare-exchange sweep (about 8*KR VALU ops, no LDS latency chain), so every wave reaches the
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(256) void m2d_topk_generic(TopkArgs p, int K)
 // wins, which keeps ties in ascending-id order.
 template <int LPU>
 __global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k,
-                                                             float *out_scores, int32_t *out_ids)
+                                                             float *out_scores, int32_t *out_ids, int32_t *tie_flags, int64_t flag_div)
 {
     const int lane = threadIdx.x & 63, w = lane & (LPU - 1);
     const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPU;
@@ -484,6 +495,8 @@ __global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, co
     int ptr = 0;
     float hs = live ? s[0] : 0.f;
     int32_t hi = live ? id[0] : -1;                          // -1: this list is exhausted (or the lane is idle)
+    float last = 0.f;
+    int32_t last_i = -1;
     for (int o = 0; o < k; ++o) {                           // wave-uniform trip count: the shuffles see a full EXEC
         float bs = hs;
         int32_t bi = hi;
@@ -506,7 +519,12 @@ __global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, co
             hi = ptr < k ? id[ptr] : -1;
             hs = ptr < k ? s[ptr] : 0.f;
         }
+        last = bs;
+        last_i = bi;
     }
+    // the cut: a score left at the head of some split's list equals the last one taken -- which of the tied dishes made
+    // the list was decided by split order (scan order of the pattern-grouped kernels), not by dish id
+    if (tie_flags && live && last_i >= 0 && hi >= 0 && hs == last) atomicOr(&tie_flags[u / flag_div], 1);
 }
 
 // Users with fewer than k ranked dishes (every finite-scored dish is already in their list, the rest of the
@@ -520,6 +538,15 @@ __global__ void m2d_topk_fill_absent(float *scores, int32_t *ids, int64_t nU, in
     int32_t *id = ids + u * k;
     int n = 0;
     while (n < k && id[n] >= 0) ++n;
+    // bit-equal scores inside the list: ascending dish id, as heapq.nlargest leaves them (evaluate.py:63); the
+    // pattern-grouped kernels deliver them in scan order
+    for (int q = 1; q < n; ++q) {
+        for (int r = q; r > 0 && s[r - 1] == s[r] && id[r - 1] > id[r]; --r) {
+            const int32_t t = id[r - 1];
+            id[r - 1] = id[r];
+            id[r] = t;
+        }
+    }
     for (int64_t d = 0; n < k && d < I; ++d) {
         bool present = false;
         for (int q = 0; q < n; ++q) present = present || (id[q] == (int32_t)d);
@@ -527,6 +554,98 @@ __global__ void m2d_topk_fill_absent(float *scores, int32_t *ids, int64_t nU, in
             id[n] = (int32_t)d;
             s[n] = __builtin_nanf("");
             ++n;
+        }
+    }
+}
+
+// Flagged users (a tie at a list boundary of a pattern-grouped kernel, see tie_at_boundary): the whole catalogue again
+// in dish-id order with the reference formula in plain f32 -- Model_Recommender.py:67-96 term by term, as the pair
+// kernels compute it -- and a strict insertion, so equal scores keep the lower id exactly as heapq.nlargest does.
+// One block per flagged user (blocks walk the user list and look at the flags: no compaction, nothing to do is the
+// common case), a thread takes every 256th dish and keeps its own top-k in LDS, the 256 lists are merged by k rounds
+// of a block-wide argmax on (score desc, id asc).  Rare by construction -- an all-zero Personal_Memory block, rows
+// that score whole groups identically -- so it is written for clarity, not speed (100 k dishes, E = 64: ~0.1 ms a user).
+struct RepairArgs {
+    const float *pm, *re, *ce, *cats, *hv;      // hv: per-dish high-level vectors of the ingredient extension, or null
+    const int32_t *users;
+    const int32_t *flags;
+    int64_t nU, U, I, user_base;
+    int32_t C, E, k;
+    float a, b;
+    float *out_scores;                          // [nU, k]
+    int32_t *out_ids;
+};
+
+__global__ __launch_bounds__(256) void m2d_topk_repair_ties(RepairArgs p)
+{
+    extern __shared__ __align__(16) float rsm[];
+    const int C = p.C, E = p.E, k = p.k, W = (C + 1) * E;
+    float *um = rsm;                                        // [(C+1) E] this user's block
+    float *cem = um + W;                                    // [C E]
+    float *ls = cem + C * E;                                // [256][k] scores
+    int32_t *li = reinterpret_cast<int32_t *>(ls + 256 * k);
+    __shared__ float red_s[4];
+    __shared__ int32_t red_i[4], red_t[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i < C * E; i += 256) cem[i] = p.ce[i];
+    for (int64_t u = blockIdx.x; u < p.nU; u += gridDim.x) {
+        if (p.flags[u] == 0) continue;                      // block-uniform
+        int64_t ul = (int64_t)p.users[u] - p.user_base;
+        if (ul < 0 || ul >= p.U) ul = 0;                    // latched by the scan kernel
+        __syncthreads();
+        for (int i = t; i < W; i += 256) um[i] = p.pm[(size_t)ul * W + i];
+        float *ms = ls + (size_t)t * k;
+        int32_t *mi = li + (size_t)t * k;
+        for (int i = 0; i < k; ++i) { ms[i] = -INFINITY; mi[i] = -1; }
+        __syncthreads();
+        for (int64_t d = t; d < p.I; d += 256) {
+            const float *m = p.cats + (size_t)d * C;
+            const float *it = p.re + (size_t)d * E;
+            float n = 0.f, hs = 0.f, lo = 0.f;
+            for (int c = 0; c < C; ++c) n += m[c];                                   // :77
+            for (int c = 0; c < C; ++c) {
+                const float mc = m[c];
+                for (int e = 0; e < E; ++e) {
+                    if (!p.hv) hs = fmaf(um[e], mc * cem[c * E + e], hs);             // :67-75
+                    lo = fmaf(it[e], mc * um[(c + 1) * E + e], lo);                   // :82-90
+                }
+            }
+            if (p.hv)
+                for (int e = 0; e < E; ++e) hs = fmaf(um[e], p.hv[(size_t)d * E + e], hs);
+            const float sc = __fadd_rn(__fmul_rn(p.a, p.hv ? hs : hs / n), __fmul_rn(p.b, lo / n));   // :79, :92, :95-96
+            if (sc > ms[k - 1]) {                           // strict, dishes in ascending id: ties keep the lower id (NaN never enters)
+                int pos = k - 1;
+                while (pos > 0 && sc > ms[pos - 1]) { ms[pos] = ms[pos - 1]; mi[pos] = mi[pos - 1]; --pos; }
+                ms[pos] = sc;
+                mi[pos] = (int32_t)d;
+            }
+        }
+        __syncthreads();
+        int ptr = 0;
+        for (int o = 0; o < k; ++o) {
+            float bs = ptr < k ? ms[ptr] : -INFINITY;
+            int32_t bi = ptr < k ? mi[ptr] : -1;
+            int bt = t;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float os = __shfl_xor(bs, off, 64);
+                const int32_t oi = __shfl_xor(bi, off, 64);
+                const int ot = __shfl_xor(bt, off, 64);
+                if (oi >= 0 && (bi < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; bt = ot; }
+            }
+            if (lane == 0) { red_s[wave] = bs; red_i[wave] = bi; red_t[wave] = bt; }
+            __syncthreads();
+            float fs = red_s[0];
+            int32_t fi = red_i[0];
+            int ft = red_t[0];
+            for (int w = 1; w < 4; ++w)
+                if (red_i[w] >= 0 && (fi < 0 || red_s[w] > fs || (red_s[w] == fs && red_i[w] < fi))) { fs = red_s[w]; fi = red_i[w]; ft = red_t[w]; }
+            if (t == 0) {
+                p.out_scores[u * k + o] = fi >= 0 ? fs : __builtin_nanf("");
+                p.out_ids[u * k + o] = fi;
+            }
+            if (fi >= 0 && ft == t) ++ptr;
+            __syncthreads();
         }
     }
 }
@@ -767,7 +886,59 @@ struct GroupedArgs {
     int32_t *err;
     unsigned long long *dbg;   // scripts/diag only
     int32_t e_real;            // padded form only: the tables' E (rows of `rs` are zero-padded to the kernel's E)
+    int32_t *tie_flags;        // [nU] set when a user's list met a tie at its boundary (see tie_at_boundary)
 };
+
+// End of a pattern-grouped scan: the lane's register list goes to LDS with its slots translated to dish ids, the two
+// lanes of a user (l, l + 32) are merged into this split's sorted list of k, and the user is flagged when the lists met
+// a tie at a boundary -- inside a lane (tie_mask) or where the merge cuts (a score left behind equals the last one taken).
+template <int KR>
+__device__ __forceinline__ void grouped_publish(float *ls, int32_t *li, const float (&rs)[KR], const int32_t (&ri)[KR],
+                                                const GroupedArgs &p, const int lane, const int64_t uidx, const bool uvalid,
+                                                const unsigned long long tie_mask)
+{
+    const int j = lane & 31, h = lane >> 5, k = p.k;
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+        ls[i * 64 + lane] = rs[i];
+        li[i * 64 + lane] = ri[i] >= 0 ? p.perm[ri[i]] : -1;
+        cnt += ri[i] >= 0 ? 1 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int cnt_hi = __shfl(cnt, j + 32, 64);
+    bool tie = ((tie_mask >> lane) & 1ull) != 0ull;
+    if (h == 0 && uvalid) {
+        const int ca = cnt, cb = cnt_hi;
+        int pa = 0, pb = 0;
+        float *os = p.out_scores + ((size_t)uidx * p.nsplit + blockIdx.y) * k;
+        int32_t *oi = p.out_ids + ((size_t)uidx * p.nsplit + blockIdx.y) * k;
+        float last = 0.f;
+        bool full = true;
+        for (int o = 0; o < k; ++o) {
+            const bool ha = pa < ca, hb = pb < cb;
+            if (!ha && !hb) {
+                os[o] = __builtin_nanf("");
+                oi[o] = -1;
+                full = false;
+                continue;
+            }
+            const float sa = ha ? ls[pa * 64 + lane] : 0.f, sb = hb ? ls[pb * 64 + lane + 32] : 0.f;
+            const int32_t ia = ha ? li[pa * 64 + lane] : 0, ib = hb ? li[pb * 64 + lane + 32] : 0;
+            bool take_a;
+            if (!hb) take_a = true;
+            else if (!ha) take_a = false;
+            else take_a = sa > sb || (sa == sb && ia < ib);
+            os[o] = last = take_a ? sa : sb;
+            oi[o] = take_a ? ia : ib;
+            pa += take_a ? 1 : 0;
+            pb += take_a ? 0 : 1;
+        }
+        if (full && ((pa < ca && ls[pa * 64 + lane] == last) || (pb < cb && ls[pb * 64 + lane + 32] == last))) tie = true;
+    }
+    if (tie && uvalid) atomicOr(&p.tie_flags[uidx], 1);
+}
 
 constexpr int grouped_tiles_per_stage(int E) { return E <= 32 ? 16 : (E == 64 ? 8 : (E == 128 ? 4 : 2)); }   // 64 KiB stages
 
@@ -856,6 +1027,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
     __syncthreads();
 
     v16f acc;
+    unsigned long long tie_mask = 0ull;                    // lanes whose list met a tie at its boundary
     for (int64_t s = 0; s < nstages; ++s) {
         const int buf = (int)(s & 1);
         if (s + 1 < nstages) issue_stage(s + 1, buf ^ 1);
@@ -913,14 +1085,16 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
 #pragma unroll
             for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
             mx = fmaxf(mx, acc[15]);
-            if (!__any(mx > thr)) continue;
+            if (!__any(mx >= thr)) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = acc[r];
-                const bool cand = v > thr;
+                const bool cand = v >= thr;
                 if (__any(cand)) {
+                    const float old_last = rs[KR - 1];
                     sorted_insert<KR>(rs, ri, v, sbase + (r & 3) + 8 * (r >> 2));
                     thr = rs[KR - 1];
+                    tie_mask |= __ballot(tie_at_boundary(v, old_last, thr));
                 }
             }
         }
@@ -931,40 +1105,8 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
     // ---- publish (slot -> dish id), merge the two lanes of each user -------------------------------------
     float *ls = smem + (size_t)wave * 2 * KR * 64;       // aliases stage 0: every wave is past the last barrier
     int32_t *li = reinterpret_cast<int32_t *>(ls + (size_t)KR * 64);
-    int cnt = 0;
-#pragma unroll
-    for (int i = 0; i < KR; ++i) {
-        ls[i * 64 + lane] = rs[i];
-        li[i * 64 + lane] = ri[i] >= 0 ? p.perm[ri[i]] : -1;
-        cnt += ri[i] >= 0 ? 1 : 0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int cnt_hi = __shfl(cnt, j + 32, 64);
-    if (h == 0 && uvalid) {
-        const int ca = cnt, cb = cnt_hi;
-        int pa = 0, pb = 0;
-        float *os = p.out_scores + ((size_t)uidx * p.nsplit + blockIdx.y) * k;
-        int32_t *oi = p.out_ids + ((size_t)uidx * p.nsplit + blockIdx.y) * k;
-        for (int o = 0; o < k; ++o) {
-            const bool ha = pa < ca, hb = pb < cb;
-            if (!ha && !hb) {
-                os[o] = __builtin_nanf("");
-                oi[o] = -1;
-                continue;
-            }
-            const float sa = ha ? ls[pa * 64 + lane] : 0.f, sb = hb ? ls[pb * 64 + lane + 32] : 0.f;
-            const int32_t ia = ha ? li[pa * 64 + lane] : 0, ib = hb ? li[pb * 64 + lane + 32] : 0;
-            bool take_a;
-            if (!hb) take_a = true;
-            else if (!ha) take_a = false;
-            else take_a = sa > sb || (sa == sb && ia < ib);
-            os[o] = take_a ? sa : sb;
-            oi[o] = take_a ? ia : ib;
-            pa += take_a ? 1 : 0;
-            pb += take_a ? 0 : 1;
-        }
-    }
+    grouped_publish<KR>(ls, li, rs, ri, p, lane, uidx, uvalid, tie_mask);
+    (void)k;
 }
 
 // ---- split-bf16 ("bf16x3") variant of m2d_topk_grouped ---------------------------------------------------
@@ -1059,6 +1201,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
 
     const int key = (j / RPB) & (S8 - 1);                  // this lane's row swizzle (same for hi and lo rows)
     v16f acc;
+    unsigned long long tie_mask = 0ull;                    // lanes whose list met a tie at its boundary
 #if M2D_DIAG & 16
     unsigned long long t_mfma = 0, t_epi = 0, t_bar = 0, t_slow = 0, n_slow = 0, n_tile = 0, t0_, t1_;
     STAMP(t0_);
@@ -1139,7 +1282,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
             unsigned long long m[16], any_mask = 0ull;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                m[r] = __ballot(acc[r] > thr);
+                m[r] = __ballot(acc[r] >= thr);
                 any_mask |= m[r];
             }
             if (any_mask == 0ull) {
@@ -1150,7 +1293,11 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (m[r] != 0ull) sorted_insert<KR>(rs, ri, acc[r], sbase + (r & 3) + 8 * (r >> 2));
+                if (m[r] != 0ull) {
+                    const float old_last = rs[KR - 1];
+                    sorted_insert<KR>(rs, ri, acc[r], sbase + (r & 3) + 8 * (r >> 2));
+                    tie_mask |= __ballot(tie_at_boundary(acc[r], old_last, rs[KR - 1]));
+                }
             }
             thr = rs[KR - 1];
 #if M2D_DIAG & 16
@@ -1172,40 +1319,8 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
 
     float *ls = reinterpret_cast<float *>(smem8) + (size_t)wave * 2 * KR * 64;   // aliases stage 0
     int32_t *li = reinterpret_cast<int32_t *>(ls + (size_t)KR * 64);
-    int cnt = 0;
-#pragma unroll
-    for (int i = 0; i < KR; ++i) {
-        ls[i * 64 + lane] = rs[i];
-        li[i * 64 + lane] = ri[i] >= 0 ? p.perm[ri[i]] : -1;
-        cnt += ri[i] >= 0 ? 1 : 0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int cnt_hi = __shfl(cnt, j + 32, 64);
-    if (h == 0 && uvalid) {
-        const int ca = cnt, cb = cnt_hi;
-        int pa = 0, pb = 0;
-        float *os = p.out_scores + ((size_t)uidx * p.nsplit + blockIdx.y) * k;
-        int32_t *oi = p.out_ids + ((size_t)uidx * p.nsplit + blockIdx.y) * k;
-        for (int o = 0; o < k; ++o) {
-            const bool ha = pa < ca, hb = pb < cb;
-            if (!ha && !hb) {
-                os[o] = __builtin_nanf("");
-                oi[o] = -1;
-                continue;
-            }
-            const float sa = ha ? ls[pa * 64 + lane] : 0.f, sb = hb ? ls[pb * 64 + lane + 32] : 0.f;
-            const int32_t ia = ha ? li[pa * 64 + lane] : 0, ib = hb ? li[pb * 64 + lane + 32] : 0;
-            bool take_a;
-            if (!hb) take_a = true;
-            else if (!ha) take_a = false;
-            else take_a = sa > sb || (sa == sb && ia < ib);
-            os[o] = take_a ? sa : sb;
-            oi[o] = take_a ? ia : ib;
-            pa += take_a ? 1 : 0;
-            pb += take_a ? 0 : 1;
-        }
-    }
+    grouped_publish<KR>(ls, li, rs, ri, p, lane, uidx, uvalid, tie_mask);
+    (void)k;
 }
 
 // ---- pipelined form of m2d_topk_grouped_bf16: constant-shape steps, insertions under the MFMAs ------------------
@@ -1327,6 +1442,9 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         alpha[g] = alpha_prev[g] = 0.f;
     }
     bool pend = false;                                     // wave-uniform: some (px, pid) waits to be inserted
+    unsigned long long tie_mask[G];                        // lanes whose list met a tie at its boundary (tie_at_boundary)
+#pragma unroll
+    for (int g = 0; g < G; ++g) tie_mask[g] = 0ull;
 
     const int64_t per = (p.tiles + p.nsplit - 1) / p.nsplit;
     const int64_t t_begin = (int64_t)blockIdx.y * per;
@@ -1416,11 +1534,12 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     auto body = [&](auto ins_tag, v16f (&accN)[G], const v16f (&accP)[G], const int img_prev, const int img_off,
                     const float (&thr_rel)[G], unsigned long long (&m)[G][16], float (&mx)[G]) __attribute__((always_inline)) {
         constexpr bool INS = decltype(ins_tag)::value;
-        float x[G];
+        float x[G], old_last[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             x[g] = fmaxf(px[g], -INFINITY);
             mx[g] = -INFINITY;
+            old_last[g] = rs[g][KR - 1];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1440,7 +1559,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
             for (int g = 0; g < G; ++g) {
 #pragma unroll
                 for (int r = ks * RPK; r < (ks + 1) * RPK; ++r) {
-                    m[g][r] = __ballot(accP[g][r] > thr_rel[g]);       // one v_cmp into an SGPR pair; folded into a
+                    m[g][r] = __ballot(accP[g][r] >= thr_rel[g]);      // one v_cmp into an SGPR pair; folded into a
                     mx[g] = fmaxf(mx[g], accP[g][r]);                  // per-lane row map only if some lane has a candidate
                 }
                 if constexpr (INS) {
@@ -1457,7 +1576,10 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         }
         if constexpr (INS) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) share_threshold(g);
+            for (int g = 0; g < G; ++g) {
+                tie_mask[g] |= __ballot(tie_at_boundary(x[g], old_last[g], rs[g][KR - 1]));
+                share_threshold(g);
+            }
         }
     };
 
@@ -1551,7 +1673,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         }
         unsigned long long anyc = 0ull;
 #pragma unroll
-        for (int g = 0; g < G; ++g) anyc |= __ballot(mx[g] > thr_rel[g]);
+        for (int g = 0; g < G; ++g) anyc |= __ballot(mx[g] >= thr_rel[g]);
 #if M2D_DIAG & 16
         STAMP(t1_); t_body += t1_ - t0_; t0_ = t1_; ++n_step;
 #endif
@@ -1580,8 +1702,11 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
                 for (int g = 0; g < G; ++g) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        if (m[g][r] != 0ull)
-                            sorted_insert_inplace<KR>(rs[g], ri[g], accP[g][r] + alpha_prev[g], sbase + (r & 3) + 8 * (r >> 2));
+                        if (m[g][r] != 0ull) {
+                            const float ol = rs[g][KR - 1], xv = accP[g][r] + alpha_prev[g];
+                            sorted_insert_inplace<KR>(rs[g], ri[g], xv, sbase + (r & 3) + 8 * (r >> 2));
+                            tie_mask[g] |= __ballot(tie_at_boundary(xv, ol, rs[g][KR - 1]));
+                        }
                     }
                     share_threshold(g);
                 }
@@ -1611,7 +1736,11 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     }
     if (pend) {                                            // the last parked candidates
 #pragma unroll
-        for (int g = 0; g < G; ++g) sorted_insert_inplace<KR>(rs[g], ri[g], px[g], pid[g]);
+        for (int g = 0; g < G; ++g) {
+            const float ol = rs[g][KR - 1];
+            sorted_insert_inplace<KR>(rs[g], ri[g], px[g], pid[g]);
+            tie_mask[g] |= __ballot(tie_at_boundary(px[g], ol, rs[g][KR - 1]));
+        }
     }
     wait_all_vmem();                                       // no LDS-DMA may land after the lists are published below
     __syncthreads();
@@ -1627,41 +1756,9 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     for (int g = 0; g < G; ++g) {
         float *ls = reinterpret_cast<float *>(smem8) + (size_t)(wave * G + g) * 2 * KR * 64;   // aliases stage 0
         int32_t *li = reinterpret_cast<int32_t *>(ls + (size_t)KR * 64);
-        int cnt = 0;
-#pragma unroll
-        for (int i = 0; i < KR; ++i) {
-            ls[i * 64 + lane] = rs[g][i];
-            li[i * 64 + lane] = ri[g][i] >= 0 ? p.perm[ri[g][i]] : -1;
-            cnt += ri[g][i] >= 0 ? 1 : 0;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int cnt_hi = __shfl(cnt, j + 32, 64);
-        if (h == 0 && uvalid[g]) {
-            const int ca = cnt, cb = cnt_hi;
-            int pa = 0, pb = 0;
-            float *os = p.out_scores + ((size_t)uidx[g] * p.nsplit + blockIdx.y) * k;
-            int32_t *oi = p.out_ids + ((size_t)uidx[g] * p.nsplit + blockIdx.y) * k;
-            for (int o = 0; o < k; ++o) {
-                const bool ha = pa < ca, hb = pb < cb;
-                if (!ha && !hb) {
-                    os[o] = __builtin_nanf("");
-                    oi[o] = -1;
-                    continue;
-                }
-                const float sa = ha ? ls[pa * 64 + lane] : 0.f, sb = hb ? ls[pb * 64 + lane + 32] : 0.f;
-                const int32_t ia = ha ? li[pa * 64 + lane] : 0, ib = hb ? li[pb * 64 + lane + 32] : 0;
-                bool take_a;
-                if (!hb) take_a = true;
-                else if (!ha) take_a = false;
-                else take_a = sa > sb || (sa == sb && ia < ib);
-                os[o] = take_a ? sa : sb;
-                oi[o] = take_a ? ia : ib;
-                pa += take_a ? 1 : 0;
-                pb += take_a ? 0 : 1;
-            }
-        }
+        grouped_publish<KR>(ls, li, rs[g], ri[g], p, lane, uidx[g], uvalid[g], tie_mask[g]);
     }
+    (void)k;
 }
 
 // row width of the sorted dish table: E itself where a kernel is instantiated for it, else the next such width
@@ -1725,12 +1822,12 @@ int ensure_grouped(m2d_engine *h, hipStream_t st)
 }
 
 void m2d_launch_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k, float *out_s, int32_t *out_i,
-                             hipStream_t st)
+                             hipStream_t st, int32_t *tie_flags = nullptr, int64_t flag_div = 1)
 {
     int lpu = 1;
     while (lpu < nsplit) lpu <<= 1;
     const unsigned grid = (unsigned)((nU * lpu + 255) / 256);
-#define M2D_MERGE(L) if (lpu == L) hipLaunchKernelGGL(m2d_topk_merge_splits<L>, dim3(grid), dim3(256), 0, st, ps, pi, nU, nsplit, k, out_s, out_i);
+#define M2D_MERGE(L) if (lpu == L) hipLaunchKernelGGL(m2d_topk_merge_splits<L>, dim3(grid), dim3(256), 0, st, ps, pi, nU, nsplit, k, out_s, out_i, tie_flags, flag_div);
     M2D_MERGE(1) M2D_MERGE(2) M2D_MERGE(4) M2D_MERGE(8) M2D_MERGE(16) M2D_MERGE(32) M2D_MERGE(64)
 #undef M2D_MERGE
 }
@@ -1740,15 +1837,15 @@ void m2d_launch_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int
 // tmp_s / tmp_i hold nU * (nsplit / 64) * k entries.  Consecutive groups are consecutive dish ranges, so the
 // lower-split-wins tie rule carries through both passes.
 void m2d_launch_merge_splits2(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k, float *tmp_s, int32_t *tmp_i,
-                              float *out_s, int32_t *out_i, hipStream_t st)
+                              float *out_s, int32_t *out_i, hipStream_t st, int32_t *tie_flags)
 {
     if (nsplit <= 64) {
-        m2d_launch_merge_splits(ps, pi, nU, nsplit, k, out_s, out_i, st);
+        m2d_launch_merge_splits(ps, pi, nU, nsplit, k, out_s, out_i, st, tie_flags, 1);
         return;
     }
     const int G = nsplit / 64;
-    m2d_launch_merge_splits(ps, pi, nU * G, 64, k, tmp_s, tmp_i, st);
-    m2d_launch_merge_splits(tmp_s, tmp_i, nU, G, k, out_s, out_i, st);
+    m2d_launch_merge_splits(ps, pi, nU * G, 64, k, tmp_s, tmp_i, st, tie_flags, G);      // a "user" of this pass is (user, group)
+    m2d_launch_merge_splits(tmp_s, tmp_i, nU, G, k, out_s, out_i, st, tie_flags, 1);
 }
 
 // shared tail of every MFMA retrieval launch: dish-range splits -> partial lists in scratch.  The grouped kernels run
@@ -1796,6 +1893,14 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     a.grp = h->grp_work + (size_t)((h->I + 255) / 256) * GRP_KEYS;
     a.users = users; a.nU = nU; a.U = h->U; a.user_base = h->user_base; a.k = k; a.tiles = h->grp_tiles;
     a.a = h->a; a.b = h->b; a.err = h->err_dev; a.dbg = g_m2d_diag_buffer; a.e_real = h->E;
+    if (h->topk_flags_cap < (size_t)nU) {
+        if (h->topk_flags) M2D_HIP_TRY(h, hipFree(h->topk_flags));
+        h->topk_flags = nullptr; h->topk_flags_cap = 0;
+        M2D_HIP_TRY(h, hipMalloc((void **)&h->topk_flags, (size_t)nU * sizeof(int32_t)));
+        h->topk_flags_cap = (size_t)nU;
+    }
+    M2D_HIP_TRY(h, hipMemsetAsync(h->topk_flags, 0, (size_t)nU * sizeof(int32_t), st));
+    a.tie_flags = h->topk_flags;
     const int64_t ublocks = (nU + 32 * WAVES - 1) / (32 * WAVES);
     const int nsplit = pick_splits(h, ublocks, a.tiles, 2 * TPS, 512);
     a.nsplit = nsplit;
@@ -1841,7 +1946,18 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     }
     M2D_HIP_TRY(h, hipGetLastError());
     if (nsplit > 1) {
-        m2d_launch_merge_splits2(a.out_scores, a.out_ids, nU, nsplit, k, tmp_s, tmp_i, final_s, final_i, st);
+        m2d_launch_merge_splits2(a.out_scores, a.out_ids, nU, nsplit, k, tmp_s, tmp_i, final_s, final_i, st, h->topk_flags);
+        M2D_HIP_TRY(h, hipGetLastError());
+    }
+    {   // users whose lists met a tie at a boundary: re-ranked in dish-id order (nothing to do is the common case)
+        RepairArgs r;
+        r.pm = h->pm; r.re = h->re; r.ce = h->ce; r.cats = h->dish_cats; r.hv = HV ? h->dish_high : nullptr;
+        r.users = users; r.flags = h->topk_flags; r.nU = nU; r.U = h->U; r.I = h->I; r.user_base = h->user_base;
+        r.C = h->C; r.E = h->E; r.k = k; r.a = h->a; r.b = h->b; r.out_scores = final_s; r.out_ids = final_i;
+        const size_t rlds = ((size_t)(2 * h->C + 1) * h->E + (size_t)2 * 256 * k) * sizeof(float);
+        const int64_t rgrid = nU < (int64_t)h->num_cu * 4 ? nU : (int64_t)h->num_cu * 4;
+        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_topk_repair_ties, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+        hipLaunchKernelGGL(m2d_topk_repair_ties, dim3((unsigned)rgrid), dim3(256), rlds, st, r);
         M2D_HIP_TRY(h, hipGetLastError());
     }
     hipLaunchKernelGGL(m2d_topk_fill_absent, dim3((unsigned)((nU + 127) / 128)), dim3(128), 0, st, final_s, final_i, nU, k,

@@ -91,6 +91,8 @@ struct m2d_engine {
     // scratch for rank_candidates
     float *scratch = nullptr;
     size_t scratch_bytes = 0;
+    int32_t *topk_flags = nullptr;      // [users of a call] pattern-grouped retrieval: "met a tie at a list boundary" (re-ranked in id order)
+    size_t topk_flags_cap = 0;
 
     // benchmarking knobs
     int opt_prefetch = 2;

@@ -62,7 +62,7 @@ class _EvalPlan:
     """Everything `evaluate_model` derives from its three dict arguments, built once and kept on the device: the flat
     candidate array (evaluate.py:39-51 for every user), its lengths, the user ids and the dish -> category table."""
 
-    __slots__ = ("refs", "stamp", "users", "users_dev", "items_dev", "lens_dev", "gt", "dish_table", "engine_id")
+    __slots__ = ("refs", "held", "stamp", "users", "users_dev", "items_dev", "lens_dev", "gt", "dish_table", "engine_key")
 
 
 _PLANS: "List[_EvalPlan]" = []          # most recent first; a training run alternates between at most a few splits
@@ -70,19 +70,34 @@ _MAX_PLANS = 4
 
 
 def clear_eval_plans():
-    """Forget the cached evaluation plans (call after editing a split's dicts in place)."""
+    """Forget the cached evaluation plans (call after editing ELEMENTS of a split's lists in place)."""
     del _PLANS[:]
 
 
+def _held(testRatings, testNegatives, dish_to_category):
+    """The users in order and every dict's value objects in order.  Kept by the plan (so no replaced list can be freed
+    and its id recycled) and compared with `==` on the next call: list comparison checks identity first, so an unchanged
+    entry costs a pointer compare and a replaced list is compared by content -- no replaced list can be missed."""
+    return (list(testRatings), list(testRatings.values()), len(testNegatives), list(testNegatives.values()),
+            len(dish_to_category), list(dish_to_category.values()))
+
+
 def _stamp(testRatings, testNegatives, dish_to_category):
-    """Cheap content check behind the identity key: sizes plus up to 64 evenly spaced users' candidate lists.  The
-    driver never edits its split between epochs (Train_recommender.py:124-133 load it once); an in-place edit that
-    this sample misses needs `clear_eval_plans()`."""
+    """What identity cannot see -- an element appended to, removed from or rewritten in a list that is still the same
+    object: every list's length, plus the contents of up to 64 evenly spaced users' candidate lists.  An element-wise
+    in-place edit that keeps the length and misses the sample needs `clear_eval_plans()`; the driver never edits its
+    split between epochs (Train_recommender.py:124-133 load it once)."""
     keys = list(testRatings.keys())
     step = max(1, len(keys) // 64)
     probe = tuple((k, tuple(testRatings[k][:1]), tuple(testNegatives[k][50:100]) if k in testNegatives else None)
                   for k in keys[::step][:64])
-    return len(keys), len(testNegatives), len(dish_to_category), probe
+    return (sum(map(len, testRatings.values())), sum(map(len, testNegatives.values())),
+            sum(map(len, dish_to_category.values())), probe)
+
+
+def _engine_key(engine):
+    # a serial that is never reused (id() of a collected engine can be) plus what a plan's tensors depend on
+    return engine.id, engine.I, engine.C, str(engine.device)
 
 
 def _build_plan(model: Model, testRatings, testNegatives, dish_to_category) -> _EvalPlan:
@@ -115,6 +130,7 @@ def _build_plan(model: Model, testRatings, testNegatives, dish_to_category) -> _
     dev = model.engine.device
     p = _EvalPlan()
     p.refs = (testRatings, testNegatives, dish_to_category)      # strong: keeps the ids in the cache key from being recycled
+    p.held = _held(testRatings, testNegatives, dish_to_category)
     p.stamp = _stamp(testRatings, testNegatives, dish_to_category)
     p.users = users
     p.users_dev = torch.from_numpy(users_np.astype(np.int32)).to(dev)
@@ -123,14 +139,16 @@ def _build_plan(model: Model, testRatings, testNegatives, dish_to_category) -> _
     p.gt = items_np[:, 0].copy()
     model.set_dish_categories(dish_to_category)               # dict -> [I, C] table, copied to HBM once
     p.dish_table = model.engine.dish_cats                     # the resident tensor itself (kept alive by the plan)
-    p.engine_id = model.engine.id
+    p.engine_key = _engine_key(model.engine)
     return p
 
 
 def _plan_for(model: Model, testRatings, testNegatives, dish_to_category) -> _EvalPlan:
+    key = _engine_key(model.engine)
     for i, p in enumerate(_PLANS):
         if (p.refs[0] is testRatings and p.refs[1] is testNegatives and p.refs[2] is dish_to_category
-                and p.engine_id == model.engine.id and p.stamp == _stamp(testRatings, testNegatives, dish_to_category)):
+                and p.engine_key == key and p.held == _held(testRatings, testNegatives, dish_to_category)
+                and p.stamp == _stamp(testRatings, testNegatives, dish_to_category)):
             if i:
                 _PLANS.insert(0, _PLANS.pop(i))
             return p
@@ -148,7 +166,13 @@ def evaluate_model(sess, model: Model, testRatings: Dict[str, List[int]], testNe
     through ``model.engine``.  The driver calls this every ``verbose`` epochs with the same three dicts
     (Train_recommender.py:210): the candidate arrays and the dish table built from them are kept on the device
     (``_EvalPlan``), so a repeat call costs one launch, one device-to-host copy of ``[users, K]`` ids and the
-    HR / NDCG arithmetic -- none of the per-user Python work of the first call.
+    HR / NDCG arithmetic -- none of the per-user Python work of the first call.  The plan is reused only while the three
+    dicts are the same objects holding the same keys and the same (or equal) list objects of the same lengths; rewriting
+    elements of a list in place calls for ``clear_eval_plans()``.
+
+    Like the reference, which feeds ``categories`` from ``dish_to_category`` on every call (evaluate.py:43, :50), this
+    makes ``dish_to_category`` the engine's resident dish mask table: a table set earlier with ``set_dish_categories`` is
+    replaced.
     """
     if not testRatings:
         return [], []

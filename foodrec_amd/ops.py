@@ -7,6 +7,7 @@ tensors raises ``NotImplementedError``; there is no eager/CPU fallback to fall t
 from __future__ import annotations
 
 import ctypes
+import itertools
 import weakref
 from typing import Optional
 
@@ -16,6 +17,7 @@ import torch
 from . import _native
 
 _ENGINES: "weakref.WeakValueDictionary[int, ScoringEngine]" = weakref.WeakValueDictionary()
+_ENGINE_SERIAL = itertools.count(1)         # engine keys are never reused (id() of a collected engine can be)
 
 
 def _stream_ptr() -> int:
@@ -66,7 +68,7 @@ class ScoringEngine:
         self.user_base = 0
         if user_base:
             self.set_user_base(user_base)
-        self.id = id(self)
+        self.id = next(_ENGINE_SERIAL)
         _ENGINES[self.id] = self
 
     # -- configuration ---------------------------------------------------------------------------

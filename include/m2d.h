@@ -112,13 +112,13 @@ int m2d_rank_candidates(m2d_engine *h, const int32_t *users, const int32_t *item
  * one-block-per-user kernel otherwise.
  * With the ingredient table set (m2d_set_ingredients) the high-level term uses H[d]; E = 32 / 64 stay on the
  * pattern-grouped split-bf16 kernel (rows [H[d] | RE[d]]), other shapes use the dense kernel.
- * Tie rule, precisely: with 0/1 masks, C = 4, k <= 16 the pattern-grouped kernels scan the dishes grouped by mask
- * pattern (bit c = category c) and, inside a pattern, by descending row norm in 16 coarse buckets, dish id order
- * inside a bucket; bit-equal scores resolve to the dish scanned first.  Duplicate dishes (same row, same mask: the
- * case the reference's evaluator can meet) share a bucket, so they resolve to the lower id.  Different rows tie
- * bit for bit only under a user vector that scores whole groups identically (e.g. an all-zero Personal_Memory block);
- * those ties follow the scan order, not the id.  Option "topk_grouped" = 0 selects the dense kernel, which scans in
- * id order and resolves every tie to the lower id (about 5x the matrix work). */
+ * Tie rule: bit-equal scores resolve to the lower dish id, whatever kernel runs -- heapq.nlargest's rule
+ * (evaluate.py:63).  The pattern-grouped kernels scan the dishes grouped by mask pattern and, inside a pattern, by
+ * descending row norm; they notice when a tie decides what a list holds (a score equal to a list's last entry falls off
+ * or is refused), and such users -- an all-zero Personal_Memory block, a user vector that scores whole groups
+ * identically -- are re-ranked over the catalogue in id order with the formula in plain f32 (their scores are then
+ * exact-f32 even under "topk_bf16x3" = 1).  Option "topk_grouped" = 0 selects the dense kernel (about 5x the matrix
+ * work), which scans in id order. */
 int m2d_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, float *out_scores,
                    int32_t *out_ids, void *stream);
 

@@ -88,3 +88,32 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "libm2d_oracle" not in text, f
+
+
+def test_eval_plan_fingerprint_is_exact_for_replaced_lists_and_cheap():
+    """The evaluator's plan cache (foodrec_amd/evaluator.py): the check that decides whether a cached plan may be reused
+    sees every replaced list -- whichever user it belongs to -- and costs a few milliseconds at the reference's 64 657
+    users (Train_recommender.py:51)."""
+    import time
+    from foodrec_amd import evaluator
+    U = 64657
+    rng = np.random.default_rng(0)
+    neg = rng.integers(0, 4548, (U, 100))
+    ratings = {str(u): [int(neg[u, 0])] for u in range(U)}
+    negatives = {str(u): neg[u].tolist() for u in range(U)}
+    d2c = {str(d): [[1.0], [0.0], [0.0], [1.0]] for d in range(4548)}
+    held, stamp = evaluator._held(ratings, negatives, d2c), evaluator._stamp(ratings, negatives, d2c)
+    dt = 1.0
+    for _ in range(7):
+        t0 = time.perf_counter()
+        same = held == evaluator._held(ratings, negatives, d2c) and stamp == evaluator._stamp(ratings, negatives, d2c)
+        dt = min(dt, time.perf_counter() - t0)
+    assert same and dt < 0.010, dt
+    for u in ("1", "777", "12345", str(U - 1)):              # users a 64-user sample would not look at
+        old = negatives[u]
+        negatives[u] = old[:50] + old[50:][::-1]
+        assert held != evaluator._held(ratings, negatives, d2c)
+        negatives[u] = list(old)                             # equal content in a new object: the same split
+        assert held == evaluator._held(ratings, negatives, d2c)
+    ratings["4242"] = [ratings["4242"][0] + 1]
+    assert held != evaluator._held(ratings, negatives, d2c)

@@ -25,7 +25,23 @@ def _tables(U, I, C, E, seed, n_nan=0, dup=0):
     return PM, RE, CE, cats
 
 
-def _check(eng, PM, RE, CE, cats, users, k, user_base=0):
+def _explain_mismatches(PM, RE, CE, cats, users, sa, ia, sb, ib, bound=3e-5):
+    """Two kernels' lists for the same users: wherever they hold different dishes at a position, the two dishes' exact
+    (float64) scores are closer than the kernels' rounding -- `bound` x max(1, |s|): 3e-5 is the split-bf16 product's
+    measured error -- so either order is a correct ranking at that precision.  Returns the number of such positions."""
+    from oracle import m2d_oracle as oracle
+    I = RE.shape[0]
+    n = 0
+    for r in np.flatnonzero(np.any(ia != ib, axis=1)):
+        ref = oracle.inference_f64(PM, RE, CE, np.full(I, users[r]), np.arange(I), cats)
+        for p in np.flatnonzero(ia[r] != ib[r]):
+            ea, eb = ref[ia[r, p]], ref[ib[r, p]]
+            assert abs(ea - eb) <= bound * max(1.0, abs(ea)), (int(users[r]), int(p), int(ia[r, p]), int(ib[r, p]), ea, eb)
+            n += 1
+    return n
+
+
+def _check(eng, PM, RE, CE, cats, users, k, user_base=0, dup=0):
     import torch
     from oracle import m2d_oracle as oracle
     s, ids = eng.topk_users(torch.as_tensor(users + user_base, dtype=torch.int32, device="cuda"), k)
@@ -51,6 +67,13 @@ def _check(eng, PM, RE, CE, cats, users, k, user_base=0):
         for a in range(n_valid - 1):
             if s[r, a] == s[r, a + 1]:
                 assert got_ids[a] < got_ids[a + 1], (u, got_ids[a], got_ids[a + 1])
+        # ... also where the tie decides what the list holds: dishes I - dup.. are copies of dishes 0..dup - 1 (same row,
+        # same mask, same score to the bit), so a returned copy has its lower-id original in the list as well
+        if dup:
+            held = set(got_ids[:n_valid].tolist())
+            for d in got_ids[:n_valid]:
+                if d >= I - dup and not np.isnan(ref[d]):
+                    assert int(d) - (I - dup) in held, (u, int(d))
 
 
 @pytest.mark.parametrize("E,C", [(32, 4), (64, 4), (128, 4), (200, 4), (16, 3), (20, 4), (100, 4), (48, 4), (256, 4), (260, 4), (22, 4)])
@@ -62,7 +85,7 @@ def test_topk_users_shapes(E, C, k):
     eng = ScoringEngine(PM, RE, CE)
     eng.set_dish_categories(cats)
     users = np.random.default_rng(1).integers(0, U, 45)
-    _check(eng, PM, RE, CE, cats, users, k)
+    _check(eng, PM, RE, CE, cats, users, k, dup=20)
     mfma = (C, E) in ((4, 32), (4, 64), (4, 128))
     padded = C == 4 and not mfma and E % 4 == 0 and E <= 256     # sorted dish rows zero-padded to 32 / 64 / 128 / 256 floats
     grouped = "m2d_topk_grouped_bf16x3" if E in (64, 128) else "m2d_topk_grouped"      # default: split-bf16
@@ -217,16 +240,15 @@ def test_topk_split_bf16_variant(E, k):
 
 @pytest.mark.parametrize("E", [64, 128, 32])
 def test_cross_pattern_ties_and_the_dense_option(E):
-    """A user whose Personal_Memory block is all zero scores every dish 0: one global tie.  The dense kernel (option
-    topk_grouped = 0) scans in id order and returns the lowest ids; the pattern-grouped kernels return dishes of the lowest mask
-    pattern, largest row norms first -- the documented scan order of m2d_topk_users (include/m2d.h).  Users without such ties get
-    the same lists from both."""
+    """A user whose Personal_Memory block is all zero scores every dish 0: one global tie, and heapq.nlargest's rule
+    (evaluate.py:63) returns the lowest ids.  So does every kernel: the dense one scans in id order, the pattern-grouped
+    ones notice the tie at their lists' boundary and re-rank that user in id order (include/m2d.h).  Users without such
+    ties get the same lists from both, up to swaps of dishes whose scores are closer than the kernels' rounding."""
     import torch
     from foodrec_amd import ScoringEngine
     U, I, k = 70, 3000, 10
     PM, RE, CE, cats = _tables(U, I, 4, E, seed=E + 3)
     PM[5] = 0.0
-    pat = (cats * (1 << np.arange(4))[None, :]).sum(1).astype(np.int64)
     eng = ScoringEngine(PM, RE, CE)
     eng.set_dish_categories(cats)
     users = torch.arange(U, dtype=torch.int32, device="cuda")
@@ -241,16 +263,88 @@ def test_cross_pattern_ties_and_the_dense_option(E):
         sg, ig, sd, idn = sg.cpu().numpy(), ig.cpu().numpy(), sd.cpu().numpy(), idn.cpu().numpy()
         assert np.all(sg[5] == 0) and np.all(sd[5] == 0)
         assert idn[5].tolist() == list(range(k))                                  # dense: lowest ids
-        # grouped: the lowest pattern, and inside it the scan order -- descending row norm in buckets of sigma / 4
-        assert np.all(pat[ig[5]] == pat.min())
-        nrm = np.linalg.norm(RE.astype(np.float64), axis=1)
-        in_pat = np.sort(nrm[pat == pat.min()])[::-1]
-        # (a user's two lanes each keep the first k they scan and merge ties by id: the list comes from the first 2 k scanned)
-        assert nrm[ig[5]].min() >= in_pat[2 * k - 1] - nrm.std() / 4 - 1e-6
-        others = [u for u in range(U) if u != 5]
-        # same scores within the bar; the id lists agree except where two scores are closer than the kernels' rounding
-        assert np.all(np.abs(sg[others] - sd[others]) <= TOL * np.maximum(1.0, np.abs(sd[others])))
-        assert np.mean(np.all(ig[others] == idn[others], axis=1)) > 0.9
+        assert ig[5].tolist() == list(range(k))                                   # pattern-grouped: the same
+        # same scores within the bar; every position where the id lists differ is a pair of dishes closer than the rounding
+        assert np.all(np.abs(sg - sd) <= TOL * np.maximum(1.0, np.abs(sd)))
+        _explain_mismatches(PM, RE, CE, cats, np.arange(U), sg, ig, sd, idn)
+
+
+@pytest.mark.parametrize("E", [64, 128, 32, 200])
+@pytest.mark.parametrize("forced", [0, 103, 228])          # automatic splits, 3 dish-range splits, 128 (two-pass merge)
+def test_structural_ties_resolve_to_the_lower_id(E, forced):
+    """User vectors that score whole groups of dishes identically, so that ties decide what the list holds:
+      user 0: all-zero block -- every dish scores 0;
+      user 1: zero low-level rows -- a dish's score is alpha_P, the same for every dish of a mask pattern, and the scan
+              order inside a pattern (descending row norm) is not the id order;
+      user 2: zero low-level row of category 0 only -- ties among the dishes whose only category is 0;
+      users 3..: ordinary.
+    Every kernel form returns heapq.nlargest's list: descending score, equal scores by ascending dish id."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    U, I, k = 40, 2600, 10
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=E + 17, n_nan=7)
+    PM[0] = 0.0
+    PM[1, 1:] = 0.0
+    PM[2, 1] = 0.0
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    users = torch.arange(U, dtype=torch.int32, device="cuda")
+    ref_s, ref_i = oracle.topk_catalogue(PM, RE, CE, cats, range(3), k)
+    forms = [(0, 0)] if E in (32, 200) else [(1, 0), (1, 1), (0, 0)]          # (topk_bf16x3, topk_form)
+    for x3, form in forms:
+        eng.set_option("topk_bf16x3", x3); eng.set_option("topk_form", form); eng.set_option("variant", forced)
+        s, ids = eng.topk_users(users, k); eng.check()
+        assert eng.last_kernel().startswith("m2d_topk_grouped")
+        s, ids = s.cpu().numpy(), ids.cpu().numpy()
+        for u in (0, 1):                                     # every score is tied with many others: the list is exactly the oracle's
+            assert ids[u].tolist() == ref_i[u].tolist(), (x3, form, u, ids[u], ref_i[u])
+            assert_scores_close(s[u], ref_s[u])
+        _check(eng, PM, RE, CE, cats, np.arange(U), k)
+
+
+def test_every_user_tied():
+    """A zero-initialised Personal_Memory table: every user is re-ranked in id order (the slow path at its worst)."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    U, I, E, k = 600, 3000, 64, 10
+    _, RE, CE, cats = _tables(U, I, 4, E, seed=2, n_nan=4)
+    PM = np.zeros((U, 5, E), np.float32)
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    s, ids = eng.topk_users(torch.arange(U, dtype=torch.int32, device="cuda"), k); eng.check()
+    assert eng.last_kernel() == "m2d_topk_grouped_bf16x3"
+    want = np.flatnonzero(cats.sum(1) > 0)[:k]               # the lowest ids with a non-empty mask (empty masks score NaN)
+    assert np.all(ids.cpu().numpy() == want[None, :]) and np.all(s.cpu().numpy() == 0)
+
+
+@pytest.mark.parametrize("E", [32, 64, 128, 200])
+def test_exact_f32_lists_equal_the_oracle_where_gaps_are_clear(E):
+    """Exact-f32 pattern-grouped kernel ("topk_bf16x3" = 0): the id at every position whose score is more than 1e-6 away
+    from both neighbours' (the (k + 1)-th best included) is the oracle's."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    U, I, k = 60, 4000, 10
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=E + 5, n_nan=5, dup=30)
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    eng.set_option("topk_bf16x3", 0)
+    s, ids = eng.topk_users(torch.arange(U, dtype=torch.int32, device="cuda"), k); eng.check()
+    assert eng.last_kernel() == "m2d_topk_grouped"
+    ids = ids.cpu().numpy()
+    ref_s, ref_i = oracle.topk_catalogue(PM, RE, CE, cats, range(U), k + 1)
+    clear = 0
+    for u in range(U):
+        gap_before = np.concatenate([[np.inf], ref_s[u, :k - 1] - ref_s[u, 1:k]])
+        gap_after = ref_s[u, :k] - ref_s[u, 1:k + 1]
+        ok = (gap_before > 1e-6) & (gap_after > 1e-6)
+        assert np.array_equal(ids[u][ok], ref_i[u, :k][ok]), (u, ids[u], ref_i[u])
+        # duplicates (bit-equal scores, gap 0) resolve to the lower id: the oracle's order again
+        tied = ~ok & (np.concatenate([[False], ref_s[u, :k - 1] == ref_s[u, 1:k]]) | (ref_s[u, :k] == ref_s[u, 1:k + 1]))
+        assert np.array_equal(ids[u][tied], ref_i[u, :k][tied]), (u, ids[u], ref_i[u])
+        clear += int(ok.sum())
+    assert clear > 0.9 * U * k
 
 
 @pytest.mark.parametrize("E,k", [(64, 10), (128, 10), (64, 16), (128, 13)])
@@ -273,6 +367,6 @@ def test_both_forms_of_the_split_bf16_kernel_agree(E, k):
         out[form] = (s.cpu().numpy(), i.cpu().numpy())
     (s1, i1), (s2, i2) = out[1], out[2]
     assert np.all(np.abs(s1 - s2) <= 1e-5 * np.maximum(1.0, np.abs(s1)))
-    assert np.mean(np.all(i1 == i2, axis=1)) > 0.95
+    _explain_mismatches(PM, RE, CE, cats, np.arange(U), s1, i1, s2, i2)     # differing positions: scores closer than the rounding
     eng.set_option("topk_form", 1)
     _check(eng, PM, RE, CE, cats, np.arange(0, U, 7), k)                # the first form on its own against the oracle

@@ -151,3 +151,51 @@ def test_repeat_calls_reuse_the_device_plan(monkeypatch):
     assert len(evaluator._PLANS) == 2
     clear_eval_plans()
     assert not evaluator._PLANS
+
+
+def test_a_replaced_list_is_never_served_from_the_old_plan():
+    """evaluate.py:35-51 rebuilds every user's candidates on every call.  The cached plan is reused only while the dicts
+    hold the same list objects (or equal ones): replace the negatives of ANY one user -- also one a sampled check would
+    skip -- or a dish's categories, and the next call builds a new plan and agrees with the per-user path."""
+    from foodrec_amd import clear_eval_plans, evaluate_model, evaluator
+    U, I, C, E, K = 700, 90, 4, 32, 10
+    rng = np.random.default_rng(3)
+    PM = (rng.standard_normal((U, C + 1, E)) / 6).astype(np.float32)
+    RE = (rng.standard_normal((I, E)) / 6).astype(np.float32)
+    CE = (rng.standard_normal((C, E)) / 6).astype(np.float32)
+    import types
+    import foodrec_amd
+    args = types.SimpleNamespace(num_categories=C, num_users=U, embed_size=E, high_level_score_coefficient=0.99)
+    model = foodrec_amd.Model(args, PM, RE, CE, None)
+    ratings = {str(u): [int(rng.integers(0, I))] for u in range(U)}
+    negatives = {str(u): rng.integers(0, I, 100).tolist() for u in range(U)}
+    d2c = {str(d): [[float(x)] for x in (rng.integers(1, 16) >> np.arange(C)) & 1] for d in range(I)}
+    clear_eval_plans()
+    per_user = lambda: list(zip(*[evaluator.eval_one_rating(model, u, ratings, negatives, K, d2c) for u in ratings]))
+    h0, n0 = evaluate_model(None, model, ratings, negatives, K, d2c)
+    assert (tuple(h0), tuple(n0)) == tuple(per_user())
+    assert evaluate_model(None, model, ratings, negatives, K, d2c) == (h0, n0) and len(evaluator._PLANS) == 1
+    step = max(1, U // 64)
+    victim = str(step + 3)                                   # not a multiple of the old sample's stride
+    assert int(victim) % step != 0
+    # candidates that make the held-out dish rank first or last, whichever changes this user's hit
+    pos = ratings[victim][0]
+    negatives[victim] = [pos] * 100 if not h0[int(victim)] else negatives[victim][:50] + sorted(negatives[victim][50:], key=lambda d: d == pos)
+    negatives[victim] = list(negatives[victim])              # a NEW list object of the same length
+    h1, n1 = evaluate_model(None, model, ratings, negatives, K, d2c)
+    assert len(evaluator._PLANS) == 2
+    assert (tuple(h1), tuple(n1)) == tuple(per_user())
+    # a replaced categories entry
+    some = str(negatives["0"][60])
+    d2c[some] = [[1.0 - x[0]] for x in d2c[some]] if sum(x[0] for x in d2c[some]) < C else [[1.0], [0.0], [0.0], [0.0]]
+    h2, n2 = evaluate_model(None, model, ratings, negatives, K, d2c)
+    assert len(evaluator._PLANS) == 3
+    assert (tuple(h2), tuple(n2)) == tuple(per_user())
+    # an equal list in place of the old one is the same split: no new plan
+    negatives["5"] = list(negatives["5"])
+    assert evaluate_model(None, model, ratings, negatives, K, d2c) == (h2, n2) and len(evaluator._PLANS) == 3
+    # a list that grew in place (same object): its length gives it away
+    negatives["7"].append(3)
+    evaluate_model(None, model, ratings, negatives, K, d2c)
+    assert len(evaluator._PLANS) == 4
+    clear_eval_plans()
