@@ -20,7 +20,13 @@ torch.distributed.run command above as a child BEFORE importing torch or touchin
 child's status.  At N > 1 the line also carries `sharded_topk_allgather` (the user-sharded full-catalogue
 top-k + RCCL all-gather, median of 7) and `routed_pairs_alltoall` (pairs routed to the owners of their users).
 
-Exit status: 3 when the in-run parity check of the timed kernel against the CPU restatement fails.
+Every line also carries `scaling_path`: the user-sharded top-k path north_star's ">= 6x at 8 GPUs" speaks of, at
+BASELINE configs[3]'s per-GPU shape (10 M / N users x 1 M dishes, E = 64; every user of the shard in rounds of 65 536,
+one all-gather of [shard, 10] x (f32, i32)) -- `--config 3|4` makes that path the timed step itself.
+
+Exit status: 3 when the in-run parity check of the timed kernel against the CPU restatement fails; 4 when a leg after
+the timed region did not return within --side-timeout (the headline line is still printed; `side_legs` names the leg
+and rank in flight).
 """
 from __future__ import annotations
 
@@ -71,6 +77,13 @@ def parse():
                         "training step (SURVEY.md 8f N4) at its own default sizes unless --users/--dishes/--embed/--pairs "
                         "are given: loss + gradients + clip + optimizer update per step, single GPU")
     p.add_argument("--ingredients", type=int, default=10_000, help="rows of the ingredient table (workload ingredients)")
+    p.add_argument("--config", type=int, choices=[3, 4], default=None,
+                   help="BASELINE.json configs[3] / configs[4] as the timed step: 10 M / N users per GPU x 1 M replicated dishes, "
+                        "E = 64 / 128, top-10 for EVERY user of the shard in rounds of --round-users, then ONE all-gather of "
+                        "[shard, 10] x (f32 score, i32 id) (100 MB per rank at N = 8)")
+    p.add_argument("--round-users", type=int, default=65536, help="users per retrieval launch in the sharded top-k path")
+    p.add_argument("--scaling-users", type=int, default=10_000_000,
+                   help="users over ALL GPUs in the scaling_path block (configs[3]: 10 M; 0 = leave the block out)")
     p.add_argument("--topk-with-ingredients", action="store_true",
                    help="workload topk: set the ingredient table first (retrieval over [H[d] | RE[d]] rows, E = 32 / 64)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -303,6 +316,27 @@ def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10):
             "kernel": kernel}
 
 
+class _Clock:
+    """HIP events on the current stream for a GPU device, perf_counter on CPU (the gloo test of these legs)."""
+
+    def __init__(self, torch, dev):
+        self.torch, self.gpu = torch, torch.device(dev).type == "cuda"
+
+    def mark(self):
+        if self.gpu:
+            e = self.torch.cuda.Event(enable_timing=True)
+            e.record()
+            return e
+        return time.perf_counter()
+
+    def sync(self):
+        if self.gpu:
+            self.torch.cuda.synchronize()
+
+    def ms(self, a, b):
+        return a.elapsed_time(b) if self.gpu else (b - a) * 1e3
+
+
 def sharded_topk_leg(torch, dist, eng, U, I, C, E, dev, user_base, n_users, world, k=10, repeats=7):
     """Every rank: top-k over the replicated catalogue for n_users of ITS users, then ONE all-gather of
     [n_users, k] x (f32 score, i32 id) per rank, through foodrec_amd.sharding.  Timed
@@ -321,20 +355,20 @@ def sharded_topk_leg(torch, dist, eng, U, I, C, E, dev, user_base, n_users, worl
     for _ in range(5):                                    # the first full launches run 5-10 % slow (clock ramp)
         sh.topk_users_gathered(users, k)
     walls, tk_ms, ag_ms = [], [], []
+    clk = _Clock(torch, dev)
     for _ in range(repeats):
-        torch.cuda.synchronize()
+        clk.sync()
         if dist is not None:
             dist.barrier()
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         t0 = time.perf_counter()
-        e0.record()
+        e0 = clk.mark()
         s, ids = sh.topk_local(k, users)
-        e1.record()
+        e1 = clk.mark()
         gs, gi = sh._gather_topk(s, ids, n_users, k) if dist is not None else (s, ids)
-        e2.record()
-        torch.cuda.synchronize()
+        e2 = clk.mark()
+        clk.sync()
         wall = time.perf_counter() - t0
-        t = torch.tensor([wall, e0.elapsed_time(e1), e1.elapsed_time(e2)], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall, clk.ms(e0, e1), clk.ms(e1, e2)], dtype=torch.float64, device=dev)
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         w, a_, b_ = (float(x) for x in t.tolist())
@@ -352,6 +386,114 @@ def sharded_topk_leg(torch, dist, eng, U, I, C, E, dev, user_base, n_users, worl
                     + ("" if dist is not None else " (single process: no peers, no collective)")}
 
 
+def sharded_all_users_leg(torch, dist, sh, I, k, round_users, repeats=1, warm_rounds=2):
+    """The user-sharded top-k path as north_star states it: every rank ranks EVERY user of its shard over the replicated
+    catalogue (rounds of `round_users` users, foodrec_amd.sharding.topk_local_rounds), then ONE all-gather of
+    [shard, k] x (f32 score, i32 id) per rank.  `sh` is a UserShardedScorer; `dist` is None in a single-process run (no
+    peers, no collective).  Wall time = max over ranks, median over repeats."""
+    clk = _Clock(torch, sh.device)
+    per_round = min(int(round_users), max(sh.count, 1))
+    if sh.count:
+        sh.topk_local(k, torch.arange(sh.base, sh.base + min(per_round, sh.count), dtype=torch.int32, device=sh.device))   # builds the retrieval tables
+        for _ in range(warm_rounds):
+            sh.topk_local(k, torch.arange(sh.base, sh.base + min(per_round, sh.count), dtype=torch.int32, device=sh.device))
+    if dist is not None:                                  # the collective's buffers and connections, once, at its real size
+        sh._gather_topk(torch.zeros((sh.count, k), dtype=torch.float32, device=sh.device),
+                        torch.zeros((sh.count, k), dtype=torch.int32, device=sh.device), sh.per, k)
+    walls, tk, ag = [], [], []
+    ok = True
+    for _ in range(repeats):
+        clk.sync()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        e0 = clk.mark()
+        s, ids = sh.topk_local_rounds(k, round_users)
+        e1 = clk.mark()
+        gs, gi = sh._gather_topk(s, ids, sh.per, k) if dist is not None else (s, ids)
+        e2 = clk.mark()
+        clk.sync()
+        t = torch.tensor([time.perf_counter() - t0, clk.ms(e0, e1), clk.ms(e1, e2)], dtype=torch.float64, device=sh.device)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        w, a_, b_ = (float(x) for x in t.tolist())
+        walls.append(w); tk.append(a_); ag.append(b_)
+        lo = sh.rank * sh.per
+        ok = ok and bool(torch.equal(gi[lo:lo + sh.count], ids) and torch.equal(gs[lo:lo + sh.count].view(torch.int32), s.view(torch.int32)))
+    if sh.scorer is not None:
+        sh.scorer.check()
+    wall = median(walls)
+    total_users = sh.num_users_total
+    return {"path": "sharded_topk_allgather", "users_total": total_users, "users_per_gpu": sh.per, "dishes": I, "k": k,
+            "round_users": int(round_users), "rounds_per_gpu": -(-sh.per // int(round_users)), "repeats": repeats,
+            "wall_ms": wall * 1e3, "topk_ms": median(tk), "allgather_ms": median(ag),
+            "allgather_bytes_per_rank": sh.per * k * 8 if dist is not None else 0,
+            "users_per_s_whole_job": total_users / wall, "pairs_per_s_whole_job": total_users * I / wall,
+            "own_slice_roundtrip_ok": ok}
+
+
+def scaling_path_block(torch, dist, foodrec_amd, dev, world, rank, users_total, I, E, k, round_users, repeats=1):
+    """`scaling_path`: the sharded top-k path at BASELINE configs[3] / configs[4]'s per-GPU shape, on tables of its own
+    (users_total / world users per GPU x I replicated dishes).  The split-bf16 kernel (the default) over every user of
+    the shard + the all-gather; the exact-f32 kernel's rate beside it, measured on one round of users per GPU."""
+    from foodrec_amd.sharding import UserShardedScorer, shard_range
+    C = 4
+    base, count = shard_range(users_total, world, rank)
+    g = torch.Generator(device=dev); g.manual_seed(20260101 + 4)             # replicated tables: the same on every rank
+    sc = E ** -0.5
+    RE = torch.randn((I, E), generator=g, device=dev) * sc
+    CE = torch.randn((C, E), generator=g, device=dev) * sc
+    pat = torch.randint(1, 2 ** C, (I,), generator=g, device=dev, dtype=torch.int32)
+    dish_cats = ((pat[:, None] >> torch.arange(C, device=dev, dtype=torch.int32)[None, :]) & 1).float()
+    g.manual_seed(20260101 + 40 + rank)
+    PM = torch.randn((max(count, 1), C + 1, E), generator=g, device=dev) * sc
+    eng = foodrec_amd.ScoringEngine(PM, RE, CE, coef=0.99, device=dev, user_base=base)
+    eng.set_dish_categories(dish_cats)
+    sh = UserShardedScorer(eng, users_total, device=dev, always_collective=dist is not None)
+    out = sharded_all_users_leg(torch, dist, sh, I, k, round_users, repeats=repeats)
+    out["kernel"] = eng.last_kernel()
+    x3 = out["kernel"].endswith("bf16x3")
+    out["dtype"] = "bf16x3 (x = hi + lo, 3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)" if x3 else "f32"
+    out["embed_size"] = E
+    flop = 2.0 * E * (3 if x3 else 1)                      # per (user, dish) on the pattern-grouped kernels
+    out["roofline_frac_of_mfma_peak"] = flop * out["pairs_per_s_whole_job"] / world / 1e12 / (2500.0 if x3 else 157.3)
+    out["repaired_users_last_round"] = eng.get_option("topk_repaired")
+    # the exact-f32 kernel on one round of this shard's users (every rank at once; max over ranks)
+    clk = _Clock(torch, dev)
+    eng.set_option("topk_bf16x3", 0)
+    n1 = min(int(round_users), count)
+    users = torch.arange(base, base + n1, dtype=torch.int32, device=dev)
+    ms = []
+    if n1:
+        eng.topk_users(users, k)
+        for _ in range(3):
+            clk.sync()
+            if dist is not None:
+                dist.barrier()
+            a = clk.mark(); eng.topk_users(users, k); b = clk.mark(); clk.sync()
+            t = torch.tensor([clk.ms(a, b)], dtype=torch.float64, device=dev)
+            if dist is not None:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms.append(float(t.item()))
+        eng.check()
+    if ms:
+        m = median(ms)
+        out["exact_f32"] = {"kernel": eng.last_kernel(), "users_per_gpu_in_sample": n1, "topk_ms": m,
+                            "pairs_per_s_whole_job": world * n1 * I / m * 1e3,
+                            "roofline_frac_of_f32_mfma_peak": 2.0 * E * n1 * I / m / 1e9 / 157.3,
+                            "what": "option topk_bf16x3 = 0 (v_mfma_f32_32x32x2_f32, exact): one round of users per GPU, all "
+                                    "ranks at once, no all-gather; whole-shard time = this rate x the shard"}
+    out["what"] = ("BASELINE configs[%d] per-GPU shape: %d users over %d GPU(s) x %d replicated dishes, E = %d; per-shard "
+                   "top-%d for every user in rounds of %d + ONE all-gather of [shard, %d] x (f32, i32)%s; max over ranks"
+                   % (3 if E == 64 else 4, users_total, world, I, E, k, round_users, k,
+                      "" if dist is not None else " (single process: no peers, no collective)"))
+    eng.close()
+    del PM, RE, CE, dish_cats, eng, sh
+    if torch.device(dev).type == "cuda":
+        torch.cuda.empty_cache()
+    return out
+
+
 def routed_pairs_leg(torch, dist, eng, U, I, C, dev, world, B, repeats=5):
     """Every rank brings B pairs whose users are spread over ALL shards; UserShardedScorer.score_pairs_routed buckets
     them by owner, all-to-alls the records, the owners score, the scores come back ('pairs routed to the
@@ -366,12 +508,13 @@ def routed_pairs_leg(torch, dist, eng, U, I, C, dev, world, B, repeats=5):
     cats = ((pat[:, None] >> torch.arange(C, device=dev, dtype=torch.int32)[None, :]) & 1).to(torch.float32).contiguous()
     sh.score_pairs_routed(users, items, cats)             # warm-up, with the collective id check
     walls = []
+    clk = _Clock(torch, dev)
     for _ in range(repeats):
-        torch.cuda.synchronize()
+        clk.sync()
         dist.barrier()
         t0 = time.perf_counter()
         out = sh.score_pairs_routed(users, items, cats, check=False)
-        torch.cuda.synchronize()
+        clk.sync()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         walls.append(float(t.item()))
@@ -645,6 +788,11 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         return
+    if a.config is not None:                              # BASELINE configs[3] / [4]: the sharded top-k path is the timed step
+        a.workload = "topk"
+        a.users = -(-10_000_000 // world)
+        a.dishes = 1_000_000
+        a.embed = 64 if a.config == 3 else 128
     C, E, U, I, B = 4, a.embed, a.users, a.dishes, a.pairs
     user_base = rank * U
     PM, RE, CE, users, items, cats = make_inputs(torch, dev, U, I, C, E, B, 20260101 + 2 + rank, user_base)
@@ -680,7 +828,7 @@ def main():
     tk_users = sharded = None
     if wl == "topk":
         from foodrec_amd.sharding import UserShardedScorer
-        n_tk = min(a.topk_users if a.topk_users > 0 else 65536, U)
+        n_tk = U if a.config is not None else min(a.topk_users if a.topk_users > 0 else 65536, U)
         tk_users = (torch.randperm(U, generator=torch.Generator(device=dev).manual_seed(11 + rank), device=dev)[:n_tk]
                     .to(torch.int32) + int(user_base)).contiguous()
         sharded = UserShardedScorer(eng, world * U, device=dev)
@@ -692,6 +840,8 @@ def main():
             eng.score_pairs_ingredients(users, items, cats, out=out)
         elif wl == "mlp":
             eng.score_pairs_mlp(users, items, out=out)
+        elif a.config is not None:                                       # every user of the shard, rounds, ONE all-gather
+            sharded.topk_all_users(10, round_users=a.round_users)
         else:                                                            # retrieval: per-shard top-k, then the exchange
             sharded.topk_users_gathered(tk_users, 10)
 
@@ -720,6 +870,24 @@ def main():
     timed_sample = out[:Bc].clone() if wl == "pairs" else None           # parity sample of the TIMED kernel's scores
     mlp_sample = out[:4096].clone() if wl == "mlp" else None             # same, for the head (checked in mlp_baseline)
 
+    # SURVEY.md 8d's count charges every row of the user block (1 564 B per pair at E = 64).  The timed kernel leaves out the
+    # rows of weight-0 categories, so that count cannot be applied to ITS time (it would price bytes that were not
+    # moved): the same batch is timed once more with every row fetched (option skip_masked = 0, into a buffer of its own)
+    # and the survey's formula is published from that time.
+    survey_ms = None
+    if rank == 0 and wl == "pairs" and opts_used["skip_masked"] != 0 and not a.no_side:
+        so = torch.empty_like(out)
+        eng.set_option("skip_masked", 0)
+        try:
+            time_steps(torch, eng, users, items, cats, so, 3)
+            _, per_lit = time_steps(torch, eng, users, items, cats, so, max(10, min(a.steps, 50)))
+            eng.check()
+            survey_ms = sum(per_lit) / len(per_lit)
+            survey_kernel = eng.last_kernel()
+        finally:
+            eng.set_option("skip_masked", opts_used["skip_masked"])
+        del so
+
     rc = 0
     line = None
     if rank == 0:
@@ -729,13 +897,14 @@ def main():
         bpp = algorithmic_bytes_per_pair(C, E, mean_active) if skip else bpp_survey
         avg_ms = sum(per_launch_ms) / len(per_launch_ms)
         achieved = bpp * B / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = traffic_probe = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 key = "E%d_B%d_U%d_I%d%s" % (E, B, U, I, "_skip" if skip else "")
                 traffic = tj.get(key, {}).get("fabric_bytes_per_launch", tj.get(key, {}).get("hbm_bytes_per_launch"))
+                traffic_probe = tj.get(key, {}).get("stream_probe_GBps")
             except Exception:
                 traffic = None
         table_bytes = 4 * (PM.numel() + RE.numel())
@@ -757,13 +926,27 @@ def main():
                        "kernel": kernel_used, "options": opts_used},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/traffic.json" if traffic is not None else None,
                          "traffic_kind": ("L2<->fabric bytes per launch (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE = TCC_EA0 request "
-                                          "counters); they INCLUDE Infinity-Cache hits, so this bounds HBM bytes from above; read "
-                                          "from profiles/traffic.json (separate --pmc passes of this command), not measured in "
-                                          "this run") if traffic is not None else None,
+                                          "counters); they INCLUDE Infinity-Cache hits, so this bounds HBM bytes from above; a "
+                                          "COUNTER READING OF ANOTHER RUN of this command (separate --pmc passes, "
+                                          "scripts/profile_gpu.sh), read from the committed file and kept only while this box's "
+                                          "streaming-read probe is within 5 % of the profiled box's") if traffic is not None else None,
                          "kernel_avg_ms": avg_ms, "algorithmic_bytes_per_pair": bpp, "pairs_per_launch": B,
                          "table_bytes": table_bytes},
         }
+        line["config"]["roofline_frac_is"] = (
+            "roofline.frac prices the bytes the timed kernel has to move: (2 + active categories) x E x 4 + C x 4 + 12 per "
+            "pair, %.1f B on this batch -- the user block's rows of categories the dish does not have are multiplied by 0 in "
+            "Model_Recommender.py:82 and are not fetched.  SURVEY.md 8d's formula charges all C rows (%d B per pair); it is "
+            "published from a run that fetches them all: roofline.survey_8d_frac = %d B x pairs / roofline.survey_8d_ms / peak"
+            % (bpp, bpp_survey, bpp_survey)) if skip else "roofline.frac follows SURVEY.md 8d: (C + 2) x E x 4 + C x 4 + 12 bytes per pair"
+        if survey_ms is not None:
+            line["roofline"].update({"survey_8d_ms": survey_ms, "survey_8d_bytes_per_pair": bpp_survey,
+                                     "survey_8d_GBps": bpp_survey * B / (survey_ms * 1e-3) / 1e9,
+                                     "survey_8d_frac": bpp_survey * B / (survey_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "survey_8d_pairs_per_s": B / (survey_ms * 1e-3),
+                                     "survey_8d_kernel": survey_kernel + " (option skip_masked = 0: every row of the user block fetched)"})
         if skip:
             line["roofline"].update({
                 "mean_active_categories": mean_active, "survey_bytes_per_pair": bpp_survey,
@@ -776,30 +959,48 @@ def main():
 
     # the headline is complete here; everything below decorates it.  Should a leg never return (a collective that
     # does not complete on some rank), rank 0 still prints the line and every rank leaves.
+    in_flight = {"leg": "none"}
+
     def give_up():
+        # a leg did not return (a collective that never completes on some rank, a hung launch): the headline is not lost,
+        # but the run did NOT end cleanly -- exit status 4, and the record says which leg this rank was in
+        msg = "rank %d: leg '%s' did not return within %.0f s" % (rank, in_flight["leg"], a.side_timeout)
+        print("bench.py: " + msg, file=sys.stderr)
+        sys.stderr.flush()
         if rank == 0:
-            line["side_legs"] = "not finished within %.0f s: headline line only" % a.side_timeout
+            line["side_legs"] = {"status": "not finished: headline line only", "rank": rank, "leg_in_flight": in_flight["leg"],
+                                 "timeout_s": a.side_timeout, "exit_status": 4}
             print(json.dumps(line))
             sys.stdout.flush()
-        os._exit(0)
+        os._exit(4)
     watchdog = threading.Timer(a.side_timeout, give_up)
     watchdog.daemon = True
     watchdog.start()
 
     # N > 1: the user-sharded retrieval step and the owner-routed pair step (outside the timed region, repeated)
-    topk_ag = routed = None
+    topk_ag = routed = scaling = None
     if not a.no_side and wl == "pairs":
         if a.topk_users > 0:
+            in_flight["leg"] = "sharded_topk_allgather"
             try:
                 topk_ag = sharded_topk_leg(torch, dist if use_dist else None, eng, U, I, C, E, dev, user_base,
                                            min(a.topk_users, U), world)
             except Exception as e:                                     # noqa: BLE001 -- never lose the headline line
                 topk_ag = {"error": "%s: %s" % (type(e).__name__, e)}
         if use_dist:
+            in_flight["leg"] = "routed_pairs_alltoall"
             try:
                 routed = routed_pairs_leg(torch, dist, eng, U, I, C, dev, world, min(B, 1 << 22))
             except Exception as e:                                     # noqa: BLE001
                 routed = {"error": "%s: %s" % (type(e).__name__, e)}
+        if a.scaling_users > 0:
+            in_flight["leg"] = "scaling_path"
+            try:
+                scaling = scaling_path_block(torch, dist if use_dist else None, foodrec_amd, dev, world, rank, a.scaling_users,
+                                             1_000_000, 64, 10, a.round_users)
+            except Exception as e:                                     # noqa: BLE001
+                scaling = {"error": "%s: %s" % (type(e).__name__, e)}
+    in_flight["leg"] = "rank-0 side measurements"
 
     if a.sweep and rank == 0:
         so = torch.empty_like(out)
@@ -874,7 +1075,12 @@ def main():
             fl = (2.0 * Ew * (3 if x3 else 1) if kernel_used.startswith("m2d_topk_grouped") else 2.0 * K) * units
             tf = fl / (avg_ms * 1e-3) / 1e12
             peak = 2500.0 if x3 else 157.3
-            line["config"]["workload"] = ("BASELINE configs[3]/[4] retrieval: full-catalogue top-10 for %d users per GPU over %d "
+            line["config"]["workload"] = (("BASELINE configs[%d]: %d users over %d GPU(s) (%d per GPU) x %d replicated dishes, E=%d: "
+                                           "full-catalogue top-10 for EVERY user of the shard in rounds of %d, then ONE all-gather of "
+                                           "[shard,10] x (f32 score, i32 id) (%d bytes per rank); build-defined generalisation of "
+                                           "evaluate.py:39-63" % (a.config, world * U, world, U, I, E, a.round_users, U * 80))
+                                          if a.config is not None else
+                                          "BASELINE configs[3]/[4] retrieval: full-catalogue top-10 for %d users per GPU over %d "
                                           "replicated dishes (users from this GPU's %d-user shard), E=%d, then all-gather of "
                                           "[users,10] x (f32 score, i32 id); build-defined generalisation of evaluate.py:39-63"
                                           % (tk_users.numel(), I, U, E)) + (
@@ -885,40 +1091,66 @@ def main():
                                 "dtype": ("split bf16 (3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)" if x3 else
                                           "f32 (v_mfma_f32_32x32x2_f32, exact)")}
             line["dtype"] = "bf16x3" if x3 else "f32"
-            if not a.no_cpu_baseline and world == 1:
-                cb, ok = mlp_baseline(torch, PM, RE, CE, mlp_cats, mlp_head, users, items, user_base, mlp_sample, a.cpu_seconds)
-                line["cpu_baseline"] = cb
-                if not ok:
-                    rc = 3
+            line["roofline"]["allgather_bytes_per_rank"] = tk_users.numel() * 80 if use_dist else 0
+            line["roofline"]["repaired_users_last_launch"] = eng.get_option("topk_repaired")
         if not a.no_side and wl == "pairs":
+            in_flight["leg"] = "no-reuse / stream probe"
             nr, probe, hbm_only = side_measurements(torch, eng, PM, U, I, C, E, dev, user_base)
             line["roofline"]["no_reuse"] = nr
             line["roofline"]["hbm_only"] = hbm_only
             line["roofline"]["stream_read_probe"] = probe
             line["roofline"]["frac_of_stream_probe"] = achieved / probe["GBps"]
+            # the same figures as scalars of `roofline` (a record that keeps only scalar keys keeps these)
+            line["roofline"].update({
+                "stream_probe_GBps": probe["GBps"],
+                "no_reuse_GBps": nr["achieved"], "no_reuse_frac": nr["frac"],
+                "hbm_only_GBps": hbm_only["achieved"], "hbm_only_frac_of_spec": hbm_only["frac_of_spec_peak"],
+                "hbm_only_frac_of_stream_probe": hbm_only["frac_of_stream_probe"],
+                "hbm_only_masked_GBps": hbm_only["masked"]["achieved"],
+                "hbm_only_masked_frac_of_spec": hbm_only["masked"]["frac_of_spec_peak"],
+                "hbm_only_masked_frac_of_stream_probe": hbm_only["masked"]["frac_of_stream_probe"]})
+            if traffic is not None:
+                # the counter reading belongs to the box it was taken on: kept only while this box streams like that one
+                line["roofline"]["traffic_profiled_box_stream_probe_GBps"] = traffic_probe
+                if traffic_probe is None or abs(probe["GBps"] / traffic_probe - 1.0) > 0.05:
+                    line["roofline"].update({"traffic": None, "traffic_dropped": "this box's stream probe (%.0f GB/s) is not within 5 %% "
+                                             "of the profiled box's (%s GB/s): the committed counter reading is not published for it"
+                                             % (probe["GBps"], "%.0f" % traffic_probe if traffic_probe else "unrecorded")})
         if a.topk_users > 0 and not a.no_side and wl == "pairs":
+            in_flight["leg"] = "catalogue_topk"
             line["catalogue_topk"] = catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U))
+            eng.set_option("topk_bf16x3", 0)            # the exact-f32 kernel's figure beside the split-bf16 one (same users, same dishes)
+            try:
+                line["catalogue_topk"]["exact_f32"] = catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U))
+            finally:
+                eng.set_option("topk_bf16x3", 1)
         if world == 1 and not a.no_side and wl == "pairs" and not a.no_cpu_baseline:
+            in_flight["leg"] = "evaluator"
             try:
                 line["evaluator"] = evaluator_leg(torch, dev)
             except Exception as e:                                     # noqa: BLE001
                 line["evaluator"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not a.no_side and wl == "pairs":
+            in_flight["leg"] = "with_user_high_table"
             try:
                 line["with_user_high_table"] = user_high_leg(torch, eng, users, items, cats, C, E)
             except Exception as e:                                     # noqa: BLE001
                 line["with_user_high_table"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not a.no_side and wl == "pairs":
+            in_flight["leg"] = "with_ingredient_table"
             try:
                 line["with_ingredient_table"] = ingredients_leg(torch, eng, users, items, cats, I, C, E, dev, a.ingredients)
             except Exception as e:                                     # noqa: BLE001
                 line["with_ingredient_table"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if scaling is not None:
+            line["scaling_path"] = scaling                              # ("scaling" itself is the contract's "weak" / "strong" string)
         if topk_ag is not None:
             line["sharded_topk_allgather"] = topk_ag
         if routed is not None:
             line["routed_pairs_alltoall"] = routed
         if a.unique_users:
             line["config"]["workload"] += " [--unique-users: every user at most once per step]"
+        in_flight["leg"] = "cpu_baseline"
         if world == 1 and not a.no_cpu_baseline and wl == "pairs":
             cb, ref, _ = cpu_baseline(torch, PM, RE, CE, users, items, cats, a.cpu_seconds)
             # the baseline doubles as a live parity check of the TIMED kernel's output (sampled right after the timed

@@ -159,14 +159,23 @@ __device__ __forceinline__ void sorted_insert_inplace(float (&ls)[N], int32_t (&
 }
 
 // Tie bookkeeping of the pattern-grouped kernels.  Their lists keep equal scores in SCAN order (mask pattern, row-norm
-// bucket, dish id), heapq.nlargest keeps them in id order (evaluate.py:63).  Which dishes are in a list differs between
-// the two only when a score that fell off the end of a list -- or was refused at its end -- EQUALS the list's new last
-// entry; that is noticed here (two VALU per insertion, candidate path only), the user is flagged, and
-// m2d_topk_repair_ties re-ranks flagged users in id order.  Ties that stay inside a list are put into id order when the
-// list is finished (m2d_topk_fill_absent).  Thresholds are compared with >= so that an equal score is a candidate.
+// bucket, dish id), heapq.nlargest keeps them in id order (evaluate.py:63).  Which dishes a user's final list holds
+// differs between the two only if a score that fell off the end of a list -- or was refused at its end -- EQUALS the
+// k-th score of the final list.  A lane therefore carries one bit, "such an event happened at the value my last entry
+// holds now" (set by the event, cleared when the last entry rises: four VALU / SALU per insertion, candidate path
+// only); where lists are merged the bit counts only if that value is the merged list's last one, and a score left
+// behind by the merge that equals it counts too.  A user whose final k-th score is tied this way is re-ranked in id
+// order by m2d_topk_repair_ties (on N(0, 1/E) tables: a few users in a million); ties that stay inside a list are put
+// into id order when the list is finished (m2d_topk_fill_absent).  Thresholds are compared with >= so that an equal
+// score reaches the insertion.
 __device__ __forceinline__ bool tie_at_boundary(float x, float old_last, float new_last)
 {
     return fminf(x, old_last) == new_last && new_last > -INFINITY;
+}
+
+__device__ __forceinline__ unsigned long long tie_update(unsigned long long mask, float x, float old_last, float new_last)
+{
+    return (mask & ~__ballot(new_last != old_last)) | __ballot(tie_at_boundary(x, old_last, new_last));
 }
 
 // NB = K / 8: float4 registers of the user operand per lane.  One stage = 32 dishes x KC floats.
@@ -485,7 +494,7 @@ __global__ __launch_bounds__(256) void m2d_topk_generic(TopkArgs p, int K)
 // wins, which keeps ties in ascending-id order.
 template <int LPU>
 __global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k,
-                                                             float *out_scores, int32_t *out_ids, int32_t *tie_flags, int64_t flag_div)
+                                                             float *out_scores, int32_t *out_ids, const float *tie_in, float *tie_out)
 {
     const int lane = threadIdx.x & 63, w = lane & (LPU - 1);
     const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPU;
@@ -522,9 +531,15 @@ __global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, co
         last = bs;
         last_i = bi;
     }
-    // the cut: a score left at the head of some split's list equals the last one taken -- which of the tied dishes made
-    // the list was decided by split order (scan order of the pattern-grouped kernels), not by dish id
-    if (tie_flags && live && last_i >= 0 && hi >= 0 && hs == last) atomicOr(&tie_flags[u / flag_div], 1);
+    // The merged list's tie value (see grouped_publish): its last score if a split's own tie value is that score, or a
+    // score left at the head of some split's list equals it -- which of the tied dishes made the list was then decided
+    // by split order (the scan order of the pattern-grouped kernels), not by dish id.  The dense kernels pass no tie_in.
+    if (tie_in) {
+        const bool t = live && last_i >= 0 && ((hi >= 0 && hs == last) || tie_in[(size_t)u * nsplit + w] == last);
+        const unsigned long long grp = (LPU == 64 ? ~0ull : ((1ull << LPU) - 1ull)) << (lane & ~(LPU - 1));
+        const bool any = (__ballot(t) & grp) != 0ull;
+        if (u < nU && w == 0) tie_out[u] = any ? last : __builtin_nanf("");
+    }
 }
 
 // Users with fewer than k ranked dishes (every finite-scored dish is already in their list, the rest of the
@@ -568,7 +583,7 @@ __global__ void m2d_topk_fill_absent(float *scores, int32_t *ids, int64_t nU, in
 struct RepairArgs {
     const float *pm, *re, *ce, *cats, *hv;      // hv: per-dish high-level vectors of the ingredient extension, or null
     const int32_t *users;
-    const int32_t *flags;
+    const float *tie_val;                       // [nU] NaN: nothing to do
     int64_t nU, U, I, user_base;
     int32_t C, E, k;
     float a, b;
@@ -589,7 +604,7 @@ __global__ __launch_bounds__(256) void m2d_topk_repair_ties(RepairArgs p)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int i = t; i < C * E; i += 256) cem[i] = p.ce[i];
     for (int64_t u = blockIdx.x; u < p.nU; u += gridDim.x) {
-        if (p.flags[u] == 0) continue;                      // block-uniform
+        if (p.tie_val[u] != p.tie_val[u]) continue;         // NaN: no tie at this user's k-th score (block-uniform)
         int64_t ul = (int64_t)p.users[u] - p.user_base;
         if (ul < 0 || ul >= p.U) ul = 0;                    // latched by the scan kernel
         __syncthreads();
@@ -886,12 +901,13 @@ struct GroupedArgs {
     int32_t *err;
     unsigned long long *dbg;   // scripts/diag only
     int32_t e_real;            // padded form only: the tables' E (rows of `rs` are zero-padded to the kernel's E)
-    int32_t *tie_flags;        // [nU] set when a user's list met a tie at its boundary (see tie_at_boundary)
+    float *tie_val;            // [nU, nsplit] the list's last score when a tie decides what it holds (tie_at_boundary), else NaN
 };
 
 // End of a pattern-grouped scan: the lane's register list goes to LDS with its slots translated to dish ids, the two
-// lanes of a user (l, l + 32) are merged into this split's sorted list of k, and the user is flagged when the lists met
-// a tie at a boundary -- inside a lane (tie_mask) or where the merge cuts (a score left behind equals the last one taken).
+// lanes of a user (l, l + 32) are merged into this split's sorted list of k, and the split's tie value is written: the
+// list's last score if a tie decides what the list holds -- a lane's tie event at that very value (tie_mask), or a
+// score the merge leaves behind that equals it -- else NaN.
 template <int KR>
 __device__ __forceinline__ void grouped_publish(float *ls, int32_t *li, const float (&rs)[KR], const int32_t (&ri)[KR],
                                                 const GroupedArgs &p, const int lane, const int64_t uidx, const bool uvalid,
@@ -908,7 +924,7 @@ __device__ __forceinline__ void grouped_publish(float *ls, int32_t *li, const fl
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int cnt_hi = __shfl(cnt, j + 32, 64);
-    bool tie = ((tie_mask >> lane) & 1ull) != 0ull;
+    const bool tie_a = ((tie_mask >> j) & 1ull) != 0ull, tie_b = ((tie_mask >> (j + 32)) & 1ull) != 0ull;
     if (h == 0 && uvalid) {
         const int ca = cnt, cb = cnt_hi;
         int pa = 0, pb = 0;
@@ -935,9 +951,10 @@ __device__ __forceinline__ void grouped_publish(float *ls, int32_t *li, const fl
             pa += take_a ? 1 : 0;
             pb += take_a ? 0 : 1;
         }
-        if (full && ((pa < ca && ls[pa * 64 + lane] == last) || (pb < cb && ls[pb * 64 + lane + 32] == last))) tie = true;
+        const bool tie = full && ((pa < ca && ls[pa * 64 + lane] == last) || (pb < cb && ls[pb * 64 + lane + 32] == last) ||
+                                  (tie_a && ls[(KR - 1) * 64 + lane] == last) || (tie_b && ls[(KR - 1) * 64 + lane + 32] == last));
+        p.tie_val[(size_t)uidx * p.nsplit + blockIdx.y] = tie ? last : __builtin_nanf("");
     }
-    if (tie && uvalid) atomicOr(&p.tie_flags[uidx], 1);
 }
 
 constexpr int grouped_tiles_per_stage(int E) { return E <= 32 ? 16 : (E == 64 ? 8 : (E == 128 ? 4 : 2)); }   // 64 KiB stages
@@ -1027,7 +1044,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
     __syncthreads();
 
     v16f acc;
-    unsigned long long tie_mask = 0ull;                    // lanes whose list met a tie at its boundary
+    unsigned long long tie_mask = 0ull;                    // lanes with a tie event at their list's present last value (tie_update)
     for (int64_t s = 0; s < nstages; ++s) {
         const int buf = (int)(s & 1);
         if (s + 1 < nstages) issue_stage(s + 1, buf ^ 1);
@@ -1094,7 +1111,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
                     const float old_last = rs[KR - 1];
                     sorted_insert<KR>(rs, ri, v, sbase + (r & 3) + 8 * (r >> 2));
                     thr = rs[KR - 1];
-                    tie_mask |= __ballot(tie_at_boundary(v, old_last, thr));
+                    tie_mask = tie_update(tie_mask, v, old_last, thr);
                 }
             }
         }
@@ -1201,7 +1218,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
 
     const int key = (j / RPB) & (S8 - 1);                  // this lane's row swizzle (same for hi and lo rows)
     v16f acc;
-    unsigned long long tie_mask = 0ull;                    // lanes whose list met a tie at its boundary
+    unsigned long long tie_mask = 0ull;                    // lanes with a tie event at their list's present last value (tie_update)
 #if M2D_DIAG & 16
     unsigned long long t_mfma = 0, t_epi = 0, t_bar = 0, t_slow = 0, n_slow = 0, n_tile = 0, t0_, t1_;
     STAMP(t0_);
@@ -1296,7 +1313,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
                 if (m[r] != 0ull) {
                     const float old_last = rs[KR - 1];
                     sorted_insert<KR>(rs, ri, acc[r], sbase + (r & 3) + 8 * (r >> 2));
-                    tie_mask |= __ballot(tie_at_boundary(acc[r], old_last, rs[KR - 1]));
+                    tie_mask = tie_update(tie_mask, acc[r], old_last, rs[KR - 1]);
                 }
             }
             thr = rs[KR - 1];
@@ -1442,7 +1459,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         alpha[g] = alpha_prev[g] = 0.f;
     }
     bool pend = false;                                     // wave-uniform: some (px, pid) waits to be inserted
-    unsigned long long tie_mask[G];                        // lanes whose list met a tie at its boundary (tie_at_boundary)
+    unsigned long long tie_mask[G];                        // lanes with a tie event at their list's present last value (tie_update)
 #pragma unroll
     for (int g = 0; g < G; ++g) tie_mask[g] = 0ull;
 
@@ -1577,7 +1594,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         if constexpr (INS) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                tie_mask[g] |= __ballot(tie_at_boundary(x[g], old_last[g], rs[g][KR - 1]));
+                tie_mask[g] = tie_update(tie_mask[g], x[g], old_last[g], rs[g][KR - 1]);
                 share_threshold(g);
             }
         }
@@ -1705,7 +1722,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
                         if (m[g][r] != 0ull) {
                             const float ol = rs[g][KR - 1], xv = accP[g][r] + alpha_prev[g];
                             sorted_insert_inplace<KR>(rs[g], ri[g], xv, sbase + (r & 3) + 8 * (r >> 2));
-                            tie_mask[g] |= __ballot(tie_at_boundary(xv, ol, rs[g][KR - 1]));
+                            tie_mask[g] = tie_update(tie_mask[g], xv, ol, rs[g][KR - 1]);
                         }
                     }
                     share_threshold(g);
@@ -1739,7 +1756,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         for (int g = 0; g < G; ++g) {
             const float ol = rs[g][KR - 1];
             sorted_insert_inplace<KR>(rs[g], ri[g], px[g], pid[g]);
-            tie_mask[g] |= __ballot(tie_at_boundary(px[g], ol, rs[g][KR - 1]));
+            tie_mask[g] = tie_update(tie_mask[g], fmaxf(px[g], -INFINITY), ol, rs[g][KR - 1]);
         }
     }
     wait_all_vmem();                                       // no LDS-DMA may land after the lists are published below
@@ -1822,12 +1839,12 @@ int ensure_grouped(m2d_engine *h, hipStream_t st)
 }
 
 void m2d_launch_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k, float *out_s, int32_t *out_i,
-                             hipStream_t st, int32_t *tie_flags = nullptr, int64_t flag_div = 1)
+                             hipStream_t st, const float *tie_in = nullptr, float *tie_out = nullptr)
 {
     int lpu = 1;
     while (lpu < nsplit) lpu <<= 1;
     const unsigned grid = (unsigned)((nU * lpu + 255) / 256);
-#define M2D_MERGE(L) if (lpu == L) hipLaunchKernelGGL(m2d_topk_merge_splits<L>, dim3(grid), dim3(256), 0, st, ps, pi, nU, nsplit, k, out_s, out_i, tie_flags, flag_div);
+#define M2D_MERGE(L) if (lpu == L) hipLaunchKernelGGL(m2d_topk_merge_splits<L>, dim3(grid), dim3(256), 0, st, ps, pi, nU, nsplit, k, out_s, out_i, tie_in, tie_out);
     M2D_MERGE(1) M2D_MERGE(2) M2D_MERGE(4) M2D_MERGE(8) M2D_MERGE(16) M2D_MERGE(32) M2D_MERGE(64)
 #undef M2D_MERGE
 }
@@ -1836,16 +1853,18 @@ void m2d_launch_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int
 // "user" of that pass is one (user, group)), then the per-group winners.  nsplit must be a multiple of 64 then;
 // tmp_s / tmp_i hold nU * (nsplit / 64) * k entries.  Consecutive groups are consecutive dish ranges, so the
 // lower-split-wins tie rule carries through both passes.
+// tie: [nU * nsplit] values of the splits, then room for the nU * (nsplit / 64) of the first pass, then the nU final ones
 void m2d_launch_merge_splits2(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k, float *tmp_s, int32_t *tmp_i,
-                              float *out_s, int32_t *out_i, hipStream_t st, int32_t *tie_flags)
+                              float *out_s, int32_t *out_i, hipStream_t st, float *tie, float *tie_final)
 {
     if (nsplit <= 64) {
-        m2d_launch_merge_splits(ps, pi, nU, nsplit, k, out_s, out_i, st, tie_flags, 1);
+        m2d_launch_merge_splits(ps, pi, nU, nsplit, k, out_s, out_i, st, tie, tie_final);
         return;
     }
     const int G = nsplit / 64;
-    m2d_launch_merge_splits(ps, pi, nU * G, 64, k, tmp_s, tmp_i, st, tie_flags, G);      // a "user" of this pass is (user, group)
-    m2d_launch_merge_splits(tmp_s, tmp_i, nU, G, k, out_s, out_i, st, tie_flags, 1);
+    float *tie_mid = tie + (size_t)nU * nsplit;
+    m2d_launch_merge_splits(ps, pi, nU * G, 64, k, tmp_s, tmp_i, st, tie, tie_mid);      // a "user" of this pass is (user, group)
+    m2d_launch_merge_splits(tmp_s, tmp_i, nU, G, k, out_s, out_i, st, tie_mid, tie_final);
 }
 
 // shared tail of every MFMA retrieval launch: dish-range splits -> partial lists in scratch.  The grouped kernels run
@@ -1893,17 +1912,21 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     a.grp = h->grp_work + (size_t)((h->I + 255) / 256) * GRP_KEYS;
     a.users = users; a.nU = nU; a.U = h->U; a.user_base = h->user_base; a.k = k; a.tiles = h->grp_tiles;
     a.a = h->a; a.b = h->b; a.err = h->err_dev; a.dbg = g_m2d_diag_buffer; a.e_real = h->E;
-    if (h->topk_flags_cap < (size_t)nU) {
-        if (h->topk_flags) M2D_HIP_TRY(h, hipFree(h->topk_flags));
-        h->topk_flags = nullptr; h->topk_flags_cap = 0;
-        M2D_HIP_TRY(h, hipMalloc((void **)&h->topk_flags, (size_t)nU * sizeof(int32_t)));
-        h->topk_flags_cap = (size_t)nU;
-    }
-    M2D_HIP_TRY(h, hipMemsetAsync(h->topk_flags, 0, (size_t)nU * sizeof(int32_t), st));
-    a.tie_flags = h->topk_flags;
     const int64_t ublocks = (nU + 32 * WAVES - 1) / (32 * WAVES);
     const int nsplit = pick_splits(h, ublocks, a.tiles, 2 * TPS, 512);
     a.nsplit = nsplit;
+    // tie values (floats): per (user, split), per (user, group of 64 splits) when the merge takes two passes, per user
+    const size_t tie_need = (size_t)nU * (nsplit > 1 ? nsplit + (nsplit > 64 ? nsplit / 64 : 0) + 1 : 1);
+    if (h->topk_flags_cap < tie_need) {
+        if (h->topk_flags) M2D_HIP_TRY(h, hipFree(h->topk_flags));
+        h->topk_flags = nullptr; h->topk_flags_cap = 0;
+        M2D_HIP_TRY(h, hipMalloc((void **)&h->topk_flags, tie_need * sizeof(float)));
+        h->topk_flags_cap = tie_need;
+    }
+    float *tie_final = h->topk_flags + (nsplit > 1 ? (size_t)nU * (nsplit + (nsplit > 64 ? nsplit / 64 : 0)) : 0);
+    a.tie_val = h->topk_flags;
+    h->topk_tie_final = tie_final;
+    h->topk_flags_used = nU;
     const size_t tmp_entries = nsplit > 64 ? (size_t)nU * (nsplit / 64) * k : 0;
     if (nsplit > 1) {
         const size_t need = ((size_t)nU * nsplit * k + tmp_entries) * 8 + 256;
@@ -1946,13 +1969,13 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     }
     M2D_HIP_TRY(h, hipGetLastError());
     if (nsplit > 1) {
-        m2d_launch_merge_splits2(a.out_scores, a.out_ids, nU, nsplit, k, tmp_s, tmp_i, final_s, final_i, st, h->topk_flags);
+        m2d_launch_merge_splits2(a.out_scores, a.out_ids, nU, nsplit, k, tmp_s, tmp_i, final_s, final_i, st, h->topk_flags, tie_final);
         M2D_HIP_TRY(h, hipGetLastError());
     }
     {   // users whose lists met a tie at a boundary: re-ranked in dish-id order (nothing to do is the common case)
         RepairArgs r;
         r.pm = h->pm; r.re = h->re; r.ce = h->ce; r.cats = h->dish_cats; r.hv = HV ? h->dish_high : nullptr;
-        r.users = users; r.flags = h->topk_flags; r.nU = nU; r.U = h->U; r.I = h->I; r.user_base = h->user_base;
+        r.users = users; r.tie_val = tie_final; r.nU = nU; r.U = h->U; r.I = h->I; r.user_base = h->user_base;
         r.C = h->C; r.E = h->E; r.k = k; r.a = h->a; r.b = h->b; r.out_scores = final_s; r.out_ids = final_i;
         const size_t rlds = ((size_t)(2 * h->C + 1) * h->E + (size_t)2 * 256 * k) * sizeof(float);
         const int64_t rgrid = nU < (int64_t)h->num_cu * 4 ? nU : (int64_t)h->num_cu * 4;

@@ -91,8 +91,10 @@ struct m2d_engine {
     // scratch for rank_candidates
     float *scratch = nullptr;
     size_t scratch_bytes = 0;
-    int32_t *topk_flags = nullptr;      // [users of a call] pattern-grouped retrieval: "met a tie at a list boundary" (re-ranked in id order)
-    size_t topk_flags_cap = 0;
+    float *topk_flags = nullptr;        // pattern-grouped retrieval: tie values per (user, split) / per user (NaN: no tie at the k-th score)
+    size_t topk_flags_cap = 0;          // floats
+    float *topk_tie_final = nullptr;    // the per-user values of the last call, inside topk_flags
+    int64_t topk_flags_used = 0;        // users of the last pattern-grouped call (get_option "topk_repaired" counts the non-NaN values)
 
     // benchmarking knobs
     int opt_prefetch = 2;

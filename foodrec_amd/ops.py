@@ -344,12 +344,21 @@ class ScoringEngine:
 
     def topk_users(self, users: torch.Tensor, k: int):
         """users i32[nU] -> (scores f32[nU, k], dish ids i32[nU, k]) over the whole catalogue."""
+        nU = users.numel()
+        out_s = torch.empty((nU, k), dtype=torch.float32, device=self.device)
+        out_i = torch.empty((nU, k), dtype=torch.int32, device=self.device)
+        return self.topk_users_into(users, k, out_s, out_i)
+
+    def topk_users_into(self, users: torch.Tensor, k: int, out_s: torch.Tensor, out_i: torch.Tensor):
+        """topk_users into caller-owned contiguous buffers f32[nU, k] / i32[nU, k] (slices of a larger result)."""
         if users.dtype != torch.int32 or users.device != self.device:
             raise TypeError("topk_users: users must be an int32 tensor on %s" % self.device)
         users = users.contiguous()
         nU = users.numel()
-        out_s = torch.empty((nU, k), dtype=torch.float32, device=self.device)
-        out_i = torch.empty((nU, k), dtype=torch.int32, device=self.device)
+        if (tuple(out_s.shape) != (nU, k) or tuple(out_i.shape) != (nU, k) or out_s.dtype != torch.float32 or
+                out_i.dtype != torch.int32 or not out_s.is_contiguous() or not out_i.is_contiguous() or
+                out_s.device != self.device or out_i.device != self.device):
+            raise ValueError("topk_users_into: need contiguous f32[%d, %d] / i32[%d, %d] buffers on %s" % (nU, k, nU, k, self.device))
         with torch.cuda.device(self.device):
             rc = _native.lib().m2d_topk_users(self._h, users.data_ptr(), nU, k, out_s.data_ptr(), out_i.data_ptr(),
                                               _stream_ptr())

@@ -178,6 +178,24 @@ class UserShardedScorer:
                     torch.empty((0, k), dtype=torch.int32, device=self.device))
         return self.scorer.topk_users(users, k)
 
+    def topk_local_rounds(self, k: int, round_users: int = 65536):
+        """Top-k for EVERY user of this shard, computed in rounds of `round_users` users -- a launch and its scratch stay
+        the same size whatever the shard holds (1.25 M users per GPU at BASELINE configs[3]) -- into one pair of
+        ``[count, k]`` buffers: (scores f32, dish ids i32)."""
+        s = torch.empty((self.count, k), dtype=torch.float32, device=self.device)
+        ids = torch.empty((self.count, k), dtype=torch.int32, device=self.device)
+        into = getattr(self.scorer, "topk_users_into", None)          # ScoringEngine: straight into the slices, no copy
+        for lo in range(0, self.count, int(round_users)):
+            n = min(int(round_users), self.count - lo)
+            users = torch.arange(self.base + lo, self.base + lo + n, dtype=torch.int32, device=self.device)
+            if into is not None:
+                into(users, k, s[lo:lo + n], ids[lo:lo + n])
+            else:
+                rs, ri = self.scorer.topk_users(users, k)
+                s[lo:lo + n] = rs
+                ids[lo:lo + n] = ri
+        return s, ids
+
     def _gather_topk(self, s: torch.Tensor, ids: torch.Tensor, rows: int, k: int):
         """One all-gather of ``[rows, k] x (f32 score, i32 id)`` per rank; scores and ids travel in one int32 buffer.
         Ranks with fewer than `rows` results pad with (NaN, -1)."""
@@ -201,10 +219,11 @@ class UserShardedScorer:
             return s, ids
         return self._gather_topk(s, ids, users.numel(), k)
 
-    def topk_all_users(self, k: int):
+    def topk_all_users(self, k: int, round_users: Optional[int] = None):
         """Per-user top-k for EVERY user, on every rank: one all-gather of ``[shard, k] x (f32, i32)``.
-        Shards are padded to the common size ``per`` for the collective and trimmed afterwards."""
-        s, ids = self.topk_local(k)
+        Shards are padded to the common size ``per`` for the collective and trimmed afterwards.  `round_users`: the
+        local part runs in rounds of that many users (`topk_local_rounds`)."""
+        s, ids = self.topk_local_rounds(k, round_users) if round_users else self.topk_local(k)
         if self._solo:
             return s, ids
         gs, gi = self._gather_topk(s, ids, self.per, k)

@@ -28,9 +28,13 @@ def main():
     for r in rows(os.path.join(out, "stats", "**", "*kernel_trace.csv")):
         name = r.get("Kernel_Name", "")
         dur[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    order = defaultdict(list)
+    for r in rows(os.path.join(out, "stats", "**", "*kernel_trace.csv")):
+        order[r.get("Kernel_Name", "")].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     for name, d in dur.items():
+        last = [x[1] for x in sorted(order[name])[-10:]]          # the warm launches: the last 10 dispatches of the kernel
         summ["kernels"][name] = {"calls": len(d), "avg_us": sum(d) / len(d) / 1e3, "min_us": min(d) / 1e3,
-                                 "max_us": max(d) / 1e3, "total_ms": sum(d) / 1e6}
+                                 "max_us": max(d) / 1e3, "total_ms": sum(d) / 1e6, "last10_avg_us": sum(last) / len(last) / 1e3}
     # counters: average per dispatch per kernel
     for d in glob.glob(os.path.join(out, "pmc_*")):
         if not os.path.isdir(d):
@@ -57,12 +61,36 @@ def main():
         summ["bench_line"] = json.loads(open(os.path.join(out, "stats_bench.json")).read().strip().splitlines()[-1])
     except Exception as e:                                             # noqa: BLE001
         summ["bench_line"] = "unavailable: %s" % e
+    # MFMA profile (scripts/prof_mfma.py): the roofline fractions of its JSON, recomputed from the kernel trace
+    try:
+        mb = json.load(open(os.path.join(out, "mfma_bench.json")))
+        summ["mfma_bench"] = mb
+        summ["mfma_fractions_from_trace"] = {}
+        for key, v in mb.items():
+            base = {"m2d_topk_grouped_bf16x3": "m2d_topk_grouped_bf16_pipe2", "m2d_topk_grouped": "m2d_topk_grouped<",
+                    "m2d_mlp_pc_bf16x3": "m2d_mlp_pc<"}.get(v["kernel"], v["kernel"])
+            cands = [(n, k) for n, k in summ["kernels"].items() if base in n and "merge" not in n]
+            if not cands:
+                continue
+            n, k = max(cands, key=lambda nk: nk[1]["total_ms"])
+            frac = v["executed_flop_per_launch"] / (k["last10_avg_us"] * 1e-6) / 1e12 / v["peak_TFLOPs"]
+            summ["mfma_fractions_from_trace"][key] = {"trace_kernel": n, "trace_last10_avg_us": k["last10_avg_us"],
+                                                      "event_avg_ms": v["event_avg_ms"], "frac_from_trace": frac,
+                                                      "frac_from_events": v["frac_of_peak"]}
+    except Exception:                                                  # noqa: BLE001
+        pass
     with open(os.path.join(out, "summary.json"), "w") as f:
         json.dump(summ, f, indent=1)
     with open(os.path.join(out, "summary.md"), "w") as f:
-        f.write("# rocprofv3 summary %s\n\n| kernel | calls | avg us | min us | max us |\n|---|---|---|---|---|\n" % tag)
+        f.write("# rocprofv3 summary %s\n\n| kernel | calls | avg us | min us | max us | avg of last 10 us |\n|---|---|---|---|---|---|\n" % tag)
         for k, v in sorted(summ["kernels"].items(), key=lambda kv: -kv[1]["total_ms"]):
-            f.write("| %s | %d | %.1f | %.1f | %.1f |\n" % (k[:90], v["calls"], v["avg_us"], v["min_us"], v["max_us"]))
+            f.write("| %s | %d | %.1f | %.1f | %.1f | %.1f |\n" % (k[:90], v["calls"], v["avg_us"], v["min_us"], v["max_us"], v["last10_avg_us"]))
+        if summ.get("mfma_fractions_from_trace"):
+            f.write("\n## roofline fractions, recomputed from the trace (executed flop per launch / last-10 average / peak)\n\n"
+                    "| leg | kernel | trace last-10 avg us | HIP-event avg ms | frac from trace | frac from events |\n|---|---|---|---|---|---|\n")
+            for key, v in summ["mfma_fractions_from_trace"].items():
+                f.write("| %s | %s | %.1f | %.3f | %.3f | %.3f |\n" % (key, v["trace_kernel"][:60], v["trace_last10_avg_us"], v["event_avg_ms"],
+                                                                    v["frac_from_trace"], v["frac_from_events"]))
         f.write("\n## counters (average per dispatch)\n\n")
         for k, cs in summ["counters"].items():
             f.write("### %s\n\n" % k[:120])

@@ -83,3 +83,80 @@ def test_launch_command_is_the_drivers(monkeypatch):
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "5"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+# ---- the N > 1 legs of bench.py on CPU: two gloo ranks, an oracle double per shard -------------------------------------
+def _legs_worker(rank, world, port, out_dir):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import random_case
+    from test_sharding_gloo import OracleShard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from foodrec_amd.sharding import UserShardedScorer, shard_range
+        b = _bench()
+        U_per, I, C, E, k = 23, 40, 4, 16, 5
+        U = world * U_per
+        PM, RE, CE, *_ = random_case(U, I, C, E, 1, seed=3, zero_rows=False)
+        base, count = shard_range(U, world, rank)
+
+        class Double(OracleShard):          # what the legs ask of a ScoringEngine beyond the sharding tests' double
+            def set_dish_categories(self, cats):
+                self.dish_cats = cats.numpy()
+
+            def last_kernel(self):
+                return "oracle double"
+
+        dish_cats = np.ones((I, C), np.float32)
+        eng = Double(PM, RE, CE, dish_cats, base, count)
+        dev = torch.device("cpu")
+        # (i) the leg every line carries: n users of each shard, one all-gather
+        r1 = b.sharded_topk_leg(torch, dist, eng, U_per, I, C, E, dev, base, 9, world, k=k, repeats=2)
+        for key in ("users_per_gpu", "wall_ms_median", "topk_ms_median", "allgather_ms_median", "allgather_bytes_per_rank",
+                    "pairs_per_s_whole_job", "own_slice_roundtrip_ok", "kernel"):
+            assert key in r1, key
+        assert r1["own_slice_roundtrip_ok"] is True and r1["allgather_bytes_per_rank"] == 9 * k * 8
+        assert r1["pairs_per_s_whole_job"] > 0
+        # (ii) scaling_path's leg: EVERY user of the shard in rounds (here of 7 users: 4 rounds), one all-gather
+        sh = UserShardedScorer(eng, U, device=dev, always_collective=True)
+        r2 = b.sharded_all_users_leg(torch, dist, sh, I, k, round_users=7, repeats=2)
+        for key in ("path", "users_total", "users_per_gpu", "rounds_per_gpu", "wall_ms", "topk_ms", "allgather_ms",
+                    "allgather_bytes_per_rank", "pairs_per_s_whole_job", "own_slice_roundtrip_ok"):
+            assert key in r2, key
+        assert r2["path"] == "sharded_topk_allgather" and r2["rounds_per_gpu"] == 4 and r2["users_total"] == U
+        assert r2["own_slice_roundtrip_ok"] is True and r2["allgather_bytes_per_rank"] == U_per * k * 8
+        # what the rounds produce is what one call produces, on every rank
+        s_all, i_all = sh.topk_all_users(k, round_users=7)
+        s_one, i_one = sh.topk_all_users(k)
+        assert torch.equal(i_all, i_one) and torch.equal(s_all, s_one) and i_all.shape == (U, k)
+        # (iii) pairs routed to the owners of their users
+        r3 = b.routed_pairs_leg(torch, dist, eng, U_per, I, C, dev, world, 300, repeats=2)
+        for key in ("pairs_per_gpu", "wall_ms_median", "pairs_per_s_whole_job", "own_pairs_match_local_scoring"):
+            assert key in r3, key
+        assert r3["own_pairs_match_local_scoring"] is True
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_multi_gpu_legs_run_over_gloo_with_an_oracle_double(tmp_path):
+    """sharded_topk_leg / sharded_all_users_leg (the `scaling_path` block) / routed_pairs_leg at world 2 on CPU: the keys
+    a line carries are there and every rank gets its own slice back through the collectives."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_legs_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(os.path.join(tmp_path, "ok%d" % r)) for r in range(2))
+
+
+def test_side_leg_watchdog_exits_nonzero():
+    """A leg that never returns must not read as a clean run: the line is printed, the exit status is 4 and the record
+    names the leg and rank in flight (bench.py::give_up)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "os._exit(4)" in src and "os._exit(0)" not in src
+    assert '"leg_in_flight": in_flight["leg"]' in src
