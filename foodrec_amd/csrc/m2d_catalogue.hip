@@ -28,6 +28,9 @@
 #ifndef M2D_DIAG
 #define M2D_DIAG 0
 #endif
+#ifndef M2D_TIE_EXP
+#define M2D_TIE_EXP 0
+#endif
 static unsigned long long *g_m2d_diag_buffer = nullptr;   // set by scripts/diag only
 #if M2D_DIAG & 16
 #define STAMP(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
@@ -536,8 +539,10 @@ __global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, co
     // by split order (the scan order of the pattern-grouped kernels), not by dish id.  The dense kernels pass no tie_in.
     if (tie_in) {
         const bool t = live && last_i >= 0 && ((hi >= 0 && hs == last) || tie_in[(size_t)u * nsplit + w] == last);
-        const unsigned long long grp = (LPU == 64 ? ~0ull : ((1ull << LPU) - 1ull)) << (lane & ~(LPU - 1));
-        const bool any = (__ballot(t) & grp) != 0ull;
+        int tv = t ? 1 : 0;
+#pragma unroll
+        for (int off = LPU / 2; off >= 1; off >>= 1) tv |= __shfl_xor(tv, off, 64);
+        const bool any = tv != 0;
         if (u < nU && w == 0) tie_out[u] = any ? last : __builtin_nanf("");
     }
 }
@@ -573,25 +578,201 @@ __global__ void m2d_topk_fill_absent(float *scores, int32_t *ids, int64_t nU, in
     }
 }
 
-// Flagged users (a tie at a list boundary of a pattern-grouped kernel, see tie_at_boundary): the whole catalogue again
-// in dish-id order with the reference formula in plain f32 -- Model_Recommender.py:67-96 term by term, as the pair
-// kernels compute it -- and a strict insertion, so equal scores keep the lower id exactly as heapq.nlargest does.
-// One block per flagged user (blocks walk the user list and look at the flags: no compaction, nothing to do is the
-// common case), a thread takes every 256th dish and keeps its own top-k in LDS, the 256 lists are merged by k rounds
-// of a block-wide argmax on (score desc, id asc).  Rare by construction -- an all-zero Personal_Memory block, rows
-// that score whole groups identically -- so it is written for clarity, not speed (100 k dishes, E = 64: ~0.1 ms a user).
+// Users whose final k-th score is tied with a score that was left out (tie_list: a count and their positions in the
+// call, gathered from the final tie values by m2d_topk_tie_compact): the whole catalogue again in dish-id order, in plain
+// f32 -- Model_Recommender.py:67-96 with the sums over a 0/1 mask's categories taken first -- and a strict insertion, so
+// equal scores keep the lower id exactly as heapq.nlargest does (evaluate.py:63).  On N(0, 1/E) tables
+// about one user in ten thousand (two f32 scores at the edge of a list are bit-equal); every user of an all-zero
+// Personal_Memory table.
+//   m2d_topk_repair_scan   block (dish range sp of REPAIR_SPLITS, listed user f): 64 groups of 16 lanes take a dish each,
+//                          a float4 column per lane (coalesced 256-B row reads), and keep a private top-k in LDS; the
+//                          block's 64 lists are merged into the partial list of (f, sp);
+//   m2d_topk_repair_merge  one wave per listed user: its REPAIR_SPLITS partial lists -> the final list.
+// Users beyond the REPAIR_CAP the scratch holds (degenerate tables) are done by m2d_topk_repair_rest, one block each.
+constexpr int REPAIR_SPLITS = 64, REPAIR_CAP = 1024;
+
+// the users whose final tie value is set (not NaN), as a list: [0] count, [1 + f] position in the call
+__global__ __launch_bounds__(256) void m2d_topk_tie_compact(const float *tie_final, int64_t nU, int32_t *tie_list)
+{
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u < nU && tie_final[u] == tie_final[u]) tie_list[1 + atomicAdd(&tie_list[0], 1)] = (int32_t)u;
+}
+
 struct RepairArgs {
     const float *pm, *re, *ce, *cats, *hv;      // hv: per-dish high-level vectors of the ingredient extension, or null
     const int32_t *users;
-    const float *tie_val;                       // [nU] NaN: nothing to do
+    const int32_t *tie_list;                    // [0] listed users, [1 + f] position of listed user f in the call
     int64_t nU, U, I, user_base;
     int32_t C, E, k;
+    int32_t cap;                                // listed users the scan / merge pair handles (the rest: m2d_topk_repair_rest)
     float a, b;
+    float *part_s;                              // [cap, REPAIR_SPLITS, k] partial lists
+    int32_t *part_i;
     float *out_scores;                          // [nU, k]
     int32_t *out_ids;
 };
 
-__global__ __launch_bounds__(256) void m2d_topk_repair_ties(RepairArgs p)
+__device__ __forceinline__ bool repair_ahead(float s, int32_t i, float t, int32_t j)
+{
+    return i >= 0 && (j < 0 || s > t || (s == t && i < j));       // (score desc, id asc); id < 0: no entry
+}
+
+__global__ __launch_bounds__(1024) void m2d_topk_repair_scan(RepairArgs p)
+{
+    extern __shared__ __align__(16) float rsm[];
+    constexpr int C = 4, NG = 64, NP = 1 << C, ND = 2;      // C = 4 (as the pattern-grouped kernels); 64 groups of 16 lanes; ND dishes in flight per group
+    const int E = p.E, E4 = E >> 2, k = p.k, W = (C + 1) * E;
+    float *um = rsm;                                        // [(C+1) E] this user's block
+    float *wp = um + W;                                     // [NP][E]   sum of the pattern's low-level rows (0/1 masks: :82 summed over c)
+    float *ls = wp + NP * E;                                // [NG groups][k] scores
+    int32_t *li = reinterpret_cast<int32_t *>(ls + NG * k);
+    __shared__ float hc[C], alpha[NP];                      // <U_high, CE_c>; sum over the pattern's categories (:67-75)
+    const int t = threadIdx.x, lane = t & 63, j = lane & 15, grp = t >> 4;
+    const int count = min(p.tie_list[0], p.cap);
+    const int64_t per = (p.I + REPAIR_SPLITS - 1) / REPAIR_SPLITS;
+    const int64_t d0 = (int64_t)blockIdx.x * per, d1 = min(p.I, d0 + per);
+    for (int f = blockIdx.y; f < count; f += gridDim.y) {   // block-uniform
+        const int64_t u = p.tie_list[1 + f];
+        int64_t ul = (int64_t)p.users[u] - p.user_base;
+        if (ul < 0 || ul >= p.U) ul = 0;                    // latched by the scan kernel
+        __syncthreads();
+        for (int i = t; i < W; i += 1024) um[i] = p.pm[(size_t)ul * W + i];
+        // a group's running top-16 lives in its 16 lanes, slot j in lane j (k <= 16): an insertion is two compares and two
+        // selects per lane against the lane's own slot and its left neighbour's (DPP row_shr:1), no LDS, no serial walk
+        float slot_s = -INFINITY;
+        int32_t slot_i = -1;
+        __syncthreads();
+        // the masks are 0/1 (the pattern-grouped kernels run for nothing else): a dish's terms depend on its pattern P only
+        //   high = sum_{c in P} <U_high, CE_c> / n_P        low = < RE[d], sum_{c in P} U_low,c > / n_P
+        for (int i = t; i < NP * E; i += 1024) {
+            const int pt = i / E, e = i - pt * E;
+            float w = 0.f;
+            for (int c = 0; c < C; ++c) w += ((pt >> c) & 1) ? um[(c + 1) * E + e] : 0.f;
+            wp[i] = w;
+        }
+        if (t < C * 64) {                                   // wave c: <U_high, CE_c>
+            const int c = t >> 6;
+            float q = 0.f;
+            for (int e = lane; e < E; e += 64) q = fmaf(um[e], p.ce[(size_t)c * E + e], q);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+            if (lane == 0) hc[c] = q;
+        }
+        __syncthreads();
+        if (t < NP) {
+            float x = 0.f;
+            for (int c = 0; c < C; ++c) x += ((t >> c) & 1) ? hc[c] : 0.f;
+            alpha[t] = x;
+        }
+        __syncthreads();
+        const v4f *um4 = reinterpret_cast<const v4f *>(um), *wp4 = reinterpret_cast<const v4f *>(wp);
+        for (int64_t db = d0; db < d1; db += ND * NG) {     // wave-uniform trip count: the shuffles see a full EXEC
+            int64_t dd[ND];
+            bool ok[ND];
+            int pt[ND];
+            float hs[ND], lo[ND];
+#pragma unroll
+            for (int x = 0; x < ND; ++x) {
+                const int64_t d = db + x * NG + grp;
+                ok[x] = d < d1;
+                dd[x] = ok[x] ? d : d0;
+                const v4f m = *reinterpret_cast<const v4f *>(p.cats + (size_t)dd[x] * C);
+                pt[x] = (m.x != 0.f ? 1 : 0) | (m.y != 0.f ? 2 : 0) | (m.z != 0.f ? 4 : 0) | (m.w != 0.f ? 8 : 0);
+                hs[x] = lo[x] = 0.f;
+            }
+            for (int q = j; q < E4; q += 16) {
+                v4f it[ND], hvv[ND];
+#pragma unroll
+                for (int x = 0; x < ND; ++x) {
+                    it[x] = reinterpret_cast<const v4f *>(p.re)[(size_t)dd[x] * E4 + q];
+                    if (p.hv) hvv[x] = reinterpret_cast<const v4f *>(p.hv)[(size_t)dd[x] * E4 + q];
+                }
+                const v4f uh = um4[q];
+#pragma unroll
+                for (int x = 0; x < ND; ++x) {
+                    const v4f w = wp4[pt[x] * E4 + q];
+                    lo[x] = fmaf(it[x].x, w.x, fmaf(it[x].y, w.y, fmaf(it[x].z, w.z, fmaf(it[x].w, w.w, lo[x]))));
+                    if (p.hv) hs[x] = fmaf(uh.x, hvv[x].x, fmaf(uh.y, hvv[x].y, fmaf(uh.z, hvv[x].z, fmaf(uh.w, hvv[x].w, hs[x]))));
+                }
+            }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {
+#pragma unroll
+                for (int x = 0; x < ND; ++x) {
+                    lo[x] += __shfl_xor(lo[x], off, 64);
+                    if (p.hv) hs[x] += __shfl_xor(hs[x], off, 64);
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < ND; ++x) {                  // ascending id inside a group: x = 0 first
+                const float n = (float)__builtin_popcount(pt[x]);                            // :77 (an empty mask: 0 / 0 = NaN, never enters)
+                float sc = __fadd_rn(__fmul_rn(p.a, p.hv ? hs[x] : alpha[pt[x]] / n), __fmul_rn(p.b, lo[x] / n));   // :79, :92, :95-96
+                sc = ok[x] ? fmaxf(sc, -INFINITY) : -INFINITY;                               // NaN -> -inf: never enters
+                // left neighbour's slot (lane j - 1 of the same 16-lane row; lane 0 sees +inf / -1)
+                const float left_s = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, INFINITY),
+                                                        __builtin_bit_cast(int, slot_s), 0x111, 0xf, 0xf, false));
+                const int32_t left_i = __builtin_amdgcn_update_dpp(-1, slot_i, 0x111, 0xf, 0xf, false);
+                const bool above_left = sc > left_s, above_me = sc > slot_s;                 // strict: equal scores keep the earlier (lower) id first
+                slot_i = above_left ? left_i : (above_me ? (int32_t)dd[x] : slot_i);
+                slot_s = above_left ? left_s : (above_me ? sc : slot_s);
+            }
+        }
+        if (j < k) { ls[grp * k + j] = slot_s; li[grp * k + j] = slot_s > -INFINITY ? slot_i : -1; }
+        __syncthreads();
+        if (t < 64) {                                       // wave 0: the NG lists -> this block's partial list, (score desc, id asc)
+            int ptr = 0;
+            float *os = p.part_s + ((size_t)f * REPAIR_SPLITS + blockIdx.x) * k;
+            int32_t *oi = p.part_i + ((size_t)f * REPAIR_SPLITS + blockIdx.x) * k;
+            for (int o = 0; o < k; ++o) {
+                float bs = ptr < k ? ls[lane * k + ptr] : 0.f;
+                int32_t bi = ptr < k ? li[lane * k + ptr] : -1;
+                int bl = lane;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const float xs = __shfl_xor(bs, off, 64);
+                    const int32_t xi = __shfl_xor(bi, off, 64);
+                    const int xl = __shfl_xor(bl, off, 64);
+                    if (repair_ahead(xs, xi, bs, bi)) { bs = xs; bi = xi; bl = xl; }
+                }
+                if (lane == 0) { os[o] = bs; oi[o] = bi; }
+                if (bi >= 0 && bl == lane) ++ptr;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void m2d_topk_repair_merge(RepairArgs p)
+{
+    const int lane = threadIdx.x & 63, k = p.k;
+    const int count = min(p.tie_list[0], p.cap);
+    for (int f = blockIdx.x * 4 + (threadIdx.x >> 6); f < count; f += gridDim.x * 4) {     // wave-uniform
+        const int64_t u = p.tie_list[1 + f];
+        const bool live = lane < REPAIR_SPLITS;
+        const float *s = p.part_s + ((size_t)f * REPAIR_SPLITS + (live ? lane : 0)) * k;
+        const int32_t *id = p.part_i + ((size_t)f * REPAIR_SPLITS + (live ? lane : 0)) * k;
+        int ptr = 0;
+        for (int o = 0; o < k; ++o) {
+            float bs = (live && ptr < k) ? s[ptr] : 0.f;
+            int32_t bi = (live && ptr < k) ? id[ptr] : -1;
+            int bl = lane;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float xs = __shfl_xor(bs, off, 64);
+                const int32_t xi = __shfl_xor(bi, off, 64);
+                const int xl = __shfl_xor(bl, off, 64);
+                if (repair_ahead(xs, xi, bs, bi)) { bs = xs; bi = xi; bl = xl; }
+            }
+            if (lane == 0) {
+                p.out_scores[u * k + o] = bi >= 0 ? bs : __builtin_nanf("");
+                p.out_ids[u * k + o] = bi;
+            }
+            if (live && bi >= 0 && bl == lane) ++ptr;
+        }
+    }
+}
+
+// listed users p.cap, p.cap + 1, ...: one block each, a thread takes every 256th dish (slow; degenerate tables only)
+__global__ __launch_bounds__(256) void m2d_topk_repair_rest(RepairArgs p)
 {
     extern __shared__ __align__(16) float rsm[];
     const int C = p.C, E = p.E, k = p.k, W = (C + 1) * E;
@@ -602,9 +783,10 @@ __global__ __launch_bounds__(256) void m2d_topk_repair_ties(RepairArgs p)
     __shared__ float red_s[4];
     __shared__ int32_t red_i[4], red_t[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int count = p.tie_list[0];
     for (int i = t; i < C * E; i += 256) cem[i] = p.ce[i];
-    for (int64_t u = blockIdx.x; u < p.nU; u += gridDim.x) {
-        if (p.tie_val[u] != p.tie_val[u]) continue;         // NaN: no tie at this user's k-th score (block-uniform)
+    for (int f = p.cap + blockIdx.x; f < count; f += gridDim.x) {     // block-uniform
+        const int64_t u = p.tie_list[1 + f];
         int64_t ul = (int64_t)p.users[u] - p.user_base;
         if (ul < 0 || ul >= p.U) ul = 0;                    // latched by the scan kernel
         __syncthreads();
@@ -638,15 +820,15 @@ __global__ __launch_bounds__(256) void m2d_topk_repair_ties(RepairArgs p)
         __syncthreads();
         int ptr = 0;
         for (int o = 0; o < k; ++o) {
-            float bs = ptr < k ? ms[ptr] : -INFINITY;
+            float bs = ptr < k ? ms[ptr] : 0.f;
             int32_t bi = ptr < k ? mi[ptr] : -1;
             int bt = t;
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) {
-                const float os = __shfl_xor(bs, off, 64);
-                const int32_t oi = __shfl_xor(bi, off, 64);
-                const int ot = __shfl_xor(bt, off, 64);
-                if (oi >= 0 && (bi < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; bt = ot; }
+                const float xs = __shfl_xor(bs, off, 64);
+                const int32_t xi = __shfl_xor(bi, off, 64);
+                const int xt = __shfl_xor(bt, off, 64);
+                if (repair_ahead(xs, xi, bs, bi)) { bs = xs; bi = xi; bt = xt; }
             }
             if (lane == 0) { red_s[wave] = bs; red_i[wave] = bi; red_t[wave] = bt; }
             __syncthreads();
@@ -654,7 +836,7 @@ __global__ __launch_bounds__(256) void m2d_topk_repair_ties(RepairArgs p)
             int32_t fi = red_i[0];
             int ft = red_t[0];
             for (int w = 1; w < 4; ++w)
-                if (red_i[w] >= 0 && (fi < 0 || red_s[w] > fs || (red_s[w] == fs && red_i[w] < fi))) { fs = red_s[w]; fi = red_i[w]; ft = red_t[w]; }
+                if (repair_ahead(red_s[w], red_i[w], fs, fi)) { fs = red_s[w]; fi = red_i[w]; ft = red_t[w]; }
             if (t == 0) {
                 p.out_scores[u * k + o] = fi >= 0 ? fs : __builtin_nanf("");
                 p.out_ids[u * k + o] = fi;
@@ -704,7 +886,8 @@ constexpr int GRP_KEYS = GRP_MAXPAT * GRP_NB;   // sort key = pattern * GRP_NB +
 // layout of the small `grp` table behind the block histograms (int32 words):
 //   [0..15] first slot of each pattern's group   [16] tiles  [17] slots  [32] flags   [40..55] rows per pattern
 //   [64..64+GRP_KEYS) first slot of each (pattern, bucket) key        [GRP_STAT..+4) row-norm statistics (floats)
-constexpr int GRP_KEYOFF = 64, GRP_STAT = 64 + GRP_KEYS, GRP_WORDS = GRP_STAT + 8;
+//   [GRP_RMAX..+16) largest row norm of each pattern (float bits; scan-start threshold, grouped_threshold_seed)
+constexpr int GRP_KEYOFF = 64, GRP_STAT = 64 + GRP_KEYS, GRP_RMAX = GRP_STAT + 8, GRP_WORDS = GRP_RMAX + 16;
 
 // Inside a pattern group the dishes are scanned in descending order of their row norm, coarsely: 16 buckets of a
 // quarter standard deviation between mean + 2 sigma and mean - 2 sigma, dish id order inside a bucket.  A dish's score
@@ -758,7 +941,7 @@ __device__ __forceinline__ int grp_bucket(float nr, const float *stat)
 }
 
 __global__ __launch_bounds__(256) void m2d_grp_hist(const float *cats, const float *norm, const float *stat, int64_t I, int C,
-                                                    int32_t *blk_hist, int32_t *flags)
+                                                    int32_t *blk_hist, int32_t *flags, int32_t *rmax_bits)
 {
     __shared__ int sh[GRP_KEYS];
     sh[threadIdx.x] = 0;
@@ -774,6 +957,9 @@ __global__ __launch_bounds__(256) void m2d_grp_hist(const float *cats, const flo
             }
         }
         atomicAdd(&sh[pat * GRP_NB + grp_bucket(norm[d], stat)], 1);
+        // the pattern's largest row norm (non-negative floats order like their bit patterns; a NaN norm counts as +inf)
+        const float nr = norm[d];
+        atomicMax(&rmax_bits[pat], __float_as_int(nr == nr ? nr : INFINITY));
     }
     __syncthreads();
     blk_hist[(size_t)blockIdx.x * GRP_KEYS + threadIdx.x] = sh[threadIdx.x];
@@ -904,6 +1090,50 @@ struct GroupedArgs {
     float *tie_val;            // [nU, nsplit] the list's last score when a tie decides what it holds (tie_at_boundary), else NaN
 };
 
+// A threshold to start the scan from, known before any dish is scored.  With 0/1 masks score(u, d) = alpha_P[u] +
+// <w_P[u], RE[d]> >= alpha_P[u] - |w_P[u]| max_{d in P} |RE[d]| (Cauchy-Schwarz), so a pattern that holds at least k dishes
+// puts k scores at or above that bound, and the user's final k-th score cannot be below the largest such bound.  The
+// model blends 0.99 high level + 0.01 low level (Model_Recommender.py:95-96), so alpha_P dominates: for most users the
+// bound of their best pattern is above every score of the other fourteen, and the scan inserts half as often (110 -> 60
+// insertions per lane at 100 k dishes, scripts/diag/topk_scan_sim.py).  |w_P|^2 comes from the 4 x 4 Gram matrix of the
+// user's low-level rows; the margin covers the kernels' rounding (split-bf16 products: ~2e-5 of |w||r|).
+__device__ __forceinline__ float grouped_threshold_seed(const v4f *pmu, const int Sr, const float (&hc)[4], const GroupedArgs &p)
+{
+    float G[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) G[i] = 0.f;
+#pragma unroll 1
+    for (int q = 0; q < Sr; ++q) {
+        v4f u[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) u[c] = pmu[(c + 1) * Sr + q];
+        int i = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int d = c; d < 4; ++d, ++i) G[i] += (u[c].x * u[d].x + u[c].y * u[d].y) + (u[c].z * u[d].z + u[c].w * u[d].w);
+    }
+    float seed = -INFINITY;
+#pragma unroll 1
+    for (int pt = 1; pt < 16; ++pt) {
+        if (p.grp[40 + pt] < p.k) continue;                 // wave-uniform: fewer than k dishes carry this pattern
+        const float rmax = __int_as_float(p.grp[GRP_RMAX + pt]);
+        const float inv_n = 1.0f / (float)__builtin_popcount(pt);
+        float hs = 0.f, w2 = 0.f;
+        int i = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            hs += ((pt >> c) & 1) ? hc[c] : 0.f;
+#pragma unroll
+            for (int d = c; d < 4; ++d, ++i) w2 += (((pt >> c) & 1) && ((pt >> d) & 1)) ? (c == d ? G[i] : 2.f * G[i]) : 0.f;
+        }
+        const float alpha = p.a * (hs * inv_n);
+        const float reach = (p.b * inv_n) * sqrtf(fmaxf(w2, 0.f)) * rmax;
+        seed = fmaxf(seed, alpha - reach - (1e-4f * reach + 1e-6f * fabsf(alpha) + 1e-30f));     // a NaN / -inf bound is ignored
+    }
+    return seed;
+}
+
 // End of a pattern-grouped scan: the lane's register list goes to LDS with its slots translated to dish ids, the two
 // lanes of a user (l, l + 32) are merged into this split's sorted list of k, and the split's tie value is written: the
 // list's last score if a tie decides what the list holds -- a lane's tie event at that very value (tie_mask), or a
@@ -1021,7 +1251,8 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
         rs[i] = -INFINITY;
         ri[i] = -1;
     }
-    float thr = -INFINITY;
+    const float seed = grouped_threshold_seed(pmu, Sr, hc, p);
+    float thr = seed;
 
     const int64_t per = (p.tiles + p.nsplit - 1) / p.nsplit;
     const int64_t t_begin = (int64_t)blockIdx.y * per;
@@ -1110,8 +1341,8 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
                 if (__any(cand)) {
                     const float old_last = rs[KR - 1];
                     sorted_insert<KR>(rs, ri, v, sbase + (r & 3) + 8 * (r >> 2));
-                    thr = rs[KR - 1];
-                    tie_mask = tie_update(tie_mask, v, old_last, thr);
+                    tie_mask = tie_update(tie_mask, v, old_last, rs[KR - 1]);
+                    thr = fmaxf(rs[KR - 1], seed);
                 }
             }
         }
@@ -1194,7 +1425,8 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
         rs[i] = -INFINITY;
         ri[i] = -1;
     }
-    float thr = -INFINITY;
+    const float seed = grouped_threshold_seed(pmu, S4, hc, p);
+    float thr = seed;
 
     const int64_t per = (p.tiles + p.nsplit - 1) / p.nsplit;
     const int64_t t_begin = (int64_t)blockIdx.y * per;
@@ -1316,7 +1548,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
                     tie_mask = tie_update(tie_mask, acc[r], old_last, rs[KR - 1]);
                 }
             }
-            thr = rs[KR - 1];
+            thr = fmaxf(rs[KR - 1], seed);
 #if M2D_DIAG & 16
             STAMP(t1_); t_slow += t1_ - t0_; ++n_slow; t0_ = t1_;
 #endif
@@ -1445,7 +1677,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
 
     float rs[G][KR];
     int32_t ri[G][KR];
-    float thr[G], px[G];                                   // px, pid: parked candidate = this lane's best score of one tile
+    float thr[G], px[G], seed[G];                          // px, pid: parked candidate = this lane's best score of one tile
     int32_t pid[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -1454,7 +1686,9 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
             rs[g][i] = -INFINITY;
             ri[g][i] = -1;
         }
-        thr[g] = px[g] = -INFINITY;
+        seed[g] = HV ? -INFINITY : grouped_threshold_seed(pmu[g], S4, hc[g], p);   // HV: no alpha_P term to bound the scores with
+        thr[g] = seed[g];
+        px[g] = -INFINITY;
         pid[g] = -1;
         alpha[g] = alpha_prev[g] = 0.f;
     }
@@ -1539,11 +1773,16 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
 #endif
 
     auto share_threshold = [&](const int g) __attribute__((always_inline)) {
-        // the user's other lane (l ^ 32): a score that does not beat the larger of the two k-th bests cannot be in the
-        // user's merged top-k
-        const float t = rs[g][KR - 1];
+        // the user's other lane (l ^ 32): a score below the larger of the two lists' last entries cannot be in the user's
+        // merged top-KR, nor can one below the smaller of their MIDDLE entries (KR / 2 entries of each list are at or above
+        // it: KR scores in all) -- with the dishes dealt evenly to the two lanes that is about the merged list's last
+        // entry itself, where each lane's own last is about its 2 KR-th (candidate tiles 17 % -> 15 %, insertions per
+        // lane 110 -> 85 in scripts/diag/topk_scan_sim.py); and never below the scan-start bound
+        const float t = rs[g][KR - 1], m = rs[g][KR / 2 - 1];
         const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(t), false, false);
-        thr[g] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        const auto sm = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+        thr[g] = fmaxf(fmaxf(fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])),
+                             fminf(__uint_as_float(sm[0]), __uint_as_float(sm[1]))), seed[g]);
     };
 
     // the interleaved body: M(q-1) into accN, L(q), the compares + max tree of tile q-2 (accP), and -- INS -- the
@@ -1576,7 +1815,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
             for (int g = 0; g < G; ++g) {
 #pragma unroll
                 for (int r = ks * RPK; r < (ks + 1) * RPK; ++r) {
-                    m[g][r] = __ballot(accP[g][r] >= thr_rel[g]);      // one v_cmp into an SGPR pair; folded into a
+                    m[g][r] = (M2D_TIE_EXP & 1) ? __ballot(accP[g][r] > thr_rel[g]) : __ballot(accP[g][r] >= thr_rel[g]);      // one v_cmp into an SGPR pair; folded into a
                     mx[g] = fmaxf(mx[g], accP[g][r]);                  // per-lane row map only if some lane has a candidate
                 }
                 if constexpr (INS) {
@@ -1594,7 +1833,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         if constexpr (INS) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                tie_mask[g] = tie_update(tie_mask[g], x[g], old_last[g], rs[g][KR - 1]);
+                if (!(M2D_TIE_EXP & 2)) tie_mask[g] = tie_update(tie_mask[g], x[g], old_last[g], rs[g][KR - 1]);
                 share_threshold(g);
             }
         }
@@ -1690,7 +1929,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         }
         unsigned long long anyc = 0ull;
 #pragma unroll
-        for (int g = 0; g < G; ++g) anyc |= __ballot(mx[g] >= thr_rel[g]);
+        for (int g = 0; g < G; ++g) anyc |= (M2D_TIE_EXP & 1) ? __ballot(mx[g] > thr_rel[g]) : __ballot(mx[g] >= thr_rel[g]);
 #if M2D_DIAG & 16
         STAMP(t1_); t_body += t1_ - t0_; t0_ = t1_; ++n_step;
 #endif
@@ -1722,7 +1961,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
                         if (m[g][r] != 0ull) {
                             const float ol = rs[g][KR - 1], xv = accP[g][r] + alpha_prev[g];
                             sorted_insert_inplace<KR>(rs[g], ri[g], xv, sbase + (r & 3) + 8 * (r >> 2));
-                            tie_mask[g] = tie_update(tie_mask[g], xv, ol, rs[g][KR - 1]);
+                            if (!(M2D_TIE_EXP & 4)) tie_mask[g] = tie_update(tie_mask[g], xv, ol, rs[g][KR - 1]);
                         }
                     }
                     share_threshold(g);
@@ -1818,7 +2057,8 @@ int ensure_grouped(m2d_engine *h, hipStream_t st)
     // scan order by the norm of the row that carries the larger term: H[d] (weight a) when the ingredient table is set
     hipLaunchKernelGGL(m2d_grp_norm_stats, dim3(nblk), dim3(256), 0, st, h->dish_high ? h->dish_high : h->re, I, h->E, norm, acc);
     hipLaunchKernelGGL(m2d_grp_norm_params, dim3(1), dim3(1), 0, st, acc, I, stat);
-    hipLaunchKernelGGL(m2d_grp_hist, dim3(nblk), dim3(256), 0, st, h->dish_cats, norm, stat, I, h->C, blk_hist, flags);
+    M2D_HIP_TRY(h, hipMemsetAsync(grp + GRP_RMAX, 0, 16 * sizeof(int32_t), st));
+    hipLaunchKernelGGL(m2d_grp_hist, dim3(nblk), dim3(256), 0, st, h->dish_cats, norm, stat, I, h->C, blk_hist, flags, grp + GRP_RMAX);
     hipLaunchKernelGGL(m2d_grp_scan, dim3(1), dim3(GRP_KEYS * GRP_SCAN_SPLIT), 0, st, blk_hist, nblk, grp, h->grp_tile_info);
     hipLaunchKernelGGL(m2d_grp_scatter, dim3(nblk), dim3(256), 0, st, h->dish_cats, norm, stat, I, h->C, blk_hist, grp, h->grp_perm);
     hipLaunchKernelGGL(m2d_grp_gather, dim3((unsigned)((cap_rows + 3) / 4)), dim3(256), 0, st, h->re, h->dish_high,
@@ -1915,8 +2155,10 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     const int64_t ublocks = (nU + 32 * WAVES - 1) / (32 * WAVES);
     const int nsplit = pick_splits(h, ublocks, a.tiles, 2 * TPS, 512);
     a.nsplit = nsplit;
-    // tie values (floats): per (user, split), per (user, group of 64 splits) when the merge takes two passes, per user
-    const size_t tie_need = (size_t)nU * (nsplit > 1 ? nsplit + (nsplit > 64 ? nsplit / 64 : 0) + 1 : 1);
+    // tie values (floats): per (user, split), per (user, group of 64 splits) when the merge takes two passes, per user;
+    // behind them the repair list (int32: count, users) and the repair's partial lists
+    const size_t tie_vals = (size_t)nU * (nsplit > 1 ? nsplit + (nsplit > 64 ? nsplit / 64 : 0) + 1 : 1);
+    const size_t tie_need = tie_vals + 1 + (size_t)nU + (size_t)2 * REPAIR_CAP * REPAIR_SPLITS * k;
     if (h->topk_flags_cap < tie_need) {
         if (h->topk_flags) M2D_HIP_TRY(h, hipFree(h->topk_flags));
         h->topk_flags = nullptr; h->topk_flags_cap = 0;
@@ -1925,6 +2167,8 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     }
     float *tie_final = h->topk_flags + (nsplit > 1 ? (size_t)nU * (nsplit + (nsplit > 64 ? nsplit / 64 : 0)) : 0);
     a.tie_val = h->topk_flags;
+    int32_t *tie_list = reinterpret_cast<int32_t *>(h->topk_flags + tie_vals);
+    M2D_HIP_TRY(h, hipMemsetAsync(tie_list, 0, sizeof(int32_t), st));
     h->topk_tie_final = tie_final;
     h->topk_flags_used = nU;
     const size_t tmp_entries = nsplit > 64 ? (size_t)nU * (nsplit / 64) * k : 0;
@@ -1972,15 +2216,21 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         m2d_launch_merge_splits2(a.out_scores, a.out_ids, nU, nsplit, k, tmp_s, tmp_i, final_s, final_i, st, h->topk_flags, tie_final);
         M2D_HIP_TRY(h, hipGetLastError());
     }
-    {   // users whose lists met a tie at a boundary: re-ranked in dish-id order (nothing to do is the common case)
+    {   // users whose final k-th score is tied with a score left out: re-ranked in dish-id order (none is the common case)
         RepairArgs r;
         r.pm = h->pm; r.re = h->re; r.ce = h->ce; r.cats = h->dish_cats; r.hv = HV ? h->dish_high : nullptr;
-        r.users = users; r.tie_val = tie_final; r.nU = nU; r.U = h->U; r.I = h->I; r.user_base = h->user_base;
+        r.users = users; r.tie_list = tie_list; r.nU = nU; r.U = h->U; r.I = h->I; r.user_base = h->user_base;
         r.C = h->C; r.E = h->E; r.k = k; r.a = h->a; r.b = h->b; r.out_scores = final_s; r.out_ids = final_i;
+        r.cap = h->opt_variant == 13 ? 2 : REPAIR_CAP;      // test hook: send all but two listed users to the one-block-per-user kernel
+        r.part_s = h->topk_flags + tie_vals + 1 + (size_t)nU;
+        r.part_i = reinterpret_cast<int32_t *>(r.part_s + (size_t)REPAIR_CAP * REPAIR_SPLITS * k);
+        const size_t slds = ((size_t)(h->C + 1 + 16) * h->E + (size_t)2 * 64 * k) * sizeof(float);
         const size_t rlds = ((size_t)(2 * h->C + 1) * h->E + (size_t)2 * 256 * k) * sizeof(float);
-        const int64_t rgrid = nU < (int64_t)h->num_cu * 4 ? nU : (int64_t)h->num_cu * 4;
-        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_topk_repair_ties, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
-        hipLaunchKernelGGL(m2d_topk_repair_ties, dim3((unsigned)rgrid), dim3(256), rlds, st, r);
+        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_topk_repair_rest, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+        hipLaunchKernelGGL(m2d_topk_tie_compact, dim3((unsigned)((nU + 255) / 256)), dim3(256), 0, st, tie_final, nU, tie_list);
+        hipLaunchKernelGGL(m2d_topk_repair_scan, dim3(REPAIR_SPLITS, 16), dim3(1024), slds, st, r);
+        hipLaunchKernelGGL(m2d_topk_repair_merge, dim3(16), dim3(256), 0, st, r);
+        hipLaunchKernelGGL(m2d_topk_repair_rest, dim3((unsigned)(h->num_cu * 2)), dim3(256), rlds, st, r);
         M2D_HIP_TRY(h, hipGetLastError());
     }
     hipLaunchKernelGGL(m2d_topk_fill_absent, dim3((unsigned)((nU + 127) / 128)), dim3(128), 0, st, final_s, final_i, nU, k,

@@ -303,7 +303,8 @@ def test_structural_ties_resolve_to_the_lower_id(E, forced):
         _check(eng, PM, RE, CE, cats, np.arange(U), k)
 
 
-def test_every_user_tied():
+@pytest.mark.parametrize("variant", [0, 13])       # 13: all but two of the tied users take the one-block-per-user repair kernel
+def test_every_user_tied(variant):
     """A zero-initialised Personal_Memory table: every user is re-ranked in id order (the slow path at its worst)."""
     import torch
     from foodrec_amd import ScoringEngine
@@ -312,8 +313,9 @@ def test_every_user_tied():
     PM = np.zeros((U, 5, E), np.float32)
     eng = ScoringEngine(PM, RE, CE)
     eng.set_dish_categories(cats)
+    eng.set_option("variant", variant)
     s, ids = eng.topk_users(torch.arange(U, dtype=torch.int32, device="cuda"), k); eng.check()
-    assert eng.last_kernel() == "m2d_topk_grouped_bf16x3"
+    assert eng.last_kernel() == "m2d_topk_grouped_bf16x3" and eng.get_option("topk_repaired") == U
     want = np.flatnonzero(cats.sum(1) > 0)[:k]               # the lowest ids with a non-empty mask (empty masks score NaN)
     assert np.all(ids.cpu().numpy() == want[None, :]) and np.all(s.cpu().numpy() == 0)
 
