@@ -303,13 +303,24 @@ def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10):
     # the pattern-grouped kernel (0/1 masks) contracts over E only: price it on the flops it executes
     flops = 2.0 * E * n_users * I if kernel.startswith("m2d_topk_grouped") else dense
     x3 = kernel.endswith("bf16x3")                         # 3 bf16 MFMAs per 16 k-values: 6*E flop per pair on the bf16 pipe
+    scanned = full = None
+    if x3:                                                 # the pipelined kernel steps through its blocks' relevant patterns only
+        scanned, full = eng.get_option("topk_tiles_scanned"), eng.get_option("topk_tiles_full")
+        if scanned > 0:
+            flops = 2.0 * E * 256 * 32 * scanned            # a block is 256 user lanes, a tile 32 dishes
     return {"users": n_users, "dishes": I, "k": k, "median_ms": ms, "users_per_s": n_users / ms * 1e3,
             "pairs_per_s": n_users * I / ms * 1e3, "tflops": flops / ms / 1e9,
             "dense_equivalent_tflops": dense / ms / 1e9,
             "roofline": ({"bound": "mfma", "achieved": 3 * flops / ms / 1e9, "peak": 2500.0, "unit": "TFLOP/s",
                           "frac": 3 * flops / ms / 1e9 / 2500.0, "flop_per_pair": 3 * flops / n_users / I,
+                          "tiles_scanned": scanned, "tiles_without_pruning": full,
+                          "scanned_fraction": (scanned / full if scanned and full else None),
+                          "frac_if_every_tile_were_scanned": 3 * 2.0 * E * n_users * I / ms / 1e9 / 2500.0,
                           "dtype": "split bf16 (x = hi + lo, 3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
-                          "note": "pipelined kernel; what bounds it: DESIGN.md 4.4"} if x3 else
+                          "note": "pipelined kernel; `frac` prices the flops EXECUTED: users are sorted by the mask patterns that "
+                                  "can reach their top-k and a block steps through those patterns' tiles only (rigorous bounds; "
+                                  "DESIGN.md 4.4), so most (user, dish) pairs are decided without being multiplied -- pairs_per_s "
+                                  "counts every pair of the catalogue"} if x3 else
                          {"bound": "mfma", "achieved": flops / ms / 1e9, "peak": 157.3, "unit": "TFLOP/s",
                           "frac": flops / ms / 1e9 / 157.3, "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact)",
                           "flop_per_pair": flops / n_users / I}),
@@ -458,6 +469,12 @@ def scaling_path_block(torch, dist, foodrec_amd, dev, world, rank, users_total, 
     flop = 2.0 * E * (3 if x3 else 1)                      # per (user, dish) on the pattern-grouped kernels
     out["roofline_frac_of_mfma_peak"] = flop * out["pairs_per_s_whole_job"] / world / 1e12 / (2500.0 if x3 else 157.3)
     out["repaired_users_last_round"] = eng.get_option("topk_repaired")
+    if x3:
+        sc_, fl_ = eng.get_option("topk_tiles_scanned"), eng.get_option("topk_tiles_full")
+        out["scanned_fraction_last_round"] = sc_ / fl_ if fl_ else None
+        out["roofline_frac_of_mfma_peak"] = (out["roofline_frac_of_mfma_peak"] * sc_ / fl_) if fl_ else out["roofline_frac_of_mfma_peak"]
+        out["roofline_note"] = ("fraction of the dense bf16 MFMA peak on the flops executed (tiles stepped through x 3 MFMAs); "
+                                "pairs_per_s_whole_job counts every (user, dish) pair of the catalogue")
     # the exact-f32 kernel on one round of this shard's users (every rank at once; max over ranks)
     clk = _Clock(torch, dev)
     eng.set_option("topk_bf16x3", 0)

@@ -131,6 +131,7 @@ void release(m2d_engine *h)
     }
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->topk_flags) (void)hipFree(h->topk_flags);
+    if (h->topk_plan) (void)hipFree(h->topk_plan);
     if (h->err_dev) (void)hipFree(h->err_dev);
     if (h->err_host) (void)hipHostFree(h->err_host);
 }
@@ -761,6 +762,7 @@ int m2d_set_option(m2d_engine *h, const char *name, int64_t value)
     else if (!strcmp(name, "variant")) h->opt_variant = (int)value;
     else if (!strcmp(name, "topk_bf16x3")) h->opt_topk_bf16x3 = (int)value;
     else if (!strcmp(name, "topk_form")) h->opt_topk_form = (int)value;
+    else if (!strcmp(name, "topk_prune")) h->opt_topk_prune = (int)value;
     else if (!strcmp(name, "topk_grouped")) h->opt_topk_grouped = (int)value;
     else if (!strcmp(name, "mlp_bf16x3")) h->opt_mlp_bf16x3 = (int)value;
     else if (!strcmp(name, "mlp_form")) h->opt_mlp_form = (int)value;
@@ -780,6 +782,20 @@ int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value)
     else if (!strcmp(name, "variant")) *value = h->opt_variant;
     else if (!strcmp(name, "topk_bf16x3")) *value = h->opt_topk_bf16x3;
     else if (!strcmp(name, "topk_form")) *value = h->opt_topk_form;
+    else if (!strcmp(name, "topk_prune")) *value = h->opt_topk_prune;
+    else if (!strcmp(name, "topk_tiles_scanned") || !strcmp(name, "topk_tiles_full")) {
+        // diagnostic (synchronises the device): 32-dish tiles the blocks of the last pipelined retrieval launch stepped
+        // through, and what they would have stepped through without pattern pruning
+        *value = 0;
+        if (!strcmp(name, "topk_tiles_full")) *value = h->topk_tiles_full;
+        else if (h->topk_tiles_counter) {
+            unsigned long long v = 0;
+            if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+                hipMemcpy(&v, h->topk_tiles_counter, sizeof v, hipMemcpyDeviceToHost) != hipSuccess)
+                return M2D_ERR_HIP;
+            *value = (int64_t)v;
+        }
+    }
     else if (!strcmp(name, "topk_grouped")) *value = h->opt_topk_grouped;
     else if (!strcmp(name, "mlp_bf16x3")) *value = h->opt_mlp_bf16x3;
     else if (!strcmp(name, "mlp_form")) *value = h->opt_mlp_form;

@@ -28,9 +28,6 @@
 #ifndef M2D_DIAG
 #define M2D_DIAG 0
 #endif
-#ifndef M2D_TIE_EXP
-#define M2D_TIE_EXP 0
-#endif
 static unsigned long long *g_m2d_diag_buffer = nullptr;   // set by scripts/diag only
 #if M2D_DIAG & 16
 #define STAMP(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
@@ -944,7 +941,9 @@ __global__ __launch_bounds__(256) void m2d_grp_hist(const float *cats, const flo
                                                     int32_t *blk_hist, int32_t *flags, int32_t *rmax_bits)
 {
     __shared__ int sh[GRP_KEYS];
+    __shared__ int srmax[GRP_MAXPAT];
     sh[threadIdx.x] = 0;
+    if (threadIdx.x < GRP_MAXPAT) srmax[threadIdx.x] = 0;
     __syncthreads();
     const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (d < I) {
@@ -959,10 +958,11 @@ __global__ __launch_bounds__(256) void m2d_grp_hist(const float *cats, const flo
         atomicAdd(&sh[pat * GRP_NB + grp_bucket(norm[d], stat)], 1);
         // the pattern's largest row norm (non-negative floats order like their bit patterns; a NaN norm counts as +inf)
         const float nr = norm[d];
-        atomicMax(&rmax_bits[pat], __float_as_int(nr == nr ? nr : INFINITY));
+        atomicMax(&srmax[pat], __float_as_int(nr == nr ? nr : INFINITY));
     }
     __syncthreads();
     blk_hist[(size_t)blockIdx.x * GRP_KEYS + threadIdx.x] = sh[threadIdx.x];
+    if (threadIdx.x < GRP_MAXPAT && srmax[threadIdx.x] != 0) atomicMax(&rmax_bits[threadIdx.x], srmax[threadIdx.x]);   // one per pattern and block
 }
 
 // one block of 4 GRP_KEYS threads: per-key exclusive scan over the blocks (in place; four threads share a key, each
@@ -1088,6 +1088,9 @@ struct GroupedArgs {
     unsigned long long *dbg;   // scripts/diag only
     int32_t e_real;            // padded form only: the tables' E (rows of `rs` are zero-padded to the kernel's E)
     float *tie_val;            // [nU, nsplit] the list's last score when a tie decides what it holds (tie_at_boundary), else NaN
+    const float *plan;         // [nU, 8] per user of the call: scan-start bound, <U_high, CE_c> x 4, relevant-pattern mask (m2d_topk_user_plan)
+    const int32_t *order;      // [nU] position in the launch -> index into users / plan (users sorted by pattern mask), or null
+    unsigned long long *tiles_scanned;   // diagnostic: 32-dish tiles the blocks stepped through
 };
 
 // A threshold to start the scan from, known before any dish is scored.  With 0/1 masks score(u, d) = alpha_P[u] +
@@ -1097,6 +1100,51 @@ struct GroupedArgs {
 // bound of their best pattern is above every score of the other fourteen, and the scan inserts half as often (110 -> 60
 // insertions per lane at 100 k dishes, scripts/diag/topk_scan_sim.py).  |w_P|^2 comes from the 4 x 4 Gram matrix of the
 // user's low-level rows; the margin covers the kernels' rounding (split-bf16 products: ~2e-5 of |w||r|).
+// From <U_high, CE_c> (hc) and the Gram matrix of the low-level rows (G: 00 01 02 03 11 12 13 22 23 33): the scan-start
+// bound, and the patterns that can hold a score at or above it -- a pattern whose UPPER bound alpha_P + |w_P| max|r| is
+// below the bound cannot reach the user's top-k and need not be scanned at all.
+__device__ __forceinline__ void grouped_pattern_terms(const float (&hc)[4], const float (&G)[10], const int32_t *grp, const int pt,
+                                                      const int k, const float a, const float b, float &lo, float &hi)
+{
+    const int rows = grp[40 + pt];                          // wave-uniform
+    const float rmax = __int_as_float(grp[GRP_RMAX + pt]);
+    const float inv_n = 1.0f / (float)__builtin_popcount(pt);
+    float hs = 0.f, w2 = 0.f;
+    int i = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        hs += ((pt >> c) & 1) ? hc[c] : 0.f;
+#pragma unroll
+        for (int d = c; d < 4; ++d, ++i) w2 += (((pt >> c) & 1) && ((pt >> d) & 1)) ? (c == d ? G[i] : 2.f * G[i]) : 0.f;
+    }
+    const float alpha = a * (hs * inv_n);
+    const float reach = (b * inv_n) * sqrtf(fmaxf(w2, 0.f)) * rmax;
+    const float slack = 1e-4f * reach + 1e-6f * fabsf(alpha) + 1e-30f;        // the kernels' rounding, generously
+    lo = alpha - reach - slack;                              // k dishes at or above this ...
+    hi = alpha + reach + slack;                              // ... no dish of the pattern above this
+    if (rows < k) lo = -INFINITY;                            // (branches, not selects: a wave-uniform select between a vector value and
+    if (rows <= 0) hi = -INFINITY;                           //  a constant sent hipcc 7.2 into "Illegal instruction detected")
+}
+
+__device__ __forceinline__ void grouped_pattern_bounds(const float (&hc)[4], const float (&G)[10], const int32_t *grp, const int k,
+                                                       const float a, const float b, float &seed, uint32_t &mask)
+{
+    seed = -INFINITY;
+#pragma unroll 1
+    for (int pt = 1; pt < 16; ++pt) {
+        float lo, hi;
+        grouped_pattern_terms(hc, G, grp, pt, k, a, b, lo, hi);
+        seed = fmaxf(seed, lo);                              // a NaN bound is ignored
+    }
+    mask = 0u;
+#pragma unroll 1
+    for (int pt = 1; pt < 16; ++pt) {
+        float lo, hi;
+        grouped_pattern_terms(hc, G, grp, pt, k, a, b, lo, hi);
+        mask |= !(hi < seed) ? (1u << pt) : 0u;              // NaN bounds keep their pattern
+    }
+}
+
 __device__ __forceinline__ float grouped_threshold_seed(const v4f *pmu, const int Sr, const float (&hc)[4], const GroupedArgs &p)
 {
     float G[10];
@@ -1113,25 +1161,124 @@ __device__ __forceinline__ float grouped_threshold_seed(const v4f *pmu, const in
 #pragma unroll
             for (int d = c; d < 4; ++d, ++i) G[i] += (u[c].x * u[d].x + u[c].y * u[d].y) + (u[c].z * u[d].z + u[c].w * u[d].w);
     }
-    float seed = -INFINITY;
-#pragma unroll 1
-    for (int pt = 1; pt < 16; ++pt) {
-        if (p.grp[40 + pt] < p.k) continue;                 // wave-uniform: fewer than k dishes carry this pattern
-        const float rmax = __int_as_float(p.grp[GRP_RMAX + pt]);
-        const float inv_n = 1.0f / (float)__builtin_popcount(pt);
-        float hs = 0.f, w2 = 0.f;
-        int i = 0;
+    float seed;
+    uint32_t mask;
+    grouped_pattern_bounds(hc, G, p.grp, p.k, p.a, p.b, seed, mask);
+    return seed;
+}
+
+// The plan of a retrieval call, one record of 8 floats per user: [0] scan-start bound, [1..4] <U_high, CE_c>, [5] the
+// relevant-pattern mask (bits), for the pipelined kernel -- which takes its users in the order m2d_plan_* sort them into
+// (by mask), so that the 256 users of a block share their relevant patterns and the block steps through those
+// patterns' tiles only.  16 lanes per user, a float4 column each.
+__global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const float *ce, const int32_t *users, int64_t nU, int64_t U,
+                                                          int64_t user_base, int E, const int32_t *grp, int k, float a, float b,
+                                                          int no_alpha, float *plan)
+{
+    const int lane = threadIdx.x & 63, j = lane & 15;
+    const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int E4 = E >> 2;
+    int64_t ul = 0;
+    if (u < nU) {
+        ul = (int64_t)users[u] - user_base;
+        if (ul < 0 || ul >= U) ul = 0;                      // reported by the scan kernel
+    }
+    const v4f *pmu = reinterpret_cast<const v4f *>(pm) + (size_t)ul * (5 * E4);
+    const v4f *ce4 = reinterpret_cast<const v4f *>(ce);
+    float hc[4] = {0.f, 0.f, 0.f, 0.f}, G[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) G[i] = 0.f;
+    for (int q = j; q < E4; q += 16) {
+        const v4f uh = pmu[q];
+        v4f r[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            hs += ((pt >> c) & 1) ? hc[c] : 0.f;
-#pragma unroll
-            for (int d = c; d < 4; ++d, ++i) w2 += (((pt >> c) & 1) && ((pt >> d) & 1)) ? (c == d ? G[i] : 2.f * G[i]) : 0.f;
+            const v4f w = ce4[c * E4 + q];
+            hc[c] += (uh.x * w.x + uh.y * w.y) + (uh.z * w.z + uh.w * w.w);
+            r[c] = pmu[(c + 1) * E4 + q];
         }
-        const float alpha = p.a * (hs * inv_n);
-        const float reach = (p.b * inv_n) * sqrtf(fmaxf(w2, 0.f)) * rmax;
-        seed = fmaxf(seed, alpha - reach - (1e-4f * reach + 1e-6f * fabsf(alpha) + 1e-30f));     // a NaN / -inf bound is ignored
+        int i = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int d = c; d < 4; ++d, ++i) G[i] += (r[c].x * r[d].x + r[c].y * r[d].y) + (r[c].z * r[d].z + r[c].w * r[d].w);
     }
-    return seed;
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) hc[c] += __shfl_xor(hc[c], off, 64);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) G[i] += __shfl_xor(G[i], off, 64);
+    }
+    float seed;
+    uint32_t mask;
+    grouped_pattern_bounds(hc, G, grp, k, a, b, seed, mask);
+    if (no_alpha == 1) { seed = -INFINITY; mask = 0xfffeu; }     // ingredient rows: the score has no alpha_P term to bound it with
+    if (no_alpha == 2) mask = 0xfffeu;                        // option topk_prune = 2: the bound, but every pattern (A/B)
+    if (no_alpha == 4) seed = -INFINITY;                      // option topk_prune = 4: the patterns, but no bound (A/B)
+    if (u < nU && j == 0) {
+        float *o = plan + (size_t)u * 8;
+        o[0] = seed; o[1] = hc[0]; o[2] = hc[1]; o[3] = hc[2]; o[4] = hc[3]; o[5] = __uint_as_float(mask); o[6] = 0.f; o[7] = 0.f;
+    }
+}
+
+// counting sort of the call's users by their 15-bit pattern mask: histogram, scan (one block), scatter.  The order inside
+// a mask does not matter -- a user's list does not depend on the block it is scored in.  Two thirds of the users share
+// fifteen masks (one relevant pattern), so a wave adds ONE count per distinct mask it holds (the lanes of a mask are found
+// with a ballot; a lane's place among them is its rank): one atomic per user queued 65 536 of them on a few dozen addresses.
+constexpr int PLAN_KEYS = 1 << 16;
+__device__ __forceinline__ int plan_wave_add(int32_t *counters, const int key, const bool live)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(live);
+    int pos = 0;
+    while (todo) {                                          // wave-uniform
+        const int k0 = __builtin_amdgcn_readlane(key, __builtin_ctzll(todo));
+        const unsigned long long same = __ballot(live && key == k0) & todo;
+        int base = 0;
+        if (lane == __builtin_ctzll(same)) base = atomicAdd(&counters[k0], __builtin_popcountll(same));
+        base = __builtin_amdgcn_readlane(base, __builtin_ctzll(same));
+        if (live && key == k0) pos = base + __builtin_popcountll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return pos;
+}
+
+__global__ __launch_bounds__(256) void m2d_plan_hist(const float *plan, int64_t nU, int32_t *hist)
+{
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = u < nU;
+    (void)plan_wave_add(hist, live ? (int)(__float_as_uint(plan[(size_t)u * 8 + 5]) & (PLAN_KEYS - 1)) : 0, live);
+}
+
+__global__ __launch_bounds__(1024) void m2d_plan_scan(int32_t *hist)
+{
+    __shared__ int32_t part[1024];
+    constexpr int PER = PLAN_KEYS / 1024;
+    int32_t sum = 0;
+    for (int i = 0; i < PER; ++i) sum += hist[threadIdx.x * PER + i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int32_t run = part[threadIdx.x] - sum;
+    for (int i = 0; i < PER; ++i) {
+        const int32_t c = hist[threadIdx.x * PER + i];
+        hist[threadIdx.x * PER + i] = run;
+        run += c;
+    }
+}
+
+__global__ __launch_bounds__(256) void m2d_plan_scatter(const float *plan, int64_t nU, int32_t *cursor, int32_t *order)
+{
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = u < nU;
+    const int pos = plan_wave_add(cursor, live ? (int)(__float_as_uint(plan[(size_t)u * 8 + 5]) & (PLAN_KEYS - 1)) : 0, live);
+    if (live) order[pos] = (int32_t)u;
 }
 
 // End of a pattern-grouped scan: the lane's register list goes to LDS with its slots translated to dish ids, the two
@@ -1626,14 +1773,19 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     const int j = lane & 31, h = lane >> 5;
     const int k = p.k;
 
+    // The users of a launch come in the order the call's plan sorted them into (by relevant-pattern mask, p.order):
+    // uidx = the user's index in the CALL (users, plan, outputs), wherever the launch placed it.
     int64_t uidx[G];
     bool uvalid[G];
     const v4f *pmu[G];
-    float hc[G][C];                                        // <U_high, CE_c>   Model_Recommender.py:67-75
+    float hc[G][C];                                        // <U_high, CE_c>   Model_Recommender.py:67-75 (from the plan)
+    float seed[G];                                         // scan-start bound of the user's final k-th score (from the plan)
+    uint32_t umask_lane = 0u;                              // patterns that can reach the top-k of this lane's user(s)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        uidx[g] = (((int64_t)blockIdx.x * WAVES + wave) * G + g) * 32 + j;
-        uvalid[g] = uidx[g] < p.nU;
+        const int64_t pos = (((int64_t)blockIdx.x * WAVES + wave) * G + g) * 32 + j;
+        uvalid[g] = pos < p.nU;
+        uidx[g] = uvalid[g] ? (p.order ? (int64_t)p.order[pos] : pos) : 0;
         int64_t ul = 0;
         if (uvalid[g]) {
             const int32_t uid = p.users[uidx[g]];
@@ -1648,19 +1800,21 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
             }
         }
         pmu[g] = reinterpret_cast<const v4f *>(p.pm) + (size_t)ul * ((C + 1) * S4);
-        const v4f *ce4 = reinterpret_cast<const v4f *>(p.ce);
+        const float *rec = p.plan + (size_t)uidx[g] * 8;
 #pragma unroll
-        for (int c = 0; c < C; ++c) hc[g][c] = 0.f;
-#pragma unroll 1
-        for (int q = 0; q < (HV ? 0 : S4); ++q) {          // HV: the category sum is replaced by H[d], inside the contraction
-            const v4f u = pmu[g][q];
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const v4f w = ce4[c * S4 + q];
-                hc[g][c] += (u.x * w.x + u.y * w.y) + (u.z * w.z + u.w * w.w);
-            }
-        }
+        for (int c = 0; c < C; ++c) hc[g][c] = rec[1 + c];
+        seed[g] = uvalid[g] ? rec[0] : INFINITY;            // a lane without a user never has a candidate
+        umask_lane |= uvalid[g] ? __float_as_uint(rec[5]) : 0u;
     }
+    // the block's patterns: the union over its users.  Tiles of every other pattern are not even fetched.
+    __shared__ uint32_t s_umask;
+    if (threadIdx.x == 0) s_umask = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) umask_lane |= __shfl_xor(umask_lane, off, 64);
+    if (lane == 0) atomicOr(&s_umask, umask_lane);
+    __syncthreads();
+    const uint32_t umask = __builtin_amdgcn_readfirstlane(s_umask);
     // group table: lane q holds the first tile and the row count of mask pattern q (groups are padded to whole tiles)
     int g_first = 0, g_rows = 0;
     if (lane >= 1 && lane < GRP_MAXPAT) {
@@ -1677,7 +1831,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
 
     float rs[G][KR];
     int32_t ri[G][KR];
-    float thr[G], px[G], seed[G];                          // px, pid: parked candidate = this lane's best score of one tile
+    float thr[G], px[G];                                   // px, pid: parked candidate = this lane's best score of one tile
     int32_t pid[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -1686,7 +1840,6 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
             rs[g][i] = -INFINITY;
             ri[g][i] = -1;
         }
-        seed[g] = HV ? -INFINITY : grouped_threshold_seed(pmu[g], S4, hc[g], p);   // HV: no alpha_P term to bound the scores with
         thr[g] = seed[g];
         px[g] = -INFINITY;
         pid[g] = -1;
@@ -1700,8 +1853,49 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     const int64_t per = (p.tiles + p.nsplit - 1) / p.nsplit;
     const int64_t t_begin = (int64_t)blockIdx.y * per;
     const int64_t t_end = min(p.tiles, t_begin + per);
-    const int64_t n = t_end > t_begin ? t_end - t_begin : 0;        // tiles of this block
-    const int64_t nst = n > 0 ? (n + 2) / TPS + 1 : 0;              // stages the steps below touch (dummies included)
+    const int n_phys = (int)(t_end > t_begin ? t_end - t_begin : 0);   // tiles of this block's dish range
+    const int nst = n_phys > 0 ? (n_phys + 2) / TPS + 1 : 0;           // stages of that range (the image is padded for the overhang)
+    // The stages to step through: those that hold a tile of a pattern in `umask`, in scan order, as up to 15 ranges of
+    // stage numbers (relative to t_begin) kept in lanes -- range i in lane i of r_first / r_cnt.  A stage that straddles a
+    // group boundary brings a few tiles of a neighbouring pattern along; they are scored like any other.
+    int r_first = 0, r_cnt = 0, nranges = 0, vstages = 0;
+    {
+        int last_end = -1;
+        for (int q = 1; q < GRP_MAXPAT; ++q) {
+            const int rows = __builtin_amdgcn_readlane(g_rows, q);
+            if (rows == 0 || !((umask >> q) & 1u)) continue;
+            const int64_t gt0 = __builtin_amdgcn_readlane(g_first, q), gt1 = gt0 + ((rows + 31) >> 5);
+            const int64_t lo = gt0 > t_begin ? gt0 : t_begin, hi = gt1 < t_end ? gt1 : t_end;
+            if (lo >= hi) continue;
+            int s0 = (int)((lo - t_begin) / TPS);
+            const int s1 = (int)((hi - 1 - t_begin) / TPS);
+            if (s0 <= last_end) s0 = last_end + 1;
+            if (s0 > s1) continue;
+            r_first = lane == nranges ? s0 : r_first;
+            r_cnt = lane == nranges ? s1 - s0 + 1 : r_cnt;
+            ++nranges;
+            vstages += s1 - s0 + 1;
+            last_end = s1;
+        }
+    }
+    const int64_t n = (int64_t)vstages * TPS;                       // tiles the steps below go through ("virtual" tiles 0 .. n - 1)
+    // walker over the ranges: the physical stage of the next virtual stage (beyond the last: a stage number no range holds)
+    int w_idx = -1, w_stage = 0, w_left = 0;
+    auto next_stage = [&]() __attribute__((always_inline)) {
+        if (w_left == 0) {
+            ++w_idx;
+            if (w_idx < nranges) {
+                w_stage = __builtin_amdgcn_readlane(r_first, w_idx);
+                w_left = __builtin_amdgcn_readlane(r_cnt, w_idx);
+            } else {
+                w_stage = 0x20000000;
+                w_left = 0x20000000;
+            }
+        }
+        --w_left;
+        return w_stage++;
+    };
+    int ps_m1 = 0x20000000, ps_0 = 0x20000000, ps_p1 = 0x20000000;   // physical stages of virtual stages v - 1, v, v + 1 (v = q / TPS)
 
     // LDS-DMA: this lane's source offset inside a stage for its wave's first piece
     const unsigned char *const src_base = reinterpret_cast<const unsigned char *>(p.rs16) + (size_t)t_begin * TILE_BYTES;
@@ -1716,15 +1910,15 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     // source offset (computed once, above) as the 32-bit VGPR offset and the piece's 8 KiB multiple as the scalar
     // offset -- no 64-bit per-lane address arithmetic per piece (1-2 % over global_load_lds with VGPR addresses)
     typedef int v4i_ __attribute__((ext_vector_type(4)));
-    auto issue_pieces = [&](const int64_t stage, const int first, const int count) __attribute__((always_inline)) {
-        if (stage >= nst) return;
+    auto issue_pieces = [&](const int stage, const int buf, const int first, const int count) __attribute__((always_inline)) {
+        if (stage >= nst) return;                          // past the dish range (or no stage left): nothing to fetch
         const uint64_t b = (uint64_t)(uintptr_t)(src_base + (size_t)stage * STAGE_BYTES);
         v4i_ rsrc;                                         // raw buffer (stride 0) over this stage of the catalogue image
         rsrc.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)b);
         rsrc.y = __builtin_amdgcn_readfirstlane((int)((uint32_t)(b >> 32) & 0xffffu));
         rsrc.z = STAGE_BYTES;
         rsrc.w = 0x00020000;
-        unsigned char *dst = smem8 + (size_t)(stage & 1) * STAGE_BYTES + wave * 1024;
+        unsigned char *dst = smem8 + (size_t)(buf & 1) * STAGE_BYTES + wave * 1024;
 #pragma unroll
         for (int c = 0; c < count; ++c) {
             const int pp = first + c;
@@ -1755,10 +1949,12 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     const v16f zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     if (n > 0) {
-        issue_pieces(0, 0, PPW);
+        ps_0 = next_stage();
+        ps_p1 = next_stage();
+        issue_pieces(ps_0, 0, 0, PPW);
         wait_all_vmem();
         __syncthreads();
-        issue_pieces(1, 0, PCNT);                          // what step "0" of the first stage would have issued
+        issue_pieces(ps_p1, 1, 0, PCNT);                   // what step "0" of the first stage would have issued
 #pragma unroll
         for (int ks = 0; ks < AR; ++ks) {                  // the first AR k-steps of tile 0
             const unsigned char *a = smem8 + (lane_off ^ (ks << 5));
@@ -1815,7 +2011,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
             for (int g = 0; g < G; ++g) {
 #pragma unroll
                 for (int r = ks * RPK; r < (ks + 1) * RPK; ++r) {
-                    m[g][r] = (M2D_TIE_EXP & 1) ? __ballot(accP[g][r] > thr_rel[g]) : __ballot(accP[g][r] >= thr_rel[g]);      // one v_cmp into an SGPR pair; folded into a
+                    m[g][r] = __ballot(accP[g][r] >= thr_rel[g]);      // one v_cmp into an SGPR pair; folded into a
                     mx[g] = fmaxf(mx[g], accP[g][r]);                  // per-lane row map only if some lane has a candidate
                 }
                 if constexpr (INS) {
@@ -1833,7 +2029,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         if constexpr (INS) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                if (!(M2D_TIE_EXP & 2)) tie_mask[g] = tie_update(tie_mask[g], x[g], old_last[g], rs[g][KR - 1]);
+                tie_mask[g] = tie_update(tie_mask[g], x[g], old_last[g], rs[g][KR - 1]);
                 share_threshold(g);
             }
         }
@@ -1847,16 +2043,31 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         if (sub == 0) {                                    // tile q opens stage q / TPS: it must have landed, for every wave
             wait_all_vmem();
             __syncthreads();                               // also: every wave is done reading the buffer refilled next
+            ps_m1 = ps_0;
+            ps_0 = ps_p1;
+            ps_p1 = next_stage();
         }
-        if (sub < TPS - 1) issue_pieces(q / TPS + 1, sub * PCNT, PCNT);
+        if (KS > AR && sub == 1) {
+            // With more k-steps than fragment sets (E = 128: KS = 8, AR = 4) a tile's last KS - AR k-steps are read one step
+            // after its first ones: the LAST tile of the previous stage was still being read during step "sub 0", after that
+            // stage's barrier.  Its LDS region is refilled by the pieces issued at sub = TPS - 2; nothing kept a wave that
+            // runs two steps ahead (no insertions, while another wave rebuilds its operand at a pattern switch or works
+            // through a tile of candidates) from issuing them under the reader: wrong scores for that one tile, seen once
+            // the scan-start thresholds made some waves that much faster than others.  So: every wave is past step "sub 0"
+            // before any wave goes on to the steps that refill that region.
+            asm volatile("s_barrier" ::: "memory");
+        }
+        if (sub < TPS - 1) issue_pieces(ps_p1, (int)(q / TPS + 1), sub * PCNT, PCNT);
 #if M2D_DIAG & 16
         STAMP(t1_); t_bar += t1_ - t0_; t0_ = t1_;
 #endif
 #pragma unroll
         for (int g = 0; g < G; ++g) alpha_prev[g] = alpha[g];   // tile q-2 was multiplied under the previous step's alpha
         int nvalid = 0;
-        if (q - 1 < n) {
-            const int64_t t = t_begin + q - 1;
+        // physical tile of virtual tile q - 1 (the one being multiplied): its stage is v or v - 1
+        const int pt1 = ((q - 1) / TPS == q / TPS ? ps_0 : ps_m1) * TPS + (int)((q - 1) & (TPS - 1));
+        if (q - 1 < n && pt1 < n_phys) {
+            const int64_t t = t_begin + pt1;
             while (t >= g_end) {                            // next non-empty group (scalar; at most 15 times per block)
                 ++gp;
                 g_tot = __builtin_amdgcn_readlane(g_rows, gp);
@@ -1929,7 +2140,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         }
         unsigned long long anyc = 0ull;
 #pragma unroll
-        for (int g = 0; g < G; ++g) anyc |= (M2D_TIE_EXP & 1) ? __ballot(mx[g] > thr_rel[g]) : __ballot(mx[g] >= thr_rel[g]);
+        for (int g = 0; g < G; ++g) anyc |= __ballot(mx[g] >= thr_rel[g]);
 #if M2D_DIAG & 16
         STAMP(t1_); t_body += t1_ - t0_; t0_ = t1_; ++n_step;
 #endif
@@ -1938,7 +2149,8 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         asm volatile("" ::"s"(anyc), "s"(m[0][0] | m[0][5] | m[0][10] | m[0][15]), "v"(mx[0]), "v"(mx[G - 1]));
 #endif
         if ((M2D_DIAG & 8) ? false : anyc != 0ull) {       // some lane of tile q-2 beat its threshold
-            const int32_t sbase = (int32_t)((t_begin + q - 2) * 32) + 4 * h;
+            const int pt2 = ((q - 2) / TPS == q / TPS ? ps_0 : ps_m1) * TPS + (int)((q - 2) & (TPS - 1));   // physical tile of tile q - 2
+            const int32_t sbase = (int32_t)((t_begin + pt2) * 32) + 4 * h;
             // per-lane 16-bit map of candidate rows (bit 15 - r), built here -- in the quarter of the steps that have a
             // candidate -- from the sixteen lane masks: map = 2 map + mask bit, one v_addc each
             uint32_t rowmap[G];
@@ -1961,7 +2173,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
                         if (m[g][r] != 0ull) {
                             const float ol = rs[g][KR - 1], xv = accP[g][r] + alpha_prev[g];
                             sorted_insert_inplace<KR>(rs[g], ri[g], xv, sbase + (r & 3) + 8 * (r >> 2));
-                            if (!(M2D_TIE_EXP & 4)) tie_mask[g] = tie_update(tie_mask[g], xv, ol, rs[g][KR - 1]);
+                            tie_mask[g] = tie_update(tie_mask[g], xv, ol, rs[g][KR - 1]);
                         }
                     }
                     share_threshold(g);
@@ -2000,6 +2212,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     }
     wait_all_vmem();                                       // no LDS-DMA may land after the lists are published below
     __syncthreads();
+    if (p.tiles_scanned && threadIdx.x == 0) atomicAdd(p.tiles_scanned, (unsigned long long)n);
 #if M2D_DIAG & 16
     if (lane == 0 && p.dbg) {
         unsigned long long *d = p.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave) * 8;
@@ -2152,8 +2365,20 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     a.grp = h->grp_work + (size_t)((h->I + 255) / 256) * GRP_KEYS;
     a.users = users; a.nU = nU; a.U = h->U; a.user_base = h->user_base; a.k = k; a.tiles = h->grp_tiles;
     a.a = h->a; a.b = h->b; a.err = h->err_dev; a.dbg = g_m2d_diag_buffer; a.e_real = h->E;
+    a.plan = nullptr; a.order = nullptr; a.tiles_scanned = nullptr;
     const int64_t ublocks = (nU + 32 * WAVES - 1) / (32 * WAVES);
-    const int nsplit = pick_splits(h, ublocks, a.tiles, 2 * TPS, 512);
+    int nsplit = pick_splits(h, ublocks, a.tiles, 2 * TPS, 512);
+    if (BF16X3 && !HV && h->opt_topk_form != 1 && h->opt_topk_prune != 0 && h->opt_variant < 100) {
+        // Pattern pruning makes the blocks unequal -- a block of users with one relevant pattern steps through a fifteenth of
+        // the catalogue, one whose users need most patterns through all of it -- so the launch is cut into at least eight
+        // workgroups per CU (dish-range splits) for the dispatcher to balance (65 536 users x 100 k dishes: 2.7 ms with one
+        // split, 2.0 with eight; x 1 M dishes, E = 128: 34 -> 15 ms)
+        int64_t want = (8 * (int64_t)h->num_cu + ublocks - 1) / ublocks;
+        const int64_t cap = a.tiles / (4 * TPS) > 1 ? a.tiles / (4 * TPS) : 1;
+        if (want > cap) want = cap;
+        if (want > 64) want = 64;
+        if (want > nsplit) nsplit = (int)want;
+    }
     a.nsplit = nsplit;
     // tie values (floats): per (user, split), per (user, group of 64 splits) when the merge takes two passes, per user;
     // behind them the repair list (int32: count, users) and the repair's partial lists
@@ -2192,6 +2417,36 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         // "topk_form": 0 or 2 = pipelined form (E = 64: 2.55 ms against 3.3 at 100 k dishes; E = 128: 38.3 ms against
         // 45.4 at 1 M dishes), 1 = first form (kept as the A/B reference)
         const bool pipe = HV || h->opt_topk_form != 1;
+        if (pipe) {
+            // the call's plan: per user the scan-start bound, <U_high, CE_c> and the mask of patterns that can reach the
+            // top-k; users sorted by mask so that a block's 256 users share their patterns (a single block: no sort)
+            const size_t need = (size_t)nU * 8 + (size_t)nU + PLAN_KEYS + 4;
+            if (h->topk_plan_cap < need) {
+                if (h->topk_plan) M2D_HIP_TRY(h, hipFree(h->topk_plan));
+                h->topk_plan = nullptr; h->topk_plan_cap = 0;
+                M2D_HIP_TRY(h, hipMalloc((void **)&h->topk_plan, need * sizeof(float)));
+                h->topk_plan_cap = need;
+            }
+            float *plan = h->topk_plan;
+            int32_t *order = reinterpret_cast<int32_t *>(plan + (size_t)nU * 8), *hist = order + nU;
+            unsigned long long *counter = reinterpret_cast<unsigned long long *>(hist + PLAN_KEYS + ((nU + PLAN_KEYS) & 1));
+            const bool prune = h->opt_topk_prune != 0;
+            hipLaunchKernelGGL(m2d_topk_user_plan, dim3((unsigned)((nU * 16 + 255) / 256)), dim3(256), 0, st, h->pm, h->ce, users, nU, h->U,
+                               h->user_base, h->E, a.grp, (int)k, h->a, h->b, (HV || !prune) ? 1 : (h->opt_topk_prune == 2 ? 2 : (h->opt_topk_prune == 4 ? 4 : 0)), plan);
+            a.plan = plan;
+            if (prune && !HV && nU > 256 && h->opt_topk_prune != 3) {      // 3: pruning without the sort (A/B)
+                M2D_HIP_TRY(h, hipMemsetAsync(hist, 0, PLAN_KEYS * sizeof(int32_t), st));
+                hipLaunchKernelGGL(m2d_plan_hist, dim3((unsigned)((nU + 255) / 256)), dim3(256), 0, st, plan, nU, hist);
+                hipLaunchKernelGGL(m2d_plan_scan, dim3(1), dim3(1024), 0, st, hist);
+                hipLaunchKernelGGL(m2d_plan_scatter, dim3((unsigned)((nU + 255) / 256)), dim3(256), 0, st, plan, nU, hist, order);
+                a.order = order;
+            }
+            M2D_HIP_TRY(h, hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
+            a.tiles_scanned = counter;
+            h->topk_tiles_counter = counter;
+            h->topk_tiles_full = (int64_t)((nU + 255) / 256) * a.tiles;
+            M2D_HIP_TRY(h, hipGetLastError());
+        }
         if constexpr (HV) {
             auto kern = m2d_topk_grouped_bf16_pipe2<E, KR, 1, true>;
             M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

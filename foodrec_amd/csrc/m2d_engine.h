@@ -94,6 +94,10 @@ struct m2d_engine {
     float *topk_flags = nullptr;        // pattern-grouped retrieval: tie values per (user, split) / per user (NaN: no tie at the k-th score)
     size_t topk_flags_cap = 0;          // floats
     float *topk_tie_final = nullptr;    // the per-user values of the last call, inside topk_flags
+    float *topk_plan = nullptr;         // pipelined retrieval kernel: per-user plan records | launch order | sort histogram | tile counter
+    size_t topk_plan_cap = 0;           // floats
+    unsigned long long *topk_tiles_counter = nullptr;   // tiles the blocks of the last pipelined launch stepped through (inside topk_plan)
+    int64_t topk_tiles_full = 0;        // ... and what they would have stepped through without pattern pruning
     int64_t topk_flags_used = 0;        // users of the last pattern-grouped call (get_option "topk_repaired" counts the non-NaN values)
 
     // benchmarking knobs
@@ -110,6 +114,7 @@ struct m2d_engine {
     int opt_topk_bf16x3 = 1;            // retrieval (build-defined) on split-bf16 MFMA; 0 = exact-f32 MFMA
     int opt_topk_grouped = 1;           // 0/1-mask catalogues: pattern-grouped retrieval (contraction over E); 0 = dense kernel
     int opt_topk_form = 0;              // split-bf16 retrieval kernel: 0 / 2 = pipelined form, 1 = first form
+    int opt_topk_prune = 1;             // pipelined form: blocks step through the tiles of their users' relevant mask patterns only (0 = every tile)
 
     std::string last_error;
     const char *last_kernel = "";

@@ -2,6 +2,8 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DM2D_DIAG=<mask> scripts/diag/topk_diag.cpp -o topk_diag_<mask>
 #include "../../foodrec_amd/csrc/m2d_catalogue.hip"
 
+int m2d_ensure_finite_scan(m2d_engine *, hipStream_t) { return M2D_OK; }   // (m2d_abi.hip is not part of this binary)
+
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -26,7 +28,8 @@ int main(int argc, char **argv)
     float *dpm, *dre, *dce, *dcats, *outs; int32_t *users, *outi;
     hipMalloc(&dpm, pm.size() * 4); hipMalloc(&dre, re.size() * 4); hipMalloc(&dce, ce.size() * 4);
     hipMalloc(&dcats, cats.size() * 4); hipMalloc(&outs, U * k * 4); hipMalloc(&outi, U * k * 4);
-    hipMalloc(&users, U * 4); hipMalloc(&h.err_dev, 16); hipMemset(h.err_dev, 0, 16);
+    hipMalloc(&users, U * 4); hipMalloc(&h.err_dev, 32); hipMemset(h.err_dev, 0, 32);
+    h.nonfinite_dev = h.err_dev + 4; h.finite_scan_pending = false;
     hipMemcpy(dpm, pm.data(), pm.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(dre, re.data(), re.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(dce, ce.data(), ce.size() * 4, hipMemcpyHostToDevice);
