@@ -1141,6 +1141,11 @@ def main():
                 line["catalogue_topk"]["exact_f32"] = catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U))
             finally:
                 eng.set_option("topk_bf16x3", 1)
+            eng.set_option("topk_prune", 0)             # ... and the same kernel made to step through every tile: the MFMA-bound form
+            try:
+                line["catalogue_topk"]["every_tile"] = catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U))
+            finally:
+                eng.set_option("topk_prune", 1)
         if world == 1 and not a.no_side and wl == "pairs" and not a.no_cpu_baseline:
             in_flight["leg"] = "evaluator"
             try:

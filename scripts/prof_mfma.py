@@ -38,6 +38,9 @@ def repaired(eng):
         return None
 
 
+launches = {}                                                # scan-kernel launches so far, per kernel name (for the trace's slices)
+
+
 def timed(fn):
     for _ in range(WARM):
         fn()
@@ -58,16 +61,29 @@ if which in ("both", "topk"):
     eng = foodrec_amd.ScoringEngine(PM, RE, CE); eng.set_dish_categories(cats)
     users = torch.randperm(U, generator=g, device=dev)[:n].to(torch.int32)
     eng.topk_users(users[:1024], 10)                          # builds the retrieval tables
-    for x3 in (1, 0):
+    for name, x3, prune in (("topk_bf16x3", 1, 1), ("topk_bf16x3_every_tile", 1, 0), ("topk_f32", 0, 1)):
         eng.set_option("topk_bf16x3", x3)
+        eng.set_option("topk_prune", prune)
         avg, med = timed(lambda: eng.topk_users(users, 10))
         eng.check()
+        kn = eng.last_kernel()
+        first = launches.get(kn, 1 if x3 else 0) + WARM      # (the table-building call ran the default kernel once)
+        launches[kn] = first + TIMED
         flop = 2.0 * E * (3 if x3 else 1) * n * I
-        res["topk_bf16x3" if x3 else "topk_f32"] = {
+        scanned = full = None
+        if x3:                                               # the pipelined kernel: flops of the tiles its blocks stepped through
+            scanned, full = eng.get_option("topk_tiles_scanned"), eng.get_option("topk_tiles_full")
+            flop = 2.0 * E * 3 * 256 * 32 * scanned
+        res[name] = {
             "kernel": eng.last_kernel(), "users": n, "dishes": I, "embed_size": E, "launches": TIMED, "warmup": WARM,
             "event_avg_ms": avg, "event_median_ms": med, "executed_flop_per_launch": flop,
             "frac_of_peak": flop / avg / 1e9 / (2500.0 if x3 else 157.3), "peak_TFLOPs": 2500.0 if x3 else 157.3,
+            "tiles_scanned": scanned, "tiles_without_pruning": full, "pairs_per_s": n * I / avg * 1e3,
+            "scan_kernel_dispatches": [first, first + TIMED],
+            "what": ("event time = the whole call (plan, sort, scan kernel, merge, tie repair); the trace's kernel time is the scan "
+                     "kernel alone"),
             "repaired_users": repaired(eng)}
+    eng.set_option("topk_prune", 1)
     del eng, PM
 if which in ("both", "mlp"):
     U, I, E, B = 1_000_000, 100_000, 128, 1 << 22
