@@ -227,8 +227,12 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
 /* "skip_masked" (default 1): the pair kernels do not fetch the Personal_Memory row of a category whose mask weight is
  * exactly 0 -- the reference graph multiplies that row by 0 (Model_Recommender.py:82), so for finite tables the score
  * is the same to the bit and a pair moves (2 + active categories) x E x 4 bytes of rows instead of (C + 2) x E x 4.
- * The one input on which it shows is a non-finite value inside such a row (0 x inf = NaN in the literal graph); 0
- * restores the literal fetch-and-multiply.  m2d_score_pairs_mlp uses the same fact per tile: it groups a launch's pairs by
+ * A non-finite value inside such a row makes the graph's score NaN (0 x inf), so rows are left out only while every value
+ * of the three tables is finite: the engine keeps a device word for that -- set by a scan of the tables that m2d_create
+ * and m2d_tables_updated queue for the next scoring call, and by m2d_train_step / m2d_write_memory on the values they
+ * write -- and with it set every kernel fetches and multiplies everything, whatever this option says (results then equal
+ * the literal graph's, NaN positions included).  0 forces the literal fetch-and-multiply.  m2d_score_pairs_mlp uses the
+ * same fact per tile: it groups a launch's pairs by
  * the dish's pattern of non-zero weights and does not multiply the k-blocks a pattern lacks (0 = pairs as they come).
  * "user_high_table" (default 0, a serving option): calls of >= 2^18 pairs take the high-level sum from a derived table
  * uh[u][c] = <U_high[u], CE_c> (16 B per user, built by a pass over Personal_Memory and rebuilt after the engine's own
@@ -243,8 +247,14 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
  * picks between the two split-bf16 head kernels, same results within the split's rounding: 0 = matrix waves fed by
  * gather / DMA waves, 1 = every wave gathers its own rows.  "topk_grouped"
  * (default 1; see m2d_topk_users) and "topk_form" (0 / 2 = the pipelined split-bf16 retrieval kernel, 1 = its first
- * form; same results) select among retrieval kernels.
- * m2d_score_pairs* (the reference path) is always exact float32.  Unknown names: M2D_ERR_INVALID_ARG. */
+ * form; same results) select among retrieval kernels.  "topk_prune" (default 1): the pipelined retrieval kernel starts each
+ * user's scan from a lower bound of its k-th score and steps through the tiles of the mask patterns that can reach its
+ * top-k only (with 0/1 masks every dish of pattern P scores within alpha_P[u] +- |w_P[u]| max|RE[d]|; users are sorted by
+ * their pattern mask so that a block's users share patterns); the lists are the same bit for bit with 0 (every tile).
+ * m2d_score_pairs* (the reference path) is always exact float32.  Unknown names: M2D_ERR_INVALID_ARG.
+ * m2d_get_option also answers three diagnostics of the last m2d_topk_users call on the pattern-grouped kernels (they
+ * synchronise the device): "topk_repaired" (users re-ranked in id order because their k-th score was tied),
+ * "topk_tiles_scanned" / "topk_tiles_full" (32-dish tiles the blocks stepped through / would have without pruning). */
 int m2d_set_option(m2d_engine *h, const char *name, int64_t value);
 int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value);
 
