@@ -29,6 +29,14 @@
 //             {loss, global norm, scale, lr};
 //   apply     rows (Adam: all rows; others: claimed rows) and the dense dCE;
 //   cleanup   claimed rows: map entry back to -1, compact gradient row back to zero.
+// Batches of up to 1024 pairs (the reference's own: 128 per step, 8 in the memory-write branch) run the same steps as
+// TWO launches, with no memset and no device-to-device copy in between (nine launches took 57 us per SGD step):
+//   m2d_train_grad_fused   one wave per pair: claims its two slots itself (a pair that finds a slot being claimed by
+//                          another wave waits for the number), forward, loss, gradient rows; the LAST block to finish
+//                          (a ticket counter) adds up the per-block partials, writes {loss, norm, scale, lr}, Adam's
+//                          lr_t, advances the step count / beta powers, and resets the other parity's slot counters;
+//   m2d_train_apply_fused  every table in one grid: Adam walks all rows, the others the claimed rows; a row's slot and
+//                          gradient are released by the wave that applied it.
 // An out-of-range id is latched by the claim pass (m2d_check reports it) and the apply pass then leaves every
 // table and slot as it was -- TF raises InvalidArgumentError from the gather before anything is assigned.
 // Sums are float atomics: results are order-dependent in the last bits, like m2d_write_memory.
@@ -56,6 +64,11 @@ struct TrainArgs {
     int32_t *err;
     int32_t accumulate;         // 0: loss + norm only (no slots are claimed, nothing is added to gu / gd)
     float clip, lr;
+    // fused form (m2d_train_grad_fused): slot counters alternate between steps (cnt + 2 * parity), the last block finishes the step
+    int32_t *done;              // ticket counter
+    float *out;                 // caller's f32[4] {loss, norm, scale, lr}, or null
+    struct OptState *opt;
+    int32_t learner, parity;
 };
 
 __device__ __forceinline__ void train_latch(int32_t *err, int code, int64_t value, int64_t index)
@@ -351,6 +364,222 @@ __global__ __launch_bounds__(256) void m2d_train_cleanup(int32_t *map, const int
     }
 }
 
+// ---- the fused form for small batches (see the header comment) ---------------------------------------------------------
+// A row's slot in the compact gradient buffer, claimed by the first wave that meets the row: -1 free, -2 being claimed.
+// A wave that finds -2 waits for the number; the claimer publishes it without waiting for anybody, so nobody waits long.
+__device__ __forceinline__ int train_claim(int32_t *map, int32_t *slot_row, int32_t *cnt, int64_t row, int lane)
+{
+    int s = 0;
+    if (lane == 0) {
+        const int seen = atomicCAS(&map[row], -1, -2);
+        if (seen == -1) {
+            s = atomicAdd(cnt, 1);
+            slot_row[s] = (int32_t)row;
+            __hip_atomic_store(&map[row], s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            s = seen;
+            while (s < 0) s = __hip_atomic_load(&map[row], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(s);
+}
+
+__global__ __launch_bounds__(256) void m2d_train_grad_fused(TrainArgs p)
+{
+    extern __shared__ float dce_all[];                      // [4 waves][C, E] partial dCE
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const int C = p.C, E = p.E;
+    float *dce = dce_all + (size_t)wv * C * E;
+    int32_t *cnt = p.cnt + 2 * p.parity;
+    for (int i = lane; i < C * E; i += 64) dce[i] = 0.f;
+    __syncthreads();
+    double loss_acc = 0.0, sq_acc = 0.0;
+    const float invB = 1.0f / (float)p.B;
+    for (int64_t b = wave0; b < p.B; b += nwaves) {
+        const int32_t uid = p.users[b], did = p.items[b];
+        const int64_t ul = (int64_t)uid - p.user_base;
+        if (ul < 0 || ul >= p.U || did < 0 || (int64_t)did >= p.I) {      // TF raises from the gather: the step applies nothing
+            if (lane == 0)
+                train_latch(p.err, (ul < 0 || ul >= p.U) ? M2D_ERR_BAD_USER_ID : M2D_ERR_BAD_ITEM_ID,
+                            (ul < 0 || ul >= p.U) ? uid : did, b);
+            continue;
+        }
+        const int su = p.accumulate ? train_claim(p.map_u, p.slot_u, cnt + 0, ul, lane) : 0;
+        const int sd = p.accumulate ? train_claim(p.map_d, p.slot_d, cnt + 1, did, lane) : 0;
+        const float *m = p.cats + (size_t)b * C;
+        const float *urow = p.pm + (size_t)ul * (C + 1) * E;
+        const float *drow = p.re + (size_t)did * E;
+        float n = 0.f;
+        for (int c = 0; c < C; ++c) n += m[c];                                      // :77
+        float hi = 0.f, lo = 0.f;
+        for (int e = lane; e < E; e += 64) {
+            float H = 0.f, L = 0.f;
+            for (int c = 0; c < C; ++c) {
+                H = fmaf(m[c], p.ce[(size_t)c * E + e], H);                         // :67-75
+                L = fmaf(m[c], urow[(size_t)(1 + c) * E + e], L);                   // :82-90
+            }
+            hi = fmaf(urow[e], H, hi);
+            lo = fmaf(drow[e], L, lo);
+        }
+        hi = wave_sum(hi);
+        lo = wave_sum(lo);
+        const float s = __fadd_rn(__fmul_rn(p.a, hi / n), __fmul_rn(p.b, lo / n));  // :79, :93, :95-96
+        const float y = p.labels[b];
+        const float loss_b = fmaxf(s, 0.f) - s * y + log1pf(expf(-fabsf(s)));       // :101
+        const float gs = (1.0f / (1.0f + expf(-s)) - y) * invB;                     // d mean / d s_b
+        const float qh = gs * p.a / n, ql = gs * p.b / n;
+        float *gu = p.gu + (size_t)su * (C + 1) * E;
+        float *gd = p.gd + (size_t)sd * E;
+        float sq = 0.f;
+        for (int e = lane; e < E; e += 64) {
+            float H = 0.f, L = 0.f;
+            for (int c = 0; c < C; ++c) {
+                H = fmaf(m[c], p.ce[(size_t)c * E + e], H);
+                L = fmaf(m[c], urow[(size_t)(1 + c) * E + e], L);
+            }
+            const float uh = urow[e], it = drow[e];
+            const float v0 = qh * H, vd = ql * L;
+            sq = fmaf(v0, v0, sq);
+            sq = fmaf(vd, vd, sq);
+            if (p.accumulate) {
+                atomicAdd(gu + e, v0);
+                atomicAdd(gd + e, vd);
+            }
+            for (int c = 0; c < C; ++c) {
+                const float vc = (ql * m[c]) * it;
+                sq = fmaf(vc, vc, sq);
+                if (p.accumulate && m[c] != 0.f) atomicAdd(gu + (size_t)(1 + c) * E + e, vc);
+                dce[c * E + e] += (qh * m[c]) * uh;                                 // this lane owns column e
+            }
+        }
+        sq_acc += (double)wave_sum(sq);
+        loss_acc += (double)loss_b;
+    }
+    __shared__ double wave_acc[4][2];
+    __shared__ int s_ticket;
+    if (lane == 0) { wave_acc[wv][0] = loss_acc; wave_acc[wv][1] = sq_acc; }
+    __syncthreads();
+    // dCE: a few dozen blocks at most -- each adds its C x E sums into the (zeroed) dense gradient; the apply pass zeroes it again
+    for (int i = threadIdx.x; i < C * E; i += 256) {
+        const float t = (dce_all[i] + dce_all[C * E + i]) + (dce_all[2 * C * E + i] + dce_all[3 * C * E + i]);
+        if (t != 0.f) atomicAdd(p.gce + i, t);
+    }
+    if (threadIdx.x < 2)
+        p.part_acc[(size_t)blockIdx.x * 2 + threadIdx.x] =
+            (wave_acc[0][threadIdx.x] + wave_acc[1][threadIdx.x]) + (wave_acc[2][threadIdx.x] + wave_acc[3][threadIdx.x]);
+    // the last block to get here finishes the step (every other block's partials and gradient rows are then in memory)
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = atomicAdd(p.done, 1);
+    __syncthreads();
+    if (s_ticket != (int)gridDim.x - 1) return;
+    __threadfence();
+    __shared__ double red[4][3];
+    double s2 = 0.0, l = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < C * E; i += 256) {        // |dCE|^2 (values other blocks added: read past this CU's L1)
+        const float t = __builtin_nontemporal_load(p.gce + i);
+        s2 += (double)t * (double)t;
+        if (!p.accumulate) p.gce[i] = 0.f;                  // a loss-only call has no apply pass to zero it
+    }
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) {   // the blocks' loss / square sums (at most 256 blocks: one each)
+        l += __builtin_nontemporal_load(p.part_acc + (size_t)b * 2);
+        q += __builtin_nontemporal_load(p.part_acc + (size_t)b * 2 + 1);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s2 += __shfl_xor(s2, off, 64);
+        l += __shfl_xor(l, off, 64);
+        q += __shfl_xor(q, off, 64);
+    }
+    if (lane == 0) { red[wv][0] = s2; red[wv][1] = l; red[wv][2] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        l = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+        q = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
+        const float norm = (float)sqrt(q + ((red[0][0] + red[1][0]) + (red[2][0] + red[3][0])));
+        const float loss = (float)(l / (double)p.B), scale = p.clip * fminf(1.0f / norm, 1.0f / p.clip);
+        p.scal[0] = loss; p.scal[1] = norm; p.scal[2] = scale; p.scal[3] = p.lr;
+        if (p.out) { p.out[0] = loss; p.out[1] = norm; p.out[2] = scale; p.out[3] = p.lr; }
+        float lr_t = p.lr;
+        if (p.learner == M2D_LEARNER_ADAM) lr_t = p.lr * sqrtf(1.0f - p.opt->b2p) / (1.0f - p.opt->b1p);   // AdamOptimizer._apply_dense
+        p.scal[4] = lr_t;
+        if (p.accumulate && __hip_atomic_load(&p.err[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {   // the step applies: AdamOptimizer._finish
+            p.opt->b1p *= 0.9f;
+            p.opt->b2p *= 0.999f;
+            p.opt->steps += 1;
+        }
+        p.cnt[2 * (p.parity ^ 1)] = 0;                       // the next step's slot counters (its own were read by this step's apply)
+        p.cnt[2 * (p.parity ^ 1) + 1] = 0;
+        *p.done = 0;
+    }
+}
+
+// One grid over the three tables.  Table t holds R[t] rows of W[t] floats; its work items are all rows (ALL: Adam, and the
+// dense Category_Embedding gradient) or the claimed rows slot_row[0 .. *count).  After a row is applied (or found not to
+// be -- an id error was latched: nothing is assigned) its slot and gradient row are released by the same wave.
+struct ApplyTab {
+    float *var, *s0, *s1, *G;
+    int32_t *map, *slot_row;
+    const int32_t *count;
+    int64_t R;
+    int32_t W, all;
+};
+struct ApplyArgs {
+    ApplyTab t[3];
+    const float *scal;
+    const int32_t *err;
+    int32_t *nonfinite;
+    RuleArgs r;
+};
+
+__global__ __launch_bounds__(256) void m2d_train_apply_fused(ApplyArgs p)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    const bool ok = __builtin_amdgcn_readfirstlane(p.err[0]) == 0;
+    RuleArgs r = p.r;
+    const float scale = p.scal[2];
+    r.lr = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.scal[4])));   // Adam: lr_t of this step
+    const bool two = r.rule == M2D_LEARNER_ADAM || r.rule == M2D_LEARNER_RMSPROP, one = two || r.rule == M2D_LEARNER_ADAGRAD;
+    float fin = 0.f;
+    int64_t n[3], tot = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        n[t] = p.t[t].all ? p.t[t].R : (int64_t)*p.t[t].count;
+        tot += n[t];
+    }
+    for (int64_t i = wave0; i < tot; i += nwaves) {
+        const int t = i < n[0] ? 0 : (i < n[0] + n[1] ? 1 : 2);
+        const ApplyTab &tb = p.t[t];
+        const int64_t k = i - (t == 0 ? 0 : (t == 1 ? n[0] : n[0] + n[1]));
+        int64_t row, grow;
+        if (tb.all) { row = k; grow = tb.map ? (int64_t)tb.map[k] : k; }
+        else { row = tb.slot_row[k]; grow = k; }
+        const int W = tb.W;
+        const size_t base = (size_t)row * W;
+        float *g = grow >= 0 ? tb.G + (size_t)grow * W : nullptr;
+        if (ok && (g || r.rule == M2D_LEARNER_ADAM)) {     // Adam decays and moves every row; the others touch rows with a gradient
+            for (int e = lane; e < W; e += 64) {
+                float v = tb.var[base + e], a = one ? tb.s0[base + e] : 0.f, b = two ? tb.s1[base + e] : 0.f;
+                apply_one(r, g ? g[e] * scale : 0.f, v, a, b);
+                fin = fmaf(v, 0.f, fin);
+                tb.var[base + e] = v;
+                if (one) tb.s0[base + e] = a;
+                if (two) tb.s1[base + e] = b;
+            }
+        }
+        if (g && (tb.map || t == 2)) {                      // release: the gradient row back to zero, the slot back to free
+            for (int e = lane; e < W; e += 64) g[e] = 0.f;
+            if (tb.map && lane == 0) tb.map[row] = -1;
+        }
+    }
+    if (fin != fin) *p.nonfinite = 1;                       // a diverged run: the forward kernels stop leaving rows out (0 * inf = NaN, :82)
+}
+
 __global__ __launch_bounds__(256) void m2d_fill_kernel(float *x, int64_t n, float v)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = v;
@@ -382,6 +611,8 @@ struct m2d_train_state {
     float *part_ce = nullptr;           // [num_cu * 8, C, E]
     double *part_acc = nullptr;         // [num_cu * 8, 2]
     int64_t cap = 0;                    // pairs the compact buffers hold
+    int32_t *done = nullptr;            // fused form: ticket counter of m2d_train_grad_fused
+    int parity = 0;                     // fused form: which pair of slot counters the next step uses
 };
 
 void m2d_train_release(m2d_engine *h)
@@ -392,7 +623,7 @@ void m2d_train_release(m2d_engine *h)
         for (float *q : tb)
             if (q) (void)hipFree(q);
     for (void *q : {(void *)t->map_u, (void *)t->map_d, (void *)t->slot_u, (void *)t->slot_d, (void *)t->cnt, (void *)t->gu,
-                    (void *)t->gd, (void *)t->gce, (void *)t->scal, (void *)t->part_ce, (void *)t->part_acc, (void *)t->opt})
+                    (void *)t->gd, (void *)t->gce, (void *)t->scal, (void *)t->part_ce, (void *)t->part_acc, (void *)t->opt, (void *)t->done})
         if (q) (void)hipFree(q);
     delete t;
     h->train = nullptr;
@@ -417,12 +648,16 @@ int m2d_train_setup(m2d_engine *h, int32_t learner, float lr, float clip_norm, h
     M2D_HIP_TRY(h, hipMalloc((void **)&t->map_d, (size_t)h->I * 4));
     hipLaunchKernelGGL(m2d_fill_i32_kernel, dim3(blocks_for(h, h->U / 64 + 1)), dim3(256), 0, stream, t->map_u, h->U, -1);
     hipLaunchKernelGGL(m2d_fill_i32_kernel, dim3(blocks_for(h, h->I / 64 + 1)), dim3(256), 0, stream, t->map_d, h->I, -1);
-    M2D_HIP_TRY(h, hipMalloc((void **)&t->cnt, 2 * 4));
+    M2D_HIP_TRY(h, hipMalloc((void **)&t->cnt, 4 * 4));                 // two pairs: the fused form alternates between them
+    M2D_HIP_TRY(h, hipMemsetAsync(t->cnt, 0, 16, stream));
+    M2D_HIP_TRY(h, hipMalloc((void **)&t->done, 4));
+    M2D_HIP_TRY(h, hipMemsetAsync(t->done, 0, 4, stream));
     M2D_HIP_TRY(h, hipMalloc((void **)&t->gce, (size_t)n[2] * 4));
-    M2D_HIP_TRY(h, hipMalloc((void **)&t->scal, 4 * 4));
+    M2D_HIP_TRY(h, hipMemsetAsync(t->gce, 0, (size_t)n[2] * 4, stream));
+    M2D_HIP_TRY(h, hipMalloc((void **)&t->scal, 8 * 4));
     M2D_HIP_TRY(h, hipMalloc((void **)&t->part_ce, (size_t)h->num_cu * 8 * n[2] * 4));
     M2D_HIP_TRY(h, hipMalloc((void **)&t->part_acc, (size_t)h->num_cu * 8 * 2 * 8));
-    M2D_HIP_TRY(h, hipMemsetAsync(t->scal, 0, 16, stream));
+    M2D_HIP_TRY(h, hipMemsetAsync(t->scal, 0, 32, stream));
     M2D_HIP_TRY(h, hipMalloc((void **)&t->opt, sizeof(OptState)));
     const OptState st0 = {0.9f, 0.999f, 0};
     M2D_HIP_TRY(h, hipMemcpyAsync(t->opt, &st0, sizeof st0, hipMemcpyHostToDevice, stream));
@@ -456,7 +691,37 @@ int m2d_launch_train_step(m2d_engine *h, const int32_t *users, const int32_t *it
     a.map_u = t->map_u; a.map_d = t->map_d; a.slot_u = t->slot_u; a.slot_d = t->slot_d; a.cnt = t->cnt;
     a.gu = t->gu; a.gd = t->gd; a.gce = t->gce; a.scal = t->scal; a.err = h->err_dev;
     a.accumulate = apply ? 1 : 0; a.clip = t->clip; a.lr = t->lr;      // Global_Step never moves (:240): lr is constant
-    M2D_HIP_TRY(h, hipMemsetAsync(t->cnt, 0, 8, stream));
+    a.done = t->done; a.out = out; a.opt = t->opt; a.learner = t->learner; a.parity = t->parity;
+    a.part_ce = t->part_ce; a.part_acc = t->part_acc;
+    const size_t lds_f = (size_t)4 * C * E * 4;
+    if (B <= 1024 && lds_f <= 48 * 1024 && h->opt_variant != 14) {     // the fused form ("variant" = 14: the nine-launch form, A/B)
+        a.nblocks = (int32_t)blocks_for(h, B);
+        hipLaunchKernelGGL(m2d_train_grad_fused, dim3((unsigned)a.nblocks), dim3(256), lds_f, stream, a);
+        M2D_HIP_TRY(h, hipGetLastError());
+        h->last_kernel = "m2d_train_grad_fused";
+        if (!apply) return M2D_OK;
+        ApplyArgs ap;
+        const bool adam = t->learner == M2D_LEARNER_ADAM;
+        int32_t *cnt = t->cnt + 2 * t->parity;
+        ap.t[0] = {a.pm, t->slot[0][0], t->slot[0][1], t->gu, t->map_u, t->slot_u, cnt + 0, h->U, W, adam ? 1 : 0};
+        ap.t[1] = {a.re, t->slot[1][0], t->slot[1][1], t->gd, t->map_d, t->slot_d, cnt + 1, h->I, E, adam ? 1 : 0};
+        ap.t[2] = {a.ce, t->slot[2][0], t->slot[2][1], t->gce, nullptr, nullptr, nullptr, C, E, 1};
+        ap.scal = t->scal; ap.err = h->err_dev; ap.nonfinite = h->nonfinite_dev;
+        ap.r.rule = t->learner; ap.r.lr = t->lr; ap.r.b1 = ap.r.b2 = ap.r.eps = 0.f;
+        if (adam) { ap.r.b1 = 0.9f; ap.r.b2 = 0.999f; ap.r.eps = 1e-8f; }
+        else if (t->learner == M2D_LEARNER_RMSPROP) { ap.r.b1 = 0.9f; ap.r.b2 = 0.0f; ap.r.eps = 1e-10f; }
+        const int64_t rows = adam ? h->U + h->I + C : 2 * B + C;
+        hipLaunchKernelGGL(m2d_train_apply_fused, dim3(blocks_for(h, rows)), dim3(256), 0, stream, ap);
+        M2D_HIP_TRY(h, hipGetLastError());
+        t->parity ^= 1;
+        h->dish_vec_valid = false;      // everything derived from the tables is stale now
+        h->grp_valid = false;
+        h->user_high_valid = false;
+        return M2D_OK;
+    }
+    int32_t *cnt_now = t->cnt + 2 * t->parity;              // (the fused form may have left the other pair in use)
+    a.cnt = cnt_now;
+    M2D_HIP_TRY(h, hipMemsetAsync(cnt_now, 0, 8, stream));
     M2D_HIP_TRY(h, hipMemsetAsync(t->gce, 0, (size_t)C * E * 4, stream));
     if (apply) {
         hipLaunchKernelGGL(m2d_train_claim, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, a);
@@ -477,7 +742,10 @@ int m2d_launch_train_step(m2d_engine *h, const int32_t *users, const int32_t *it
     M2D_HIP_TRY(h, hipGetLastError());
     if (out) M2D_HIP_TRY(h, hipMemcpyAsync(out, t->scal, 16, hipMemcpyDeviceToDevice, stream));
     h->last_kernel = "m2d_train_grad";
-    if (!apply) return M2D_OK;
+    if (!apply) {
+        M2D_HIP_TRY(h, hipMemsetAsync(t->gce, 0, (size_t)C * E * 4, stream));   // (the fused form expects the dense gradient at zero)
+        return M2D_OK;
+    }
 
     RuleArgs r;
     r.rule = t->learner; r.lr = t->lr; r.b1 = r.b2 = r.eps = 0.f;
@@ -487,8 +755,8 @@ int m2d_launch_train_step(m2d_engine *h, const int32_t *users, const int32_t *it
         r.b1 = 0.9f; r.b2 = 0.0f; r.eps = 1e-10f;
     }
     struct Tab { float *var; float *G; int32_t *map; int32_t *slot_row; int32_t *count; int64_t R; int32_t W; int idx; };
-    const Tab tabs[3] = {{a.pm, t->gu, t->map_u, t->slot_u, t->cnt + 0, h->U, W, 0},
-                         {a.re, t->gd, t->map_d, t->slot_d, t->cnt + 1, h->I, E, 1},
+    const Tab tabs[3] = {{a.pm, t->gu, t->map_u, t->slot_u, a.cnt + 0, h->U, W, 0},
+                         {a.re, t->gd, t->map_d, t->slot_d, a.cnt + 1, h->I, E, 1},
                          {a.ce, t->gce, nullptr, nullptr, nullptr, C, E, 2}};
     for (const Tab &tb : tabs) {
         float *s0 = t->slot[tb.idx][0], *s1 = t->slot[tb.idx][1];
@@ -504,11 +772,13 @@ int m2d_launch_train_step(m2d_engine *h, const int32_t *users, const int32_t *it
 #undef M2D_APPLY
         M2D_HIP_TRY(h, hipGetLastError());
     }
-    hipLaunchKernelGGL(m2d_train_cleanup, dim3(blocks_for(h, B)), dim3(256), 0, stream, t->map_u, t->slot_u, t->cnt + 0, t->gu, W,
+    hipLaunchKernelGGL(m2d_train_cleanup, dim3(blocks_for(h, B)), dim3(256), 0, stream, t->map_u, t->slot_u, a.cnt + 0, t->gu, W,
                        h->err_dev, (OptState *)nullptr);
-    hipLaunchKernelGGL(m2d_train_cleanup, dim3(blocks_for(h, B)), dim3(256), 0, stream, t->map_d, t->slot_d, t->cnt + 1, t->gd, E,
+    hipLaunchKernelGGL(m2d_train_cleanup, dim3(blocks_for(h, B)), dim3(256), 0, stream, t->map_d, t->slot_d, a.cnt + 1, t->gd, E,
                        h->err_dev, t->opt);               // also advances the step count / beta powers if the step applied
     M2D_HIP_TRY(h, hipGetLastError());
+    M2D_HIP_TRY(h, hipMemsetAsync(cnt_now, 0, 8, stream));   // the fused form expects its slot counters ...
+    M2D_HIP_TRY(h, hipMemsetAsync(t->gce, 0, (size_t)C * E * 4, stream));   // ... and the dense gradient at zero
     // everything derived from Recipe_Embedding / Category_Embedding is stale now
     h->dish_vec_valid = false;
     h->grp_valid = false;

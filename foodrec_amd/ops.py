@@ -208,14 +208,29 @@ class ScoringEngine:
         float32[4]: loss, global gradient norm, clip scale, learning rate.  apply=False: loss / norm only."""
         self._check_ids(users, items)
         B = users.numel()
-        f = lambda t, n: t.to(device=self.device, dtype=torch.float32).reshape(B, n).contiguous()
-        cats, labels = f(cats, self.C), f(labels, 1)
+        # a step is two small launches at the reference's batch sizes: the wrapper's own cost counts.  Tensors that are
+        # already what the kernel reads (contiguous float32 / int32 on the device) are passed as they are.
+        ok = lambda t, n: (t.dtype == torch.float32 and t.device == self.device and t.is_contiguous() and t.numel() == B * n)
+        if not ok(cats, self.C):
+            cats = cats.to(device=self.device, dtype=torch.float32).reshape(B, self.C).contiguous()
+        if not ok(labels, 1):
+            labels = labels.to(device=self.device, dtype=torch.float32).reshape(B, 1).contiguous()
+        if not users.is_contiguous():
+            users = users.contiguous()
+        if not items.is_contiguous():
+            items = items.contiguous()
         out = torch.empty(4, dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            rc = _native.lib().m2d_train_step(self._h, users.contiguous().data_ptr(), items.contiguous().data_ptr(),
-                                              cats.data_ptr(), labels.data_ptr(), B, 1 if apply else 0, out.data_ptr(),
-                                              _stream_ptr())
-        _native.raise_for(rc, self._h)
+        fn = _native.lib().m2d_train_step
+        idx = self.device.index
+        if _raw_stream is not None and _cur_device is not None and idx is not None and _cur_device() == idx:
+            rc = fn(self._h, users.data_ptr(), items.data_ptr(), cats.data_ptr(), labels.data_ptr(), B, 1 if apply else 0,
+                    out.data_ptr(), _raw_stream(idx))
+        else:
+            with torch.cuda.device(self.device):
+                rc = fn(self._h, users.data_ptr(), items.data_ptr(), cats.data_ptr(), labels.data_ptr(), B, 1 if apply else 0,
+                        out.data_ptr(), _stream_ptr())
+        if rc:
+            _native.raise_for(rc, self._h)
         return out
 
     def train_slot(self, table: int, slot: int, restore: Optional[torch.Tensor] = None) -> torch.Tensor:

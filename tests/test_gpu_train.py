@@ -38,14 +38,18 @@ def _engine(PM, RE, CE):
 
 
 @pytest.mark.parametrize("learner", ["adam", "sgd", "adagrad", "rmsprop"])
-@pytest.mark.parametrize("U,I,C,E,B", [(300, 100, 4, 32, 128), (64, 40, 4, 200, 8), (50, 30, 3, 6, 257), (2000, 500, 4, 64, 4096)])
-def test_train_steps_match_restatement(learner, U, I, C, E, B):
+@pytest.mark.parametrize("U,I,C,E,B,form", [(300, 100, 4, 32, 128, 0), (64, 40, 4, 200, 8, 0), (50, 30, 3, 6, 257, 0), (2000, 500, 4, 64, 4096, 0),
+                                            (300, 100, 4, 32, 128, 14), (64, 40, 4, 200, 1000, 0), (64, 40, 4, 200, 1000, 14)])
+def test_train_steps_match_restatement(learner, U, I, C, E, B, form):
+    """Batches of up to 1024 pairs run the two-launch form (m2d_train_grad_fused + m2d_train_apply_fused), larger ones --
+    or option "variant" = 14 -- the nine-launch form; same step either way."""
     import torch
     from oracle import train_oracle as T
     PM, RE, CE, *_ = random_case(U, I, C, E, 1, seed=U + E)
     PM, RE, CE = PM * 3, RE * 3, CE * 3
     lr = 0.01
     eng = _engine(PM, RE, CE)
+    eng.set_option("variant", form)
     eng.train_begin(learner, lr)
     st = T.TrainState(PM, RE, CE, learner, lr)
     steps = 3
@@ -59,7 +63,7 @@ def test_train_steps_match_restatement(learner, U, I, C, E, B):
         assert abs(norm - ref_norm) <= 1e-5 * max(1.0, ref_norm), (k, norm, ref_norm)
         assert got_lr == np.float32(lr)
         assert scale == pytest.approx(5.0 * min(1.0 / ref_norm, 0.2), rel=1e-5)
-    assert eng.last_kernel() == "m2d_train_grad"
+    assert eng.last_kernel() == ("m2d_train_grad_fused" if B <= 1024 and form != 14 else "m2d_train_grad")
     tol = 1e-3 * lr * steps if learner in ("adam", "rmsprop") else 1e-5
     for name, got, ref, ini in (("PM", eng.pm, st.PM, PM), ("RE", eng.re, st.RE, RE), ("CE", eng.ce, st.CE, CE)):
         got = got.cpu().numpy().astype(np.float64)
@@ -324,3 +328,39 @@ def test_checkpoint_save_restore_resumes_training(tmp_path):
     wrong = types.SimpleNamespace(**{**vars(args), "learner": "sgd"})
     with pytest.raises(ValueError, match="trained with adam"):
         Model(wrong, PM.copy(), RE.copy(), CE.copy(), GM.copy()).restore(ck)
+
+
+def test_the_two_forms_of_a_step_can_alternate():
+    """The two-launch form (small batches) and the nine-launch form share the slot maps, the compact gradient rows, the dense
+    gradient and the optimizer state: steps of both kinds, loss-only calls and a refused step in between end where the
+    restatement ends."""
+    import torch
+    from oracle import train_oracle as T
+    U, I, C, E = 500, 200, 4, 64
+    PM, RE, CE, *_ = random_case(U, I, C, E, 1, seed=77)
+    PM, RE, CE = PM * 3, RE * 3, CE * 3
+    eng = _engine(PM, RE, CE)
+    eng.train_begin("adam", 0.01)
+    st = T.TrainState(PM, RE, CE, "adam", 0.01)
+    dev = lambda x: torch.as_tensor(x, device="cuda")
+    sizes = [128, 2048, 64, 64, 1500, 256, 1024, 1025, 8]
+    for k, B in enumerate(sizes):
+        users, items, cats, labels = next(iter(_batches(U, I, C, B, 1, seed=100 + k)))
+        if k in (2, 5):                                      # a loss-only call before the step: leaves everything as it was
+            lo = eng.train_step(dev(users), dev(items), dev(cats), dev(labels), apply=False).cpu().numpy()
+            ref_loss, _ = st.step(users, items, cats, labels, apply=False)
+            assert abs(lo[0] - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+        if k == 4:                                           # a refused step (an id out of range) assigns nothing, in either form
+            for Bb in (64, 2000):
+                bu, bi, bc, bl = next(iter(_batches(U, I, C, Bb, 1, seed=300 + Bb)))
+                bu = bu.copy(); bu[Bb // 2] = U + 5
+                eng.train_step(dev(bu), dev(bi), dev(bc), dev(bl))
+                with pytest.raises(IndexError):
+                    eng.check()
+        ref_loss, ref_norm = st.step(users, items, cats, labels)
+        out = eng.train_step(dev(users), dev(items), dev(cats), dev(labels)).cpu().numpy(); eng.check()
+        assert abs(out[0] - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (k, B)
+        assert abs(out[1] - ref_norm) <= 1e-5 * max(1.0, ref_norm), (k, B)
+    assert eng.train_steps() == len(sizes)
+    for got, ref in ((eng.pm, st.PM), (eng.re, st.RE), (eng.ce, st.CE)):
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-3 * 0.01 * len(sizes)
