@@ -1,10 +1,16 @@
+# Run ON THE GPU BOX: the bench lines kept under profiles/ (one JSON line each, gpurun_out/r03/lines/).
 set -o pipefail
-python bench.py > gpurun_out/b_default.json 2> gpurun_out/b_default.err; echo default rc=$?
-python bench.py --embed 128 --no-cpu-baseline > gpurun_out/b_e128.json 2>/dev/null; echo e128 rc=$?
-python bench.py --users 10000000 --dishes 1000000 --no-cpu-baseline > gpurun_out/b_10M.json 2>/dev/null; echo 10M rc=$?
-python bench.py --users 64657 --dishes 4548 --embed 200 --no-cpu-baseline > gpurun_out/b_ref200.json 2>/dev/null; echo ref200 rc=$?
-python bench.py --workload ingredients --no-cpu-baseline > gpurun_out/b_ing.json 2>/dev/null; echo ing rc=$?
-python bench.py --opt skip_masked=0 --no-cpu-baseline --no-side > gpurun_out/b_noskip.json 2>/dev/null; echo noskip rc=$?
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --no-cpu-baseline > gpurun_out/b_dist1.json 2>/dev/null; echo dist1 rc=$?
-for f in default e128 10M ref200 ing noskip dist1; do tail -1 gpurun_out/b_$f.json | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$f', round(d['value']/1e9,3), round(d['ms_per_step'],4), r.get('bound'), r.get('frac'), r.get('algorithmic_bytes_per_pair'), (r.get('hbm_only') or {}).get('frac_of_spec_peak'), (r.get('no_reuse') or {}).get('frac'))"; done
+D=gpurun_out/r03/lines; mkdir -p $D
+python bench.py > $D/bench_default.json 2> $D/bench_default.err; echo default rc=$?
+python bench.py --embed 128 --no-cpu-baseline --scaling-users 0 > $D/bench_e128.json 2>/dev/null; echo e128 rc=$?
+python bench.py --users 10000000 --dishes 1000000 --no-cpu-baseline --scaling-users 0 > $D/bench_10Musers_1Mdishes.json 2>/dev/null; echo 10M rc=$?
+python bench.py --workload ingredients --no-cpu-baseline --scaling-users 0 > $D/bench_ingredients.json 2>/dev/null; echo ing rc=$?
+python bench.py --workload mlp --embed 128 --scaling-users 0 > $D/bench_mlp_e128.json 2>/dev/null; echo mlp rc=$?
+python bench.py --config 3 --steps 2 --warmup 1 --no-cpu-baseline > $D/bench_config3.json 2>/dev/null; echo config3 rc=$?
+python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline > $D/bench_config4.json 2>/dev/null; echo config4 rc=$?
+python bench.py --workload topk --no-cpu-baseline > $D/bench_topk_100kdishes_e64.json 2>/dev/null; echo topk rc=$?
+python bench.py --workload train --learner sgd --steps 300 > $D/bench_train_sgd_refdefault.json 2>/dev/null; echo sgd rc=$?
+python bench.py --workload train --learner adam --steps 300 > $D/bench_train_adam_refdefault.json 2>/dev/null; echo adam rc=$?
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --no-cpu-baseline > $D/bench_dist1.json 2>/dev/null; echo dist1 rc=$?
+for f in $D/*.json; do tail -1 $f | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$f'.split('/')[-1], round(d['value']/1e9,3), 'G/s', round(d['ms_per_step'],4), 'ms', r.get('bound'), r.get('frac'))"; done
