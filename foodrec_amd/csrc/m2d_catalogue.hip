@@ -2165,15 +2165,43 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
                 cand[g] = rowmap[g] != 0u;
                 multi |= __ballot((rowmap[g] & (rowmap[g] - 1u)) != 0u);                      // two or more bits set
             }
-            if (multi != 0ull) {                           // immediate per-row path (first tiles of a scan, then rare)
+            if (multi != 0ull) {                           // immediate path: some lane holds two or more candidates of this tile
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
+                    // Two ways to get them in.  Row by row: every row in which SOME lane has a candidate is inserted by the
+                    // whole wave (about 55 VALU a row) -- the first tiles of a scan, where every lane wants most rows.
+                    // Lane by lane: each lane takes its own next candidate row (its map's highest bit), the value is
+                    // picked out of the sixteen accumulators by sixteen compares and selects, one insertion per pass
+                    // (about 85 VALU a pass, passes = the most candidates any lane holds).  In the tiles of a pattern the
+                    // block's users all want -- the only tiles a pruned scan still visits -- nearly every row has a taker
+                    // but a lane has two or three: 16 x 55 against 3 x 85.
+                    const uint32_t pc = (uint32_t)__builtin_popcount(rowmap[g]);
+                    const bool b5 = __ballot(pc >= 5u) != 0ull, b4 = __ballot(pc >= 4u) != 0ull, b3 = __ballot(pc >= 3u) != 0ull;
+                    int rows_any = 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if (m[g][r] != 0ull) {
-                            const float ol = rs[g][KR - 1], xv = accP[g][r] + alpha_prev[g];
+                    for (int r = 0; r < 16; ++r) rows_any += m[g][r] != 0ull ? 1 : 0;
+                    if (!b5 && (2 + (b3 ? 1 : 0) + (b4 ? 1 : 0)) * 85 < rows_any * 55) {
+                        uint32_t rm = rowmap[g];
+                        while (__ballot(rm != 0u) != 0ull) {        // wave-uniform; a lane's rows in ascending order
+                            const bool has = rm != 0u;
+                            const int r = __builtin_clz(rm | 1u) - 16;
+                            float xv = -INFINITY;
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) xv = (has && r == q) ? accP[g][q] : xv;
+                            xv += alpha_prev[g];                    // (-inf stays -inf: a lane without a candidate inserts nothing)
+                            const float ol = rs[g][KR - 1];
                             sorted_insert_inplace<KR>(rs[g], ri[g], xv, sbase + (r & 3) + 8 * (r >> 2));
                             tie_mask[g] = tie_update(tie_mask[g], xv, ol, rs[g][KR - 1]);
+                            rm &= ~(0x8000u >> r);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            if (m[g][r] != 0ull) {
+                                const float ol = rs[g][KR - 1], xv = accP[g][r] + alpha_prev[g];
+                                sorted_insert_inplace<KR>(rs[g], ri[g], xv, sbase + (r & 3) + 8 * (r >> 2));
+                                tie_mask[g] = tie_update(tie_mask[g], xv, ol, rs[g][KR - 1]);
+                            }
                         }
                     }
                     share_threshold(g);
