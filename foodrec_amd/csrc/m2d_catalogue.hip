@@ -2396,16 +2396,14 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     a.plan = nullptr; a.order = nullptr; a.tiles_scanned = nullptr;
     const int64_t ublocks = (nU + 32 * WAVES - 1) / (32 * WAVES);
     int nsplit = pick_splits(h, ublocks, a.tiles, 2 * TPS, 512);
-    if (BF16X3 && !HV && h->opt_topk_form != 1 && h->opt_topk_prune != 0 && h->opt_variant < 100) {
+    if (BF16X3 && !HV && h->opt_topk_form != 1 && h->opt_topk_prune != 0 && h->opt_variant < 100 && ublocks >= 24) {
         // Pattern pruning makes the blocks unequal -- a block of users with one relevant pattern steps through a fifteenth of
-        // the catalogue, one whose users need most patterns through all of it -- so the launch is cut into at least eight
-        // workgroups per CU (dish-range splits) for the dispatcher to balance (65 536 users x 100 k dishes: 2.7 ms with one
-        // split, 2.0 with eight; x 1 M dishes, E = 128: 34 -> 15 ms)
-        int64_t want = (8 * (int64_t)h->num_cu + ublocks - 1) / ublocks;
-        const int64_t cap = a.tiles / (4 * TPS) > 1 ? a.tiles / (4 * TPS) : 1;
-        if (want > cap) want = cap;
-        if (want > 64) want = 64;
-        if (want > nsplit) nsplit = (int)want;
+        // the catalogue, one whose users need most patterns through all of it -- so a launch with many user blocks is cut into
+        // eight dish ranges for the dispatcher to balance (65 536 users x 100 k dishes: 2.7 ms with one split, 1.7 with
+        // eight; 8 192 users: 0.57 ms with eight, 0.66 with sixteen, 1.0 with 64 -- every piece starts its lists from the
+        // scan-start bound again, so more pieces re-insert more).  Few blocks: the split count of the unpruned launch.
+        nsplit = 8;
+        if (a.tiles / (4 * TPS) < 8) nsplit = a.tiles / (4 * TPS) > 1 ? (int)(a.tiles / (4 * TPS)) : 1;
     }
     a.nsplit = nsplit;
     // tie values (floats): per (user, split), per (user, group of 64 splits) when the merge takes two passes, per user;

@@ -14,7 +14,9 @@ CE = torch.randn((C, E), generator=g, device=dev) * s
 pat = torch.randint(1, 16, (I,), generator=g, device=dev, dtype=torch.int32)
 cats = ((pat[:, None] >> torch.arange(C, device=dev, dtype=torch.int32)[None, :]) & 1).float()
 eng = foodrec_amd.ScoringEngine(PM, RE, CE); eng.set_dish_categories(cats)
-for n in (1, 8, 32, 256, 1024, 8192):
+for kv in sys.argv[3:]:                                     # engine options, name=value
+    eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+for n in (1, 8, 32, 256, 1024, 8192, 32768):
     users = torch.randperm(U, generator=g, device=dev)[:n].to(torch.int32)
     for _ in range(3):
         eng.topk_users(users, 10)
