@@ -609,120 +609,176 @@ struct RepairArgs {
     int32_t *out_ids;
 };
 
+__device__ __forceinline__ float row16_sum(float x)
+{
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xf, 0xf, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false));
+    return x;
+}
+
 __device__ __forceinline__ bool repair_ahead(float s, int32_t i, float t, int32_t j)
 {
     return i >= 0 && (j < 0 || s > t || (s == t && i < j));       // (score desc, id asc); id < 0: no entry
 }
 
+// UB listed users per pass over a dish range: a dish row is read once and scored for all of them (one user per pass read the
+// whole f32 table per listed user -- 230 MB for nine users of a 100 k-dish catalogue, 73 us; eight per pass: two passes).
+template <int UB, bool HVR>
 __global__ __launch_bounds__(1024) void m2d_topk_repair_scan(RepairArgs p)
 {
     extern __shared__ __align__(16) float rsm[];
-    constexpr int C = 4, NG = 64, NP = 1 << C, ND = 2;      // C = 4 (as the pattern-grouped kernels); 64 groups of 16 lanes; ND dishes in flight per group
+    constexpr int C = 4, NG = 64, NP = 1 << C, ND = 2;   // C = 4 (as the pattern-grouped kernels); 64 groups of 16 lanes; ND dishes in flight per group
     const int E = p.E, E4 = E >> 2, k = p.k, W = (C + 1) * E;
-    float *um = rsm;                                        // [(C+1) E] this user's block
-    float *wp = um + W;                                     // [NP][E]   sum of the pattern's low-level rows (0/1 masks: :82 summed over c)
-    float *ls = wp + NP * E;                                // [NG groups][k] scores
-    int32_t *li = reinterpret_cast<int32_t *>(ls + NG * k);
-    __shared__ float hc[C], alpha[NP];                      // <U_high, CE_c>; sum over the pattern's categories (:67-75)
-    const int t = threadIdx.x, lane = t & 63, j = lane & 15, grp = t >> 4;
+    float *um = rsm;                                        // [UB][(C+1) E] the users' blocks
+    float *wp = um + UB * W;                                // [UB][NP][E]   sum of the pattern's low-level rows (0/1 masks: :82 summed over c)
+    float *ls = wp + UB * NP * E;                           // [UB][NG groups][k] scores
+    int32_t *li = reinterpret_cast<int32_t *>(ls + UB * NG * k);
+    __shared__ float hc[UB][C], alpha[UB][NP];              // <U_high, CE_c>; sum over the pattern's categories (:67-75)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, j = lane & 15, grp = t >> 4;
     const int count = min(p.tie_list[0], p.cap);
     const int64_t per = (p.I + REPAIR_SPLITS - 1) / REPAIR_SPLITS;
     const int64_t d0 = (int64_t)blockIdx.x * per, d1 = min(p.I, d0 + per);
-    for (int f = blockIdx.y; f < count; f += gridDim.y) {   // block-uniform
-        const int64_t u = p.tie_list[1 + f];
-        int64_t ul = (int64_t)p.users[u] - p.user_base;
-        if (ul < 0 || ul >= p.U) ul = 0;                    // latched by the scan kernel
+    for (int f0 = blockIdx.y * UB; f0 < count; f0 += gridDim.y * UB) {   // block-uniform
+        const int nu = min(UB, count - f0);
         __syncthreads();
-        for (int i = t; i < W; i += 1024) um[i] = p.pm[(size_t)ul * W + i];
-        // a group's running top-16 lives in its 16 lanes, slot j in lane j (k <= 16): an insertion is two compares and two
-        // selects per lane against the lane's own slot and its left neighbour's (DPP row_shr:1), no LDS, no serial walk
-        float slot_s = -INFINITY;
-        int32_t slot_i = -1;
+        for (int ub = 0; ub < nu; ++ub) {
+            int64_t ul = (int64_t)p.users[p.tie_list[1 + f0 + ub]] - p.user_base;
+            if (ul < 0 || ul >= p.U) ul = 0;                // latched by the scan kernel
+            for (int i = t; i < W; i += 1024) um[ub * W + i] = p.pm[(size_t)ul * W + i];
+        }
+        // a group's running top-16 of a user lives in its 16 lanes, slot j in lane j (k <= 16): an insertion is two compares
+        // and two selects per lane against the lane's own slot and its left neighbour's (DPP row_shr:1), no LDS, no serial walk
+        float slot_s[UB];
+        int32_t slot_i[UB];
+#pragma unroll
+        for (int ub = 0; ub < UB; ++ub) { slot_s[ub] = -INFINITY; slot_i[ub] = -1; }
         __syncthreads();
         // the masks are 0/1 (the pattern-grouped kernels run for nothing else): a dish's terms depend on its pattern P only
         //   high = sum_{c in P} <U_high, CE_c> / n_P        low = < RE[d], sum_{c in P} U_low,c > / n_P
-        for (int i = t; i < NP * E; i += 1024) {
-            const int pt = i / E, e = i - pt * E;
+        for (int i = t; i < nu * NP * E; i += 1024) {
+            const int ub = i / (NP * E), r = i - ub * (NP * E), pt = r / E, e = r - pt * E;
             float w = 0.f;
-            for (int c = 0; c < C; ++c) w += ((pt >> c) & 1) ? um[(c + 1) * E + e] : 0.f;
+            for (int c = 0; c < C; ++c) w += ((pt >> c) & 1) ? um[ub * W + (c + 1) * E + e] : 0.f;
             wp[i] = w;
         }
-        if (t < C * 64) {                                   // wave c: <U_high, CE_c>
-            const int c = t >> 6;
+        for (int x = wave; x < nu * C; x += 16) {           // a wave per (user, category): <U_high, CE_c>
+            const int ub = x / C, c = x - ub * C;
             float q = 0.f;
-            for (int e = lane; e < E; e += 64) q = fmaf(um[e], p.ce[(size_t)c * E + e], q);
+            for (int e = lane; e < E; e += 64) q = fmaf(um[ub * W + e], p.ce[(size_t)c * E + e], q);
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
-            if (lane == 0) hc[c] = q;
+            if (lane == 0) hc[ub][c] = q;
         }
         __syncthreads();
-        if (t < NP) {
+        if (t < nu * NP) {
+            const int ub = t / NP, pt = t - ub * NP;
             float x = 0.f;
-            for (int c = 0; c < C; ++c) x += ((t >> c) & 1) ? hc[c] : 0.f;
-            alpha[t] = x;
+            for (int c = 0; c < C; ++c) x += ((pt >> c) & 1) ? hc[ub][c] : 0.f;
+            alpha[ub][pt] = x / (float)__builtin_popcount(pt);                               // :79 (pattern 0: 0 / 0 = NaN)
         }
         __syncthreads();
         const v4f *um4 = reinterpret_cast<const v4f *>(um), *wp4 = reinterpret_cast<const v4f *>(wp);
+        // the masks and the first 16 float4 columns of the NEXT step's dishes are fetched while this step's are scored (a step
+        // is one round trip to memory otherwise: 12 steps, 3 us each)
+        v4f m_n[ND], it_n[ND], hv_n[ND];
+        auto fetch = [&](const int64_t db) __attribute__((always_inline)) {
+#pragma unroll
+            for (int x = 0; x < ND; ++x) {
+                const int64_t d = db + x * NG + grp;
+                const int64_t da = d < d1 ? d : d0;
+                m_n[x] = *reinterpret_cast<const v4f *>(p.cats + (size_t)da * C);
+                if (j < E4) {
+                    it_n[x] = reinterpret_cast<const v4f *>(p.re)[(size_t)da * E4 + j];
+                    if (HVR) hv_n[x] = reinterpret_cast<const v4f *>(p.hv)[(size_t)da * E4 + j];
+                }
+            }
+        };
+        if (d0 < d1) fetch(d0);
         for (int64_t db = d0; db < d1; db += ND * NG) {     // wave-uniform trip count: the shuffles see a full EXEC
             int64_t dd[ND];
             bool ok[ND];
             int pt[ND];
-            float hs[ND], lo[ND];
+            float hs[ND][UB], lo[ND][UB];
+            v4f it0[ND], hv0[ND];
 #pragma unroll
             for (int x = 0; x < ND; ++x) {
                 const int64_t d = db + x * NG + grp;
                 ok[x] = d < d1;
                 dd[x] = ok[x] ? d : d0;
-                const v4f m = *reinterpret_cast<const v4f *>(p.cats + (size_t)dd[x] * C);
+                const v4f m = m_n[x];
+                it0[x] = it_n[x];
+                hv0[x] = hv_n[x];
                 pt[x] = (m.x != 0.f ? 1 : 0) | (m.y != 0.f ? 2 : 0) | (m.z != 0.f ? 4 : 0) | (m.w != 0.f ? 8 : 0);
-                hs[x] = lo[x] = 0.f;
+#pragma unroll
+                for (int ub = 0; ub < UB; ++ub) hs[x][ub] = lo[x][ub] = 0.f;
             }
+            if (db + ND * NG < d1) fetch(db + ND * NG);
             for (int q = j; q < E4; q += 16) {
                 v4f it[ND], hvv[ND];
 #pragma unroll
                 for (int x = 0; x < ND; ++x) {
-                    it[x] = reinterpret_cast<const v4f *>(p.re)[(size_t)dd[x] * E4 + q];
-                    if (p.hv) hvv[x] = reinterpret_cast<const v4f *>(p.hv)[(size_t)dd[x] * E4 + q];
+                    if (q == j) {
+                        it[x] = it0[x];
+                        hvv[x] = hv0[x];
+                    } else {
+                        it[x] = reinterpret_cast<const v4f *>(p.re)[(size_t)dd[x] * E4 + q];
+                        if (HVR) hvv[x] = reinterpret_cast<const v4f *>(p.hv)[(size_t)dd[x] * E4 + q];
+                    }
                 }
-                const v4f uh = um4[q];
 #pragma unroll
-                for (int x = 0; x < ND; ++x) {
-                    const v4f w = wp4[pt[x] * E4 + q];
-                    lo[x] = fmaf(it[x].x, w.x, fmaf(it[x].y, w.y, fmaf(it[x].z, w.z, fmaf(it[x].w, w.w, lo[x]))));
-                    if (p.hv) hs[x] = fmaf(uh.x, hvv[x].x, fmaf(uh.y, hvv[x].y, fmaf(uh.z, hvv[x].z, fmaf(uh.w, hvv[x].w, hs[x]))));
+                for (int ub = 0; ub < UB; ++ub) {
+                    if (ub < nu) {                          // block-uniform
+#pragma unroll
+                        for (int x = 0; x < ND; ++x) {
+                            const v4f w = wp4[(ub * NP + pt[x]) * E4 + q];
+                            lo[x][ub] = fmaf(it[x].x, w.x, fmaf(it[x].y, w.y, fmaf(it[x].z, w.z, fmaf(it[x].w, w.w, lo[x][ub]))));
+                            if (HVR) {
+                                const v4f uh = um4[ub * (W >> 2) + q];
+                                hs[x][ub] = fmaf(uh.x, hvv[x].x, fmaf(uh.y, hvv[x].y, fmaf(uh.z, hvv[x].z, fmaf(uh.w, hvv[x].w, hs[x][ub]))));
+                            }
+                        }
+                    }
                 }
             }
 #pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) {
+            for (int ub = 0; ub < UB; ++ub) {
+                if (ub < nu) {                              // block-uniform
+                    // sum over the 16 lanes of a row: four rotations (DPP row_ror 8, 4, 2, 1; the same pairs as an xor butterfly,
+                    // so every lane ends with the same bits) -- no LDS round trip (ds_bpermute) per step
 #pragma unroll
-                for (int x = 0; x < ND; ++x) {
-                    lo[x] += __shfl_xor(lo[x], off, 64);
-                    if (p.hv) hs[x] += __shfl_xor(hs[x], off, 64);
+                    for (int x = 0; x < ND; ++x) {
+                        lo[x][ub] = row16_sum(lo[x][ub]);
+                        if (HVR) hs[x][ub] = row16_sum(hs[x][ub]);
+                    }
+#pragma unroll
+                    for (int x = 0; x < ND; ++x) {          // ascending id inside a group: x = 0 first
+                        const float n = (float)__builtin_popcount(pt[x]);                    // :77 (an empty mask: 0 / 0 = NaN, never enters)
+                        float sc = __fadd_rn(__fmul_rn(p.a, HVR ? hs[x][ub] : alpha[ub][pt[x]]), __fmul_rn(p.b, lo[x][ub] / n));   // :79 (done above), :92, :95-96
+                        sc = ok[x] ? fmaxf(sc, -INFINITY) : -INFINITY;                       // NaN -> -inf: never enters
+                        // left neighbour's slot (lane j - 1 of the same 16-lane row; lane 0 sees +inf / -1)
+                        const float left_s = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, INFINITY),
+                                                                __builtin_bit_cast(int, slot_s[ub]), 0x111, 0xf, 0xf, false));
+                        const int32_t left_i = __builtin_amdgcn_update_dpp(-1, slot_i[ub], 0x111, 0xf, 0xf, false);
+                        const bool above_left = sc > left_s, above_me = sc > slot_s[ub];     // strict: equal scores keep the earlier (lower) id first
+                        slot_i[ub] = above_left ? left_i : (above_me ? (int32_t)dd[x] : slot_i[ub]);
+                        slot_s[ub] = above_left ? left_s : (above_me ? sc : slot_s[ub]);
+                    }
                 }
-            }
-#pragma unroll
-            for (int x = 0; x < ND; ++x) {                  // ascending id inside a group: x = 0 first
-                const float n = (float)__builtin_popcount(pt[x]);                            // :77 (an empty mask: 0 / 0 = NaN, never enters)
-                float sc = __fadd_rn(__fmul_rn(p.a, p.hv ? hs[x] : alpha[pt[x]] / n), __fmul_rn(p.b, lo[x] / n));   // :79, :92, :95-96
-                sc = ok[x] ? fmaxf(sc, -INFINITY) : -INFINITY;                               // NaN -> -inf: never enters
-                // left neighbour's slot (lane j - 1 of the same 16-lane row; lane 0 sees +inf / -1)
-                const float left_s = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, INFINITY),
-                                                        __builtin_bit_cast(int, slot_s), 0x111, 0xf, 0xf, false));
-                const int32_t left_i = __builtin_amdgcn_update_dpp(-1, slot_i, 0x111, 0xf, 0xf, false);
-                const bool above_left = sc > left_s, above_me = sc > slot_s;                 // strict: equal scores keep the earlier (lower) id first
-                slot_i = above_left ? left_i : (above_me ? (int32_t)dd[x] : slot_i);
-                slot_s = above_left ? left_s : (above_me ? sc : slot_s);
             }
         }
-        if (j < k) { ls[grp * k + j] = slot_s; li[grp * k + j] = slot_s > -INFINITY ? slot_i : -1; }
+#pragma unroll
+        for (int ub = 0; ub < UB; ++ub)
+            if (j < k) { ls[(ub * NG + grp) * k + j] = slot_s[ub]; li[(ub * NG + grp) * k + j] = slot_s[ub] > -INFINITY ? slot_i[ub] : -1; }
         __syncthreads();
-        if (t < 64) {                                       // wave 0: the NG lists -> this block's partial list, (score desc, id asc)
+        for (int ub = wave; ub < nu; ub += 16) {            // wave ub: the user's NG lists -> this block's partial list, (score desc, id asc)
             int ptr = 0;
-            float *os = p.part_s + ((size_t)f * REPAIR_SPLITS + blockIdx.x) * k;
-            int32_t *oi = p.part_i + ((size_t)f * REPAIR_SPLITS + blockIdx.x) * k;
+            float *os = p.part_s + ((size_t)(f0 + ub) * REPAIR_SPLITS + blockIdx.x) * k;
+            int32_t *oi = p.part_i + ((size_t)(f0 + ub) * REPAIR_SPLITS + blockIdx.x) * k;
             for (int o = 0; o < k; ++o) {
-                float bs = ptr < k ? ls[lane * k + ptr] : 0.f;
-                int32_t bi = ptr < k ? li[lane * k + ptr] : -1;
+                float bs = ptr < k ? ls[(ub * NG + lane) * k + ptr] : 0.f;
+                int32_t bi = ptr < k ? li[(ub * NG + lane) * k + ptr] : -1;
                 int bl = lane;
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) {
@@ -1091,6 +1147,7 @@ struct GroupedArgs {
     const float *plan;         // [nU, 8] per user of the call: scan-start bound, <U_high, CE_c> x 4, relevant-pattern mask (m2d_topk_user_plan)
     const int32_t *order;      // [nU] position in the launch -> index into users / plan (users sorted by pattern mask), or null
     unsigned long long *tiles_scanned;   // diagnostic: 32-dish tiles the blocks stepped through
+    const int32_t *items;      // [user blocks x nsplit] launch order of a pruned scan: block * nsplit + split, longest first; or null
 };
 
 // A threshold to start the scan from, known before any dish is scored.  With 0/1 masks score(u, d) = alpha_P[u] +
@@ -1143,6 +1200,20 @@ __device__ __forceinline__ void grouped_pattern_bounds(const float (&hc)[4], con
         grouped_pattern_terms(hc, G, grp, pt, k, a, b, lo, hi);
         mask |= !(hi < seed) ? (1u << pt) : 0u;              // NaN bounds keep their pattern
     }
+}
+
+// the same from 16 lanes that all hold hc and G: lane j works out pattern j, the bound and the mask are reduced over the 16
+__device__ __forceinline__ void grouped_pattern_bounds_lanes(const float (&hc)[4], const float (&G)[10], const int32_t *grp, const int k,
+                                                             const float a, const float b, const int j, float &seed, uint32_t &mask)
+{
+    float lo = -INFINITY, hi = -INFINITY;
+    if (j >= 1) grouped_pattern_terms(hc, G, grp, j, k, a, b, lo, hi);
+    seed = fmaxf(lo, -INFINITY);                            // a NaN bound is ignored
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) seed = fmaxf(seed, __shfl_xor(seed, off, 64));
+    mask = (j >= 1 && !(hi < seed)) ? (1u << j) : 0u;      // NaN bounds keep their pattern
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) mask |= __shfl_xor(mask, off, 64);
 }
 
 __device__ __forceinline__ float grouped_threshold_seed(const v4f *pmu, const int Sr, const float (&hc)[4], const GroupedArgs &p)
@@ -1212,7 +1283,7 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
     }
     float seed;
     uint32_t mask;
-    grouped_pattern_bounds(hc, G, grp, k, a, b, seed, mask);
+    grouped_pattern_bounds_lanes(hc, G, grp, k, a, b, j, seed, mask);
     if (no_alpha == 1) { seed = -INFINITY; mask = 0xfffeu; }     // ingredient rows: the score has no alpha_P term to bound it with
     if (no_alpha == 2) mask = 0xfffeu;                        // option topk_prune = 2: the bound, but every pattern (A/B)
     if (no_alpha == 4) seed = -INFINITY;                      // option topk_prune = 4: the patterns, but no bound (A/B)
@@ -1224,61 +1295,144 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
 
 // counting sort of the call's users by their 15-bit pattern mask: histogram, scan (one block), scatter.  The order inside
 // a mask does not matter -- a user's list does not depend on the block it is scored in.  Two thirds of the users share
-// fifteen masks (one relevant pattern), so a wave adds ONE count per distinct mask it holds (the lanes of a mask are found
-// with a ballot; a lane's place among them is its rank): one atomic per user queued 65 536 of them on a few dozen addresses.
-constexpr int PLAN_KEYS = 1 << 16;
-__device__ __forceinline__ int plan_wave_add(int32_t *counters, const int key, const bool live)
+// fifteen masks (one relevant pattern): one global atomic per user queued 65 536 of them on a few dozen addresses (190 us a
+// pass; one per wave and distinct mask, found with ballots: 50 us).  Now a workgroup counts its users in a 128-KiB LDS table
+// of all 32 768 keys and adds only the table's non-zero entries to the global counts; the scatter reserves a range per
+// non-zero entry the same way and places its users inside the ranges with LDS atomics.
+constexpr int PLAN_KEYS = 1 << 15;                         // a mask holds bits 1..15: key = mask >> 1
+__device__ __forceinline__ int plan_key(const float *plan, const int64_t u)
 {
-    const int lane = threadIdx.x & 63;
-    unsigned long long todo = __ballot(live);
-    int pos = 0;
-    while (todo) {                                          // wave-uniform
-        const int k0 = __builtin_amdgcn_readlane(key, __builtin_ctzll(todo));
-        const unsigned long long same = __ballot(live && key == k0) & todo;
-        int base = 0;
-        if (lane == __builtin_ctzll(same)) base = atomicAdd(&counters[k0], __builtin_popcountll(same));
-        base = __builtin_amdgcn_readlane(base, __builtin_ctzll(same));
-        if (live && key == k0) pos = base + __builtin_popcountll(same & ((1ull << lane) - 1ull));
-        todo &= ~same;
-    }
-    return pos;
+    return (int)((__float_as_uint(plan[(size_t)u * 8 + 5]) >> 1) & (PLAN_KEYS - 1));
 }
 
-__global__ __launch_bounds__(256) void m2d_plan_hist(const float *plan, int64_t nU, int32_t *hist)
+__global__ __launch_bounds__(1024) void m2d_plan_hist(const float *plan, int64_t nU, int32_t *hist)
 {
-    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = u < nU;
-    (void)plan_wave_add(hist, live ? (int)(__float_as_uint(plan[(size_t)u * 8 + 5]) & (PLAN_KEYS - 1)) : 0, live);
+    extern __shared__ __align__(16) int32_t plan_tab[];
+    for (int i = threadIdx.x; i < PLAN_KEYS; i += 1024) plan_tab[i] = 0;
+    __syncthreads();
+    for (int64_t u = (int64_t)blockIdx.x * 1024 + threadIdx.x; u < nU; u += (int64_t)gridDim.x * 1024) atomicAdd(&plan_tab[plan_key(plan, u)], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < PLAN_KEYS; i += 1024) {
+        const int32_t c = plan_tab[i];
+        if (c) atomicAdd(&hist[i], c);
+    }
 }
 
 __global__ __launch_bounds__(1024) void m2d_plan_scan(int32_t *hist)
 {
-    __shared__ int32_t part[1024];
-    constexpr int PER = PLAN_KEYS / 1024;
+    constexpr int PER4 = PLAN_KEYS / 1024 / 4;
+    __shared__ int32_t wtot[16];
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i v[PER4];
     int32_t sum = 0;
-    for (int i = 0; i < PER; ++i) sum += hist[threadIdx.x * PER + i];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER4; ++i) {
+        v[i] = reinterpret_cast<const v4i *>(hist)[threadIdx.x * PER4 + i];
+        sum += v[i].x + v[i].y + v[i].z + v[i].w;
     }
-    int32_t run = part[threadIdx.x] - sum;
-    for (int i = 0; i < PER; ++i) {
-        const int32_t c = hist[threadIdx.x * PER + i];
-        hist[threadIdx.x * PER + i] = run;
-        run += c;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int32_t t = __shfl_up(incl, off, 64);
+        incl += lane >= off ? t : 0;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int32_t run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += wtot[w];
+#pragma unroll
+    for (int i = 0; i < PER4; ++i) {
+        v4i o;
+        o.x = run; run += v[i].x;
+        o.y = run; run += v[i].y;
+        o.z = run; run += v[i].z;
+        o.w = run; run += v[i].w;
+        reinterpret_cast<v4i *>(hist)[threadIdx.x * PER4 + i] = o;
     }
 }
 
-__global__ __launch_bounds__(256) void m2d_plan_scatter(const float *plan, int64_t nU, int32_t *cursor, int32_t *order)
+__global__ __launch_bounds__(1024) void m2d_plan_scatter(const float *plan, int64_t nU, int32_t *cursor, int32_t *order)
 {
-    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = u < nU;
-    const int pos = plan_wave_add(cursor, live ? (int)(__float_as_uint(plan[(size_t)u * 8 + 5]) & (PLAN_KEYS - 1)) : 0, live);
-    if (live) order[pos] = (int32_t)u;
+    extern __shared__ __align__(16) int32_t plan_tab[];
+    for (int i = threadIdx.x; i < PLAN_KEYS; i += 1024) plan_tab[i] = 0;
+    __syncthreads();
+    for (int64_t u = (int64_t)blockIdx.x * 1024 + threadIdx.x; u < nU; u += (int64_t)gridDim.x * 1024) atomicAdd(&plan_tab[plan_key(plan, u)], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < PLAN_KEYS; i += 1024) {       // a range of the key's positions for this workgroup's users
+        const int32_t c = plan_tab[i];
+        if (c) plan_tab[i] = atomicAdd(&cursor[i], c);
+    }
+    __syncthreads();
+    for (int64_t u = (int64_t)blockIdx.x * 1024 + threadIdx.x; u < nU; u += (int64_t)gridDim.x * 1024)
+        order[atomicAdd(&plan_tab[plan_key(plan, u)], 1)] = (int32_t)u;
+}
+
+// Launch order of a pruned scan.  Its workgroups -- (block of 256 sorted users, dish range) items -- are unequal: the
+// tiles a block steps through are those of its users' patterns inside the dish range, anything from none to all of it.
+// Handed out in grid order the long items that happen to come late leave most CUs idle at the end (a list-scheduling
+// simulation of the benchmark's call, scripts/diag/pattern_prune_sim.py: 1.53 x the even share; longest first: 1.03 x).
+// m2d_plan_items_work: one wave per user block ORs its users' masks and counts, per dish range, the tiles of those
+// patterns.  m2d_plan_items_sort: one workgroup sorts the items by that count, descending (a counting sort over 1 024
+// bins of the range's length; equal bins in any order -- the order changes when a list is computed, not what it holds).
+__global__ __launch_bounds__(256) void m2d_plan_items_work(const float *plan, const int32_t *order, int64_t nU, const int32_t *grp,
+                                                           int64_t tiles, int nsplit, int32_t *work)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // wave-uniform
+    if (b * 256 >= nU) return;
+    uint32_t m = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t pos = b * 256 + i * 64 + lane;
+        if (pos < nU) m |= __float_as_uint(plan[(size_t)(order ? (int64_t)order[pos] : pos) * 8 + 5]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m |= __shfl_xor(m, off, 64);
+    const int64_t per = (tiles + nsplit - 1) / nsplit;
+    for (int s = lane; s < nsplit; s += 64) {
+        const int64_t t0 = (int64_t)s * per, t1 = min(tiles, t0 + per);
+        int64_t w = 0;
+        for (int q = 1; q < GRP_MAXPAT; ++q) {
+            const int rows = grp[40 + q];
+            if (rows == 0 || !((m >> q) & 1u)) continue;
+            const int64_t g0 = grp[q] >> 5, g1 = g0 + ((rows + 31) >> 5);
+            const int64_t lo = g0 > t0 ? g0 : t0, hi = g1 < t1 ? g1 : t1;
+            w += hi > lo ? hi - lo : 0;
+        }
+        work[b * nsplit + s] = (int32_t)w;
+    }
+}
+
+__global__ __launch_bounds__(1024) void m2d_plan_items_sort(const int32_t *work, int64_t nitems, int64_t tiles, int nsplit, int32_t *items)
+{
+    constexpr int BINS = 1024;
+    __shared__ int32_t cnt[BINS], base[BINS];
+    const int64_t per = (tiles + nsplit - 1) / nsplit;
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    auto bin_of = [&](const int32_t w) {
+        const int64_t b = per > 0 ? (int64_t)w * (BINS - 1) / per : 0;
+        return BINS - 1 - (int)(b > BINS - 1 ? BINS - 1 : b);            // bin 0 = the longest items
+    };
+    for (int64_t i = threadIdx.x; i < nitems; i += 1024) atomicAdd(&cnt[bin_of(work[i])], 1);
+    __syncthreads();
+    // exclusive scan of the 1 024 counts: inside each wave by shuffles, the 16 wave totals by the first wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int v = cnt[threadIdx.x], incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        incl += lane >= off ? t : 0;
+    }
+    __shared__ int32_t wtot[16];
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wtot[w];
+    base[threadIdx.x] = woff + incl - v;
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < nitems; i += 1024) items[atomicAdd(&base[bin_of(work[i])], 1)] = (int32_t)i;
 }
 
 // End of a pattern-grouped scan: the lane's register list goes to LDS with its slots translated to dish ids, the two
@@ -1288,7 +1442,7 @@ __global__ __launch_bounds__(256) void m2d_plan_scatter(const float *plan, int64
 template <int KR>
 __device__ __forceinline__ void grouped_publish(float *ls, int32_t *li, const float (&rs)[KR], const int32_t (&ri)[KR],
                                                 const GroupedArgs &p, const int lane, const int64_t uidx, const bool uvalid,
-                                                const unsigned long long tie_mask)
+                                                const unsigned long long tie_mask, const int split)
 {
     const int j = lane & 31, h = lane >> 5, k = p.k;
     int cnt = 0;
@@ -1305,8 +1459,8 @@ __device__ __forceinline__ void grouped_publish(float *ls, int32_t *li, const fl
     if (h == 0 && uvalid) {
         const int ca = cnt, cb = cnt_hi;
         int pa = 0, pb = 0;
-        float *os = p.out_scores + ((size_t)uidx * p.nsplit + blockIdx.y) * k;
-        int32_t *oi = p.out_ids + ((size_t)uidx * p.nsplit + blockIdx.y) * k;
+        float *os = p.out_scores + ((size_t)uidx * p.nsplit + split) * k;
+        int32_t *oi = p.out_ids + ((size_t)uidx * p.nsplit + split) * k;
         float last = 0.f;
         bool full = true;
         for (int o = 0; o < k; ++o) {
@@ -1330,7 +1484,7 @@ __device__ __forceinline__ void grouped_publish(float *ls, int32_t *li, const fl
         }
         const bool tie = full && ((pa < ca && ls[pa * 64 + lane] == last) || (pb < cb && ls[pb * 64 + lane + 32] == last) ||
                                   (tie_a && ls[(KR - 1) * 64 + lane] == last) || (tie_b && ls[(KR - 1) * 64 + lane + 32] == last));
-        p.tie_val[(size_t)uidx * p.nsplit + blockIdx.y] = tie ? last : __builtin_nanf("");
+        p.tie_val[(size_t)uidx * p.nsplit + split] = tie ? last : __builtin_nanf("");
     }
 }
 
@@ -1500,7 +1654,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
     // ---- publish (slot -> dish id), merge the two lanes of each user -------------------------------------
     float *ls = smem + (size_t)wave * 2 * KR * 64;       // aliases stage 0: every wave is past the last barrier
     int32_t *li = reinterpret_cast<int32_t *>(ls + (size_t)KR * 64);
-    grouped_publish<KR>(ls, li, rs, ri, p, lane, uidx, uvalid, tie_mask);
+    grouped_publish<KR>(ls, li, rs, ri, p, lane, uidx, uvalid, tie_mask, (int)blockIdx.y);
     (void)k;
 }
 
@@ -1715,7 +1869,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
 
     float *ls = reinterpret_cast<float *>(smem8) + (size_t)wave * 2 * KR * 64;   // aliases stage 0
     int32_t *li = reinterpret_cast<int32_t *>(ls + (size_t)KR * 64);
-    grouped_publish<KR>(ls, li, rs, ri, p, lane, uidx, uvalid, tie_mask);
+    grouped_publish<KR>(ls, li, rs, ri, p, lane, uidx, uvalid, tie_mask, (int)blockIdx.y);
     (void)k;
 }
 
@@ -1772,6 +1926,14 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const int k = p.k;
+    // (user block, dish range) of this workgroup: the grid's (x, y), or -- a pruned launch -- entry blockIdx.x of the
+    // launch's item list, longest item first (m2d_plan_items_work / _sort)
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    if (p.items) {
+        const int it = __builtin_amdgcn_readfirstlane(p.items[blockIdx.x]);
+        bx = it / p.nsplit;
+        by = it - bx * p.nsplit;
+    }
 
     // The users of a launch come in the order the call's plan sorted them into (by relevant-pattern mask, p.order):
     // uidx = the user's index in the CALL (users, plan, outputs), wherever the launch placed it.
@@ -1783,7 +1945,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     uint32_t umask_lane = 0u;                              // patterns that can reach the top-k of this lane's user(s)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        const int64_t pos = (((int64_t)blockIdx.x * WAVES + wave) * G + g) * 32 + j;
+        const int64_t pos = (((int64_t)bx * WAVES + wave) * G + g) * 32 + j;
         uvalid[g] = pos < p.nU;
         uidx[g] = uvalid[g] ? (p.order ? (int64_t)p.order[pos] : pos) : 0;
         int64_t ul = 0;
@@ -1851,7 +2013,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     for (int g = 0; g < G; ++g) tie_mask[g] = 0ull;
 
     const int64_t per = (p.tiles + p.nsplit - 1) / p.nsplit;
-    const int64_t t_begin = (int64_t)blockIdx.y * per;
+    const int64_t t_begin = (int64_t)by * per;
     const int64_t t_end = min(p.tiles, t_begin + per);
     const int n_phys = (int)(t_end > t_begin ? t_end - t_begin : 0);   // tiles of this block's dish range
     const int nst = n_phys > 0 ? (n_phys + 2) / TPS + 1 : 0;           // stages of that range (the image is padded for the overhang)
@@ -2243,7 +2405,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     if (p.tiles_scanned && threadIdx.x == 0) atomicAdd(p.tiles_scanned, (unsigned long long)n);
 #if M2D_DIAG & 16
     if (lane == 0 && p.dbg) {
-        unsigned long long *d = p.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave) * 8;
+        unsigned long long *d = p.dbg + ((size_t)(by * ((p.nU + 255) / 256) + bx) * WAVES + wave) * 8;
         d[0] = t_body; d[1] = n_ins; d[2] = t_bar; d[3] = t_slow; d[4] = n_slow; d[5] = n_step;
         d[6] = __builtin_amdgcn_s_memtime() - clk0; d[7] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
@@ -2253,7 +2415,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     for (int g = 0; g < G; ++g) {
         float *ls = reinterpret_cast<float *>(smem8) + (size_t)(wave * G + g) * 2 * KR * 64;   // aliases stage 0
         int32_t *li = reinterpret_cast<int32_t *>(ls + (size_t)KR * 64);
-        grouped_publish<KR>(ls, li, rs[g], ri[g], p, lane, uidx[g], uvalid[g], tie_mask[g]);
+        grouped_publish<KR>(ls, li, rs[g], ri[g], p, lane, uidx[g], uvalid[g], tie_mask[g], by);
     }
     (void)k;
 }
@@ -2393,7 +2555,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     a.grp = h->grp_work + (size_t)((h->I + 255) / 256) * GRP_KEYS;
     a.users = users; a.nU = nU; a.U = h->U; a.user_base = h->user_base; a.k = k; a.tiles = h->grp_tiles;
     a.a = h->a; a.b = h->b; a.err = h->err_dev; a.dbg = g_m2d_diag_buffer; a.e_real = h->E;
-    a.plan = nullptr; a.order = nullptr; a.tiles_scanned = nullptr;
+    a.plan = nullptr; a.order = nullptr; a.tiles_scanned = nullptr; a.items = nullptr;
     const int64_t ublocks = (nU + 32 * WAVES - 1) / (32 * WAVES);
     int nsplit = pick_splits(h, ublocks, a.tiles, 2 * TPS, 512);
     if (BF16X3 && !HV && h->opt_topk_form != 1 && h->opt_topk_prune != 0 && h->opt_variant < 100 && ublocks >= 24) {
@@ -2446,7 +2608,8 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         if (pipe) {
             // the call's plan: per user the scan-start bound, <U_high, CE_c> and the mask of patterns that can reach the
             // top-k; users sorted by mask so that a block's 256 users share their patterns (a single block: no sort)
-            const size_t need = (size_t)nU * 8 + (size_t)nU + PLAN_KEYS + 4;
+            const size_t nitems = (size_t)ublocks * nsplit;
+            const size_t need = (size_t)nU * 8 + (size_t)nU + PLAN_KEYS + 8 + 2 * nitems;
             if (h->topk_plan_cap < need) {
                 if (h->topk_plan) M2D_HIP_TRY(h, hipFree(h->topk_plan));
                 h->topk_plan = nullptr; h->topk_plan_cap = 0;
@@ -2454,18 +2617,29 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
                 h->topk_plan_cap = need;
             }
             float *plan = h->topk_plan;
-            int32_t *order = reinterpret_cast<int32_t *>(plan + (size_t)nU * 8), *hist = order + nU;
-            unsigned long long *counter = reinterpret_cast<unsigned long long *>(hist + PLAN_KEYS + ((nU + PLAN_KEYS) & 1));
+            int32_t *order = reinterpret_cast<int32_t *>(plan + (size_t)nU * 8), *hist = order + ((nU + 3) & ~(int64_t)3);      // hist: 16-B aligned
+            unsigned long long *counter = reinterpret_cast<unsigned long long *>(hist + PLAN_KEYS);
             const bool prune = h->opt_topk_prune != 0;
             hipLaunchKernelGGL(m2d_topk_user_plan, dim3((unsigned)((nU * 16 + 255) / 256)), dim3(256), 0, st, h->pm, h->ce, users, nU, h->U,
                                h->user_base, h->E, a.grp, (int)k, h->a, h->b, (HV || !prune) ? 1 : (h->opt_topk_prune == 2 ? 2 : (h->opt_topk_prune == 4 ? 4 : 0)), plan);
             a.plan = plan;
             if (prune && !HV && nU > 256 && h->opt_topk_prune != 3) {      // 3: pruning without the sort (A/B)
                 M2D_HIP_TRY(h, hipMemsetAsync(hist, 0, PLAN_KEYS * sizeof(int32_t), st));
-                hipLaunchKernelGGL(m2d_plan_hist, dim3((unsigned)((nU + 255) / 256)), dim3(256), 0, st, plan, nU, hist);
+                const size_t tab = (size_t)PLAN_KEYS * sizeof(int32_t);
+                const unsigned sblocks = (unsigned)((nU + 1023) / 1024 < 4 * h->num_cu ? (nU + 1023) / 1024 : 4 * h->num_cu);
+                M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_plan_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab));
+                M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_plan_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab));
+                hipLaunchKernelGGL(m2d_plan_hist, dim3(sblocks), dim3(1024), tab, st, plan, nU, hist);
                 hipLaunchKernelGGL(m2d_plan_scan, dim3(1), dim3(1024), 0, st, hist);
-                hipLaunchKernelGGL(m2d_plan_scatter, dim3((unsigned)((nU + 255) / 256)), dim3(256), 0, st, plan, nU, hist, order);
+                hipLaunchKernelGGL(m2d_plan_scatter, dim3(sblocks), dim3(1024), tab, st, plan, nU, hist, order);
                 a.order = order;
+            }
+            if (a.order && nitems > (size_t)h->num_cu && h->opt_topk_prune != 5) {      // 5: grid order (A/B)
+                int32_t *work = reinterpret_cast<int32_t *>(counter + 1), *items = work + nitems;
+                hipLaunchKernelGGL(m2d_plan_items_work, dim3((unsigned)((ublocks + 3) / 4)), dim3(256), 0, st, plan, order, nU, a.grp, a.tiles,
+                                   nsplit, work);
+                hipLaunchKernelGGL(m2d_plan_items_sort, dim3(1), dim3(1024), 0, st, work, (int64_t)nitems, a.tiles, nsplit, items);
+                a.items = items;
             }
             M2D_HIP_TRY(h, hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
             a.tiles_scanned = counter;
@@ -2485,7 +2659,8 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
             static_assert(WAVES == 8, "the pipelined kernel is written for 256 users per block");
             auto kern = m2d_topk_grouped_bf16_pipe2<E, KR, 1>;
             M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(512), lds, st, a);
+            if (a.items) hipLaunchKernelGGL(kern, dim3((unsigned)(ublocks * nsplit)), dim3(512), lds, st, a);
+            else hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(512), lds, st, a);
         }
     } else {
         auto kern = m2d_topk_grouped<E8, WAVES, KR, PAD>;
@@ -2505,11 +2680,20 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         r.cap = h->opt_variant == 13 ? 2 : REPAIR_CAP;      // test hook: send all but two listed users to the one-block-per-user kernel
         r.part_s = h->topk_flags + tie_vals + 1 + (size_t)nU;
         r.part_i = reinterpret_cast<int32_t *>(r.part_s + (size_t)REPAIR_CAP * REPAIR_SPLITS * k);
-        const size_t slds = ((size_t)(h->C + 1 + 16) * h->E + (size_t)2 * 64 * k) * sizeof(float);
+        const int ub = (!HV && h->E <= 128) ? 4 : 2;                  // listed users per pass of the repair scan (LDS: 21 E + 128 k floats each)
+        const size_t slds = (size_t)ub * ((size_t)(h->C + 1 + 16) * h->E + (size_t)2 * 64 * k) * sizeof(float);
         const size_t rlds = ((size_t)(2 * h->C + 1) * h->E + (size_t)2 * 256 * k) * sizeof(float);
         M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_topk_repair_rest, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
         hipLaunchKernelGGL(m2d_topk_tie_compact, dim3((unsigned)((nU + 255) / 256)), dim3(256), 0, st, tie_final, nU, tie_list);
-        hipLaunchKernelGGL(m2d_topk_repair_scan, dim3(REPAIR_SPLITS, 16), dim3(1024), slds, st, r);
+        if (ub == 4) {
+            auto rk = m2d_topk_repair_scan<4, HV>;
+            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+            hipLaunchKernelGGL(rk, dim3(REPAIR_SPLITS, 8), dim3(1024), slds, st, r);
+        } else {
+            auto rk = m2d_topk_repair_scan<2, HV>;
+            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+            hipLaunchKernelGGL(rk, dim3(REPAIR_SPLITS, 8), dim3(1024), slds, st, r);
+        }
         hipLaunchKernelGGL(m2d_topk_repair_merge, dim3(16), dim3(256), 0, st, r);
         hipLaunchKernelGGL(m2d_topk_repair_rest, dim3((unsigned)(h->num_cu * 2)), dim3(256), rlds, st, r);
         M2D_HIP_TRY(h, hipGetLastError());

@@ -45,3 +45,37 @@ for name, key in (("call order", np.arange(NU)), ("sorted by best pattern", best
         union = rel[u].any(0)
         frac.append(rows[union].sum() / I)
     print("%-28s dishes a block scans: mean %.3f of the catalogue (max %.3f)" % (name, np.mean(frac), np.max(frac)))
+
+# Dispatch order: (block, dish-range split) items handed to 256 CUs in launch order (x = block fastest, then split) against
+# longest-first; an item's cost = the relevant 32-dish tiles inside its dish range + a fixed prologue (in tiles).
+import heapq
+NS, CUS, FIX = 8, 256, 6
+order = np.argsort(mask * NU + np.arange(NU), kind="stable")
+po = np.argsort(pat, kind="stable")                                      # sorted table: pattern groups in pattern order
+tiles_of = np.zeros(16, np.int64)
+start = np.zeros(17, np.int64)
+for q in range(1, 16):
+    tiles_of[q] = -(-rows[q] // 32)
+start[1:] = np.cumsum(tiles_of)
+T = start[16]
+items = []
+for bi, b0 in enumerate(range(0, NU, 256)):
+    union = rel[order[b0:b0 + 256]].any(0)
+    for sp in range(NS):
+        t0, t1 = T * sp // NS, T * (sp + 1) // NS
+        w = sum(max(0, min(t1, start[q + 1]) - max(t0, start[q])) for q in range(1, 16) if union[q])
+        items.append((sp, bi, w + FIX))
+def makespan(seq):
+    cu = [0.0] * CUS
+    heapq.heapify(cu)
+    for w in seq:
+        heapq.heappush(cu, heapq.heappop(cu) + w)
+    return max(cu)
+launch = [w for _, _, w in sorted(items)]
+total = sum(launch)
+print("items %d  total work %.0f tiles  ideal %.1f per CU  largest item %d" % (len(items), total, total / CUS, max(launch)))
+print("launch order (block fastest): makespan %.1f = %.2f x ideal" % (makespan(launch), makespan(launch) / (total / CUS)))
+by_block = [w for _, _, w in sorted(items, key=lambda t: (t[1], t[0]))]
+print("launch order (split fastest): makespan %.1f = %.2f x ideal" % (makespan(by_block), makespan(by_block) / (total / CUS)))
+lpt = sorted(launch, reverse=True)
+print("longest first:                makespan %.1f = %.2f x ideal" % (makespan(lpt), makespan(lpt) / (total / CUS)))

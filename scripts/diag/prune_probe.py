@@ -18,7 +18,8 @@ eng = foodrec_amd.ScoringEngine(PM, RE, CE); eng.set_dish_categories(cats)
 users = torch.randperm(U, generator=g, device="cuda")[:n].to(torch.int32)
 res = {}
 import itertools
-for prune, var in ((0, 0), (1, 0), (1, 101), (1, 116)):
+VARS = [int(v) for v in os.environ.get("PROBE_VARIANTS", "101 116").split()]
+for prune, var in [(0, 0), (5, 0), (1, 0)] + [(1, v) for v in VARS]:      # 5: pruned, grid launch order; 1: longest item first
     eng.set_option("topk_prune", prune); eng.set_option("variant", var)
     for _ in range(5):
         s1, i1 = eng.topk_users(users, 10)
@@ -33,4 +34,4 @@ for prune, var in ((0, 0), (1, 0), (1, 101), (1, 116)):
     print("prune=%d  %.3f ms  %.2f T pairs/s  tiles scanned %d of %d (%.3f)  repaired %d  kernel %s" %
           (prune, ms, n * I / ms / 1e9, eng.get_option("topk_tiles_scanned"), eng.get_option("topk_tiles_full"),
            eng.get_option("topk_tiles_scanned") / max(1, eng.get_option("topk_tiles_full")), eng.get_option("topk_repaired"), eng.last_kernel()))
-print("lists identical with and without pruning:", bool(torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][0], res[1][0])))
+print("lists identical with and without pruning:", bool(torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[5][1])))
