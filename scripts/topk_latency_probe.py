@@ -16,7 +16,7 @@ cats = ((pat[:, None] >> torch.arange(C, device=dev, dtype=torch.int32)[None, :]
 eng = foodrec_amd.ScoringEngine(PM, RE, CE); eng.set_dish_categories(cats)
 for kv in sys.argv[3:]:                                     # engine options, name=value
     eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-for n in (1, 8, 32, 256, 1024, 8192, 32768):
+for n in (1, 8, 32, 256, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
     users = torch.randperm(U, generator=g, device=dev)[:n].to(torch.int32)
     for _ in range(3):
         eng.topk_users(users, 10)
