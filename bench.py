@@ -304,7 +304,7 @@ def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10):
     flops = 2.0 * E * n_users * I if kernel.startswith("m2d_topk_grouped") else dense
     x3 = kernel.endswith("bf16x3")                         # 3 bf16 MFMAs per 16 k-values: 6*E flop per pair on the bf16 pipe
     scanned = full = None
-    if x3:                                                 # the pipelined kernel steps through its blocks' relevant patterns only
+    if kernel.startswith("m2d_topk_grouped"):              # these kernels step through their blocks' relevant patterns only
         scanned, full = eng.get_option("topk_tiles_scanned"), eng.get_option("topk_tiles_full")
         if scanned > 0:
             flops = 2.0 * E * 256 * 32 * scanned            # a block is 256 user lanes, a tile 32 dishes
@@ -323,7 +323,10 @@ def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10):
                                   "counts every pair of the catalogue"} if x3 else
                          {"bound": "mfma", "achieved": flops / ms / 1e9, "peak": 157.3, "unit": "TFLOP/s",
                           "frac": flops / ms / 1e9 / 157.3, "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact)",
-                          "flop_per_pair": flops / n_users / I}),
+                          "flop_per_pair": flops / n_users / I, "tiles_scanned": scanned, "tiles_without_pruning": full,
+                          "scanned_fraction": (scanned / full if scanned and full else None),
+                          "frac_if_every_tile_were_scanned": 2.0 * E * n_users * I / ms / 1e9 / 157.3,
+                          "note": "`frac` prices the flops EXECUTED (tiles of the blocks' relevant patterns), as for the split-bf16 kernel"}),
             "kernel": kernel}
 
 
@@ -495,9 +498,12 @@ def scaling_path_block(torch, dist, foodrec_amd, dev, world, rank, users_total, 
         eng.check()
     if ms:
         m = median(ms)
+        sc_, fl_ = eng.get_option("topk_tiles_scanned"), eng.get_option("topk_tiles_full")
+        part = sc_ / fl_ if (fl_ and sc_) else 1.0           # tiles stepped through / all tiles (pattern pruning)
         out["exact_f32"] = {"kernel": eng.last_kernel(), "users_per_gpu_in_sample": n1, "topk_ms": m,
                             "pairs_per_s_whole_job": world * n1 * I / m * 1e3,
-                            "roofline_frac_of_f32_mfma_peak": 2.0 * E * n1 * I / m / 1e9 / 157.3,
+                            "roofline_frac_of_f32_mfma_peak": part * 2.0 * E * n1 * I / m / 1e9 / 157.3,
+                            "scanned_fraction": part,
                             "what": "option topk_bf16x3 = 0 (v_mfma_f32_32x32x2_f32, exact): one round of users per GPU, all "
                                     "ranks at once, no all-gather; whole-shard time = this rate x the shard"}
     out["what"] = ("BASELINE configs[%d] per-GPU shape: %d users over %d GPU(s) x %d replicated dishes, E = %d; per-shard "

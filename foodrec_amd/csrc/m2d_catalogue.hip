@@ -1376,15 +1376,14 @@ __global__ __launch_bounds__(1024) void m2d_plan_scatter(const float *plan, int6
 // patterns.  m2d_plan_items_sort: one workgroup sorts the items by that count, descending (a counting sort over 1 024
 // bins of the range's length; equal bins in any order -- the order changes when a list is computed, not what it holds).
 __global__ __launch_bounds__(256) void m2d_plan_items_work(const float *plan, const int32_t *order, int64_t nU, const int32_t *grp,
-                                                           int64_t tiles, int nsplit, int32_t *work)
+                                                           int64_t tiles, int nsplit, int32_t *work, int upb)
 {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);     // wave-uniform
-    if (b * 256 >= nU) return;
+    if (b * upb >= nU) return;                                          // upb: users per block of the scan kernel
     uint32_t m = 0u;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t pos = b * 256 + i * 64 + lane;
+    for (int i = lane; i < upb; i += 64) {
+        const int64_t pos = b * upb + i;
         if (pos < nU) m |= __float_as_uint(plan[(size_t)(order ? (int64_t)order[pos] : pos) * 8 + 5]);
     }
 #pragma unroll
@@ -1509,38 +1508,49 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
     const int j = lane & 31, h = lane >> 5;
     const int k = p.k;
 
-    const int64_t uidx = ((int64_t)blockIdx.x * WAVES + wave) * 32 + j;
-    const bool uvalid = uidx < p.nU;
-    int64_t ul = 0;
+    // (user block, dish range) of this workgroup, the user's place in the call, <U_high, CE_c>, the scan-start bound and the
+    // relevant patterns: all from the call's plan, as in m2d_topk_grouped_bf16_pipe2 (m2d_topk_user_plan, m2d_plan_*)
+    int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    if (p.items) {
+        const int it = __builtin_amdgcn_readfirstlane(p.items[blockIdx.x]);
+        bx = it / p.nsplit;
+        by = it - bx * p.nsplit;
+    }
+    const int64_t pos = ((int64_t)bx * WAVES + wave) * 32 + j;
+    const bool uvalid = pos < p.nU;
+    // 32-bit on purpose (a call holds < 2^31 users, a shard < 2^31 rows): with 64-bit per-lane values live across the scan the
+    // E = 256 instantiation spills one, and hipcc 7.2 reloads it into an odd register pair ("Subtarget requires even aligned
+    // vector registers")
+    const int uidx = uvalid ? (p.order ? p.order[pos] : (int)pos) : 0;
+    int ul = 0;
     if (uvalid) {
         const int32_t uid = p.users[uidx];
-        ul = (int64_t)uid - p.user_base;
-        if (ul < 0 || ul >= p.U) {
+        const int64_t ul64 = (int64_t)uid - p.user_base;
+        ul = (int)ul64;
+        if (ul64 < 0 || ul64 >= p.U) {
             if (atomicCAS(&p.err[0], 0, M2D_ERR_BAD_USER_ID) == 0) {
                 p.err[1] = uid;
-                p.err[2] = (int32_t)(uidx & 0xffffffff);
-                p.err[3] = (int32_t)(uidx >> 32);
+                p.err[2] = uidx;
+                p.err[3] = 0;
             }
             ul = 0;
         }
     }
     const int Sr = PAD ? p.e_real / 4 : S;                 // 16-B slots per row of the tables
-    const v4f *pmu = reinterpret_cast<const v4f *>(p.pm) + (size_t)ul * ((C + 1) * Sr);
     float hc[C];                                           // <U_high, CE_c>   Model_Recommender.py:67-75
-    {
-        const v4f *ce4 = reinterpret_cast<const v4f *>(p.ce);
+    const float *rec = p.plan + (size_t)uidx * 8;
 #pragma unroll
-        for (int c = 0; c < C; ++c) hc[c] = 0.f;
-#pragma unroll 1
-        for (int q = 0; q < Sr; ++q) {
-            const v4f u = pmu[q];
+    for (int c = 0; c < C; ++c) hc[c] = rec[1 + c];
+    const float seed = uvalid ? rec[0] : INFINITY;         // a lane without a user never has a candidate
+    uint32_t umask_lane = uvalid ? __float_as_uint(rec[5]) : 0u;
+    __shared__ uint32_t s_umask;
+    if (threadIdx.x == 0) s_umask = 0u;
+    __syncthreads();
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const v4f w = ce4[c * Sr + q];
-                hc[c] += (u.x * w.x + u.y * w.y) + (u.z * w.z + u.w * w.w);
-            }
-        }
-    }
+    for (int off = 32; off >= 1; off >>= 1) umask_lane |= __shfl_xor(umask_lane, off, 64);
+    if (lane == 0) atomicOr(&s_umask, umask_lane);
+    __syncthreads();
+    const uint32_t umask = __builtin_amdgcn_readfirstlane(s_umask);   // the block's patterns: the union over its users
     v4f wP[E8];
     float alpha = 0.f;
     int cur_pat = -1;
@@ -1552,13 +1562,44 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
         rs[i] = -INFINITY;
         ri[i] = -1;
     }
-    const float seed = grouped_threshold_seed(pmu, Sr, hc, p);
     float thr = seed;
 
     const int64_t per = (p.tiles + p.nsplit - 1) / p.nsplit;
-    const int64_t t_begin = (int64_t)blockIdx.y * per;
+    const int64_t t_begin = (int64_t)by * per;
     const int64_t t_end = min(p.tiles, t_begin + per);
-    const int64_t nstages = t_end > t_begin ? (t_end - t_begin + TPS - 1) / TPS : 0;
+    // the stages to step through: those that hold a tile of a pattern in `umask`, as up to 15 ranges of stage numbers
+    // (relative to t_begin) in lanes -- range i in lane i of r_first / r_cnt; inside a stage the tiles of other patterns
+    // are passed over
+    int r_first = 0, r_cnt = 0, nranges = 0, vstages = 0;
+    {
+        int last_end = -1;
+        for (int q = 1; q < GRP_MAXPAT; ++q) {
+            const int rows = p.grp[40 + q];
+            if (rows == 0 || !((umask >> q) & 1u)) continue;
+            const int64_t gt0 = p.grp[q] >> 5, gt1 = gt0 + ((rows + 31) >> 5);
+            const int64_t lo = gt0 > t_begin ? gt0 : t_begin, hi = gt1 < t_end ? gt1 : t_end;
+            if (lo >= hi) continue;
+            int s0 = (int)((lo - t_begin) / TPS);
+            const int s1 = (int)((hi - 1 - t_begin) / TPS);
+            if (s0 <= last_end) s0 = last_end + 1;
+            if (s0 > s1) continue;
+            r_first = lane == nranges ? s0 : r_first;
+            r_cnt = lane == nranges ? s1 - s0 + 1 : r_cnt;
+            ++nranges;
+            vstages += s1 - s0 + 1;
+            last_end = s1;
+        }
+    }
+    int w_idx = -1, w_stage = 0, w_left = 0;
+    auto next_stage = [&]() __attribute__((always_inline)) {
+        if (w_left == 0) {
+            ++w_idx;
+            w_stage = __builtin_amdgcn_readlane(r_first, w_idx < nranges ? w_idx : 0);
+            w_left = __builtin_amdgcn_readlane(r_cnt, w_idx < nranges ? w_idx : 0);
+        }
+        --w_left;
+        return w_stage++;
+    };
 
     auto issue_stage = [&](int64_t s, int buf) {
         const float *src0 = p.rs + (size_t)(t_begin + s * TPS) * 32 * E;   // rows past the last tile are zero padding
@@ -1567,24 +1608,28 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
             const int ps = pc * 64 + lane;
             const int r = ps / S, sl = ps - r * S;
             const int q = sl ^ (r & (SW - 1));
-            lds_dma16(src0 + (size_t)r * E + q * 4, dst + pc * 256);
+            lds_dma16_b(src0 + (size_t)r * E + q * 4, dst + pc * 256);
         }
     };
 
-    if (nstages > 0) issue_stage(0, 0);
+    int st_cur = vstages > 0 ? next_stage() : 0, st_next = vstages > 1 ? next_stage() : 0;
+    if (vstages > 0) issue_stage(st_cur, 0);
     wait_all_vmem();
     __syncthreads();
 
     v16f acc;
     unsigned long long tie_mask = 0ull;                    // lanes with a tie event at their list's present last value (tie_update)
-    for (int64_t s = 0; s < nstages; ++s) {
-        const int buf = (int)(s & 1);
-        if (s + 1 < nstages) issue_stage(s + 1, buf ^ 1);
+    int tiles_done = 0;
+    for (int v = 0; v < vstages; ++v) {
+        const int buf = v & 1;
+        if (v + 1 < vstages) issue_stage(st_next, buf ^ 1);
         for (int tl = 0; tl < TPS; ++tl) {
-            const int64_t t = t_begin + s * TPS + tl;
+            const int64_t t = t_begin + (int64_t)st_cur * TPS + tl;
             if (t >= t_end) break;                                      // wave-uniform
             const int info = __builtin_amdgcn_readfirstlane(p.tile_info[t]);
             const int pat = info & 255, nvalid = info >> 8;
+            if (!((umask >> pat) & 1u)) continue;                       // a neighbouring pattern's tile in a straddling stage
+            ++tiles_done;
             if (pat != cur_pat) {                                       // at most 2^C - 1 times per block
                 cur_pat = pat;
                 const float inv_n = 1.0f / (float)__builtin_popcount(pat);
@@ -1598,7 +1643,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
 #pragma unroll 1
                 for (int c = 0; c < C; ++c) {           // rolled: E8 loads in flight, not C * E8
                     if (!((pat >> c) & 1)) continue;
-                    const v4f *row = pmu + (c + 1) * Sr + h;
+                    const v4f *row = reinterpret_cast<const v4f *>(p.pm) + (size_t)ul * ((C + 1) * Sr) + (c + 1) * Sr + h;
 #pragma unroll
                     for (int T = 0; T < E8; ++T) {
                         if (!PAD || 2 * T + h < Sr) wP[T] += row[2 * T];
@@ -1649,12 +1694,15 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
         }
         wait_all_vmem();
         __syncthreads();
+        st_cur = st_next;
+        if (v + 2 < vstages) st_next = next_stage();
     }
+    if (p.tiles_scanned && threadIdx.x == 0) atomicAdd(p.tiles_scanned, (unsigned long long)tiles_done);
 
     // ---- publish (slot -> dish id), merge the two lanes of each user -------------------------------------
     float *ls = smem + (size_t)wave * 2 * KR * 64;       // aliases stage 0: every wave is past the last barrier
     int32_t *li = reinterpret_cast<int32_t *>(ls + (size_t)KR * 64);
-    grouped_publish<KR>(ls, li, rs, ri, p, lane, uidx, uvalid, tie_mask, (int)blockIdx.y);
+    grouped_publish<KR>(ls, li, rs, ri, p, lane, uidx, uvalid, tie_mask, by);
     (void)k;
 }
 
@@ -2558,7 +2606,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     a.plan = nullptr; a.order = nullptr; a.tiles_scanned = nullptr; a.items = nullptr;
     const int64_t ublocks = (nU + 32 * WAVES - 1) / (32 * WAVES);
     int nsplit = pick_splits(h, ublocks, a.tiles, 2 * TPS, 512);
-    if (BF16X3 && !HV && h->opt_topk_form != 1 && h->opt_topk_prune != 0 && h->opt_variant < 100 && ublocks >= 6) {
+    if ((!BF16X3 || (!HV && h->opt_topk_form != 1)) && h->opt_topk_prune != 0 && h->opt_variant < 100 && ublocks >= 6) {
         // Pattern pruning makes the blocks unequal -- a block of users with one relevant pattern steps through a fifteenth of
         // the catalogue, one whose users need most patterns through all of it -- so a launch with many user blocks is cut into
         // dish ranges and the (block, range) items are handed out longest first (m2d_plan_items_*).  The longest item bounds
@@ -2604,71 +2652,71 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     }
     float *tmp_s = h->scratch ? h->scratch + (size_t)2 * nU * nsplit * k : nullptr;
     int32_t *tmp_i = reinterpret_cast<int32_t *>(tmp_s ? tmp_s + tmp_entries : nullptr);
-    if constexpr (BF16X3) {
-        // "topk_form": 0 or 2 = pipelined form (E = 64: 2.55 ms against 3.3 at 100 k dishes; E = 128: 38.3 ms against
-        // 45.4 at 1 M dishes), 1 = first form (kept as the A/B reference)
-        const bool pipe = HV || h->opt_topk_form != 1;
-        if (pipe) {
-            // the call's plan: per user the scan-start bound, <U_high, CE_c> and the mask of patterns that can reach the
-            // top-k; users sorted by mask so that a block's 256 users share their patterns (a single block: no sort)
-            const size_t nitems = (size_t)ublocks * nsplit;
-            const size_t need = (size_t)nU * 8 + (size_t)nU + PLAN_KEYS + 8 + 2 * nitems;
-            if (h->topk_plan_cap < need) {
-                if (h->topk_plan) M2D_HIP_TRY(h, hipFree(h->topk_plan));
-                h->topk_plan = nullptr; h->topk_plan_cap = 0;
-                M2D_HIP_TRY(h, hipMalloc((void **)&h->topk_plan, need * sizeof(float)));
-                h->topk_plan_cap = need;
-            }
-            float *plan = h->topk_plan;
-            int32_t *order = reinterpret_cast<int32_t *>(plan + (size_t)nU * 8), *hist = order + ((nU + 3) & ~(int64_t)3);      // hist: 16-B aligned
-            unsigned long long *counter = reinterpret_cast<unsigned long long *>(hist + PLAN_KEYS);
-            const bool prune = h->opt_topk_prune != 0;
-            hipLaunchKernelGGL(m2d_topk_user_plan, dim3((unsigned)((nU * 16 + 255) / 256)), dim3(256), 0, st, h->pm, h->ce, users, nU, h->U,
-                               h->user_base, h->E, a.grp, (int)k, h->a, h->b, (HV || !prune) ? 1 : (h->opt_topk_prune == 2 ? 2 : (h->opt_topk_prune == 4 ? 4 : 0)), plan);
-            a.plan = plan;
-            if (prune && !HV && nU > 256 && h->opt_topk_prune != 3) {      // 3: pruning without the sort (A/B)
-                M2D_HIP_TRY(h, hipMemsetAsync(hist, 0, PLAN_KEYS * sizeof(int32_t), st));
-                const size_t tab = (size_t)PLAN_KEYS * sizeof(int32_t);
-                const unsigned sblocks = (unsigned)((nU + 1023) / 1024 < 4 * h->num_cu ? (nU + 1023) / 1024 : 4 * h->num_cu);
-                M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_plan_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab));
-                M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_plan_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab));
-                hipLaunchKernelGGL(m2d_plan_hist, dim3(sblocks), dim3(1024), tab, st, plan, nU, hist);
-                hipLaunchKernelGGL(m2d_plan_scan, dim3(1), dim3(1024), 0, st, hist);
-                hipLaunchKernelGGL(m2d_plan_scatter, dim3(sblocks), dim3(1024), tab, st, plan, nU, hist, order);
-                a.order = order;
-            }
-            if (a.order && nitems > (size_t)h->num_cu && h->opt_topk_prune != 5) {      // 5: grid order (A/B)
-                int32_t *work = reinterpret_cast<int32_t *>(counter + 1), *items = work + nitems;
-                hipLaunchKernelGGL(m2d_plan_items_work, dim3((unsigned)((ublocks + 3) / 4)), dim3(256), 0, st, plan, order, nU, a.grp, a.tiles,
-                                   nsplit, work);
-                hipLaunchKernelGGL(m2d_plan_items_sort, dim3(1), dim3(1024), 0, st, work, (int64_t)nitems, a.tiles, nsplit, items);
-                a.items = items;
-            }
-            M2D_HIP_TRY(h, hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
-            a.tiles_scanned = counter;
-            h->topk_tiles_counter = counter;
-            h->topk_tiles_full = (int64_t)((nU + 255) / 256) * a.tiles;
-            M2D_HIP_TRY(h, hipGetLastError());
+    // "topk_form" (split-bf16 kernels): 0 or 2 = pipelined form (E = 64: 2.55 ms against 3.3 at 100 k dishes; E = 128:
+    // 38.3 ms against 45.4 at 1 M dishes), 1 = first form (kept as the A/B reference; it takes no plan)
+    const bool pipe = HV || h->opt_topk_form != 1;
+    if (!BF16X3 || pipe) {
+        // the call's plan: per user the scan-start bound, <U_high, CE_c> and the mask of patterns that can reach the
+        // top-k; users sorted by mask so that a block's 256 users share their patterns (a single block: no sort)
+        const size_t nitems = (size_t)ublocks * nsplit;
+        const size_t need = (size_t)nU * 8 + (size_t)nU + PLAN_KEYS + 8 + 2 * nitems;
+        if (h->topk_plan_cap < need) {
+            if (h->topk_plan) M2D_HIP_TRY(h, hipFree(h->topk_plan));
+            h->topk_plan = nullptr; h->topk_plan_cap = 0;
+            M2D_HIP_TRY(h, hipMalloc((void **)&h->topk_plan, need * sizeof(float)));
+            h->topk_plan_cap = need;
         }
+        float *plan = h->topk_plan;
+        int32_t *order = reinterpret_cast<int32_t *>(plan + (size_t)nU * 8), *hist = order + ((nU + 3) & ~(int64_t)3);      // hist: 16-B aligned
+        unsigned long long *counter = reinterpret_cast<unsigned long long *>(hist + PLAN_KEYS);
+        const bool prune = h->opt_topk_prune != 0;
+        hipLaunchKernelGGL(m2d_topk_user_plan, dim3((unsigned)((nU * 16 + 255) / 256)), dim3(256), 0, st, h->pm, h->ce, users, nU, h->U,
+                           h->user_base, h->E, a.grp, (int)k, h->a, h->b, (HV || !prune) ? 1 : (h->opt_topk_prune == 2 ? 2 : (h->opt_topk_prune == 4 ? 4 : 0)), plan);
+        a.plan = plan;
+        if (prune && !HV && nU > 32 * WAVES && h->opt_topk_prune != 3) {      // 3: pruning without the sort (A/B)
+            M2D_HIP_TRY(h, hipMemsetAsync(hist, 0, PLAN_KEYS * sizeof(int32_t), st));
+            const size_t tab = (size_t)PLAN_KEYS * sizeof(int32_t);
+            const unsigned sblocks = (unsigned)((nU + 1023) / 1024 < 4 * h->num_cu ? (nU + 1023) / 1024 : 4 * h->num_cu);
+            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_plan_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab));
+            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_plan_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab));
+            hipLaunchKernelGGL(m2d_plan_hist, dim3(sblocks), dim3(1024), tab, st, plan, nU, hist);
+            hipLaunchKernelGGL(m2d_plan_scan, dim3(1), dim3(1024), 0, st, hist);
+            hipLaunchKernelGGL(m2d_plan_scatter, dim3(sblocks), dim3(1024), tab, st, plan, nU, hist, order);
+            a.order = order;
+        }
+        if (a.order && nitems > (size_t)h->num_cu && h->opt_topk_prune != 5) {      // 5: grid order (A/B)
+            int32_t *work = reinterpret_cast<int32_t *>(counter + 1), *items = work + nitems;
+            hipLaunchKernelGGL(m2d_plan_items_work, dim3((unsigned)((ublocks + 3) / 4)), dim3(256), 0, st, plan, order, nU, a.grp, a.tiles,
+                               nsplit, work, 32 * WAVES);
+            hipLaunchKernelGGL(m2d_plan_items_sort, dim3(1), dim3(1024), 0, st, work, (int64_t)nitems, a.tiles, nsplit, items);
+            a.items = items;
+        }
+        M2D_HIP_TRY(h, hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
+        a.tiles_scanned = counter;
+        h->topk_tiles_counter = counter;
+        h->topk_tiles_full = (int64_t)ublocks * a.tiles;
+        M2D_HIP_TRY(h, hipGetLastError());
+    }
+    const dim3 grid = a.items ? dim3((unsigned)(ublocks * nsplit)) : dim3((unsigned)ublocks, (unsigned)nsplit);
+    if constexpr (BF16X3) {
         if constexpr (HV) {
             auto kern = m2d_topk_grouped_bf16_pipe2<E, KR, 1, true>;
             M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(512), lds, st, a);
+            hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);
         } else if (!pipe) {
             auto kern = m2d_topk_grouped_bf16<E, WAVES, KR>;
             M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(WAVES * 64), lds, st, a);
+            hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, a);
         } else {
             static_assert(WAVES == 8, "the pipelined kernel is written for 256 users per block");
             auto kern = m2d_topk_grouped_bf16_pipe2<E, KR, 1>;
             M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            if (a.items) hipLaunchKernelGGL(kern, dim3((unsigned)(ublocks * nsplit)), dim3(512), lds, st, a);
-            else hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(512), lds, st, a);
+            hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);
         }
     } else {
         auto kern = m2d_topk_grouped<E8, WAVES, KR, PAD>;
         M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(WAVES * 64), lds, st, a);
+        hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, a);
     }
     M2D_HIP_TRY(h, hipGetLastError());
     if (nsplit > 1) {

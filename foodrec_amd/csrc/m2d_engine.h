@@ -151,6 +151,14 @@ static __device__ __forceinline__ void lds_dma16(const void *src, const void *ld
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
 }
 
+// the same through the compiler's builtin (the inline-asm form takes its 64-bit address in any VGPR pair; where the
+// allocator picks an odd one hipcc 7.2 stops with "Subtarget requires even aligned vector registers")
+static __device__ __forceinline__ void lds_dma16_b(const void *src, void *lds_base_uniform)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_base_uniform, 16, 0, 0);
+}
+
 // launchers (m2d_score.hip / m2d_topk.hip); all enqueue on `stream` and return a status
 int m2d_launch_score_pairs(m2d_engine *h, const int32_t *users, const int32_t *items, const float *cats,
                            bool by_dish, int64_t B, float *out, hipStream_t stream,
