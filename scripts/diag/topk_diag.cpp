@@ -22,7 +22,7 @@ int main(int argc, char **argv)
     if (getenv("M2D_DIAG_PRUNE")) h.opt_topk_prune = atoi(getenv("M2D_DIAG_PRUNE"));
     if (argc > 1) h.opt_variant = atoi(argv[1]);
     unsigned s = 1;
-    auto rnd1 = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    auto rnd1 = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffffff) / 16777216.0f - 0.5f; };   // 24 bits: 16-bit draws tie often enough to send thousands of users through the tie repair
     // ~N(0, 1/E): twelve uniforms, scaled (the benchmark's tables); uniform non-empty category subsets
     auto rnd = [&]() { float t = 0.f; for (int i = 0; i < 12; ++i) t += rnd1(); return t * 0.125f; };
     if (getenv("M2D_DIAG_PATTERNS")) for (int64_t d = 0; d < I; ++d) { s = s * 1664525u + 1013904223u; const int pt = 1 + (int)((s >> 10) % 15u); for (int c = 0; c < C; ++c) cats[d * C + c] = (pt >> c) & 1 ? 1.0f : 0.0f; }
