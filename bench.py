@@ -1096,10 +1096,10 @@ def main():
             x3 = kernel_used.endswith("bf16x3")
             Ew = 2 * E if a.topk_with_ingredients else E                 # grouped rows are [H[d] | RE[d]] with the ingredient table
             fl = (2.0 * Ew * (3 if x3 else 1) if kernel_used.startswith("m2d_topk_grouped") else 2.0 * K) * units
-            # the pipelined split-bf16 kernel steps through its blocks' relevant mask patterns only: executed flops = that share
+            # the pattern-grouped kernels step through their blocks' relevant mask patterns only: executed flops = that share
             # of the catalogue's (the share of the step's last launch stands for the step)
             scanned_frac = None
-            if x3 and kernel_used.startswith("m2d_topk_grouped") and not a.topk_with_ingredients:
+            if kernel_used.startswith("m2d_topk_grouped") and not a.topk_with_ingredients:
                 sc_, fu_ = eng.get_option("topk_tiles_scanned"), eng.get_option("topk_tiles_full")
                 if sc_ > 0 and fu_ > 0:
                     scanned_frac = sc_ / fu_

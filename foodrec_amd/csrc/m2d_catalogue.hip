@@ -2331,9 +2331,16 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
                 }
             }
         }
-        float thr_rel[G];                                  // accumulators carry no alpha: compare against thr - alpha
+        // accumulators carry no alpha: compare against thr - alpha -- less the two roundings between `acc >= thr - alpha` and
+        // `acc + alpha >= thr` (the sum is quantised at ulp(alpha), many ulps of acc under the 0.99 : 0.01 blend), so that every
+        // score whose TOTAL reaches thr gets to the insertion, which compares totals: an equal total refused here would be a
+        // tie nobody records (seen as a tie-listed user that one split count listed and another did not)
+        float thr_rel[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) thr_rel[g] = thr[g] - alpha_prev[g];
+        for (int g = 0; g < G; ++g) {
+            const float d = thr[g] - alpha_prev[g];
+            thr_rel[g] = d - 2.4e-7f * (fabsf(thr[g]) + fabsf(alpha_prev[g]));   // 2^-22 (|thr| + |alpha|); thr = +inf: NaN, no candidate
+        }
         const int img_off = (int)(((q / TPS) & 1) * STAGE_BYTES + sub * TILE_BYTES) + lane_off;   // tile q
         const int img_prev = (int)((((q - 1) / TPS) & 1) * STAGE_BYTES + ((q - 1) & (TPS - 1)) * TILE_BYTES) + lane_off;
         unsigned long long m[G][16];                       // lane masks: row r of tile q-2 beats the lane's threshold

@@ -406,3 +406,29 @@ def test_pattern_pruning_changes_nothing_but_the_work(E, low_scale):
     eng.set_option("variant", 0); eng.set_option("topk_prune", 1)
     _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:60], k, dup=50)
     _check(eng, PM, RE, CE, cats, np.array([7, 3, 7]), k)       # a single block of users: no sort, the union of three masks
+
+
+@pytest.mark.parametrize("E,x3", [(64, 1), (64, 0), (128, 1), (200, 0), (32, 0)])
+def test_launch_order_and_the_exact_kernels_plan(E, x3):
+    """A pruned launch with more (user block, dish range) items than CUs hands them out longest first (m2d_plan_items_*;
+    "topk_prune" = 5 keeps the grid's order), and the exact-f32 kernel -- also the zero-padded one that serves the
+    reference's embed_size 200 -- takes the same plan as the split-bf16 one.  The order of the work changes no list."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    U, I, k = 12000, 9000, 10
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=E + 77 + x3, n_nan=5, dup=40)
+    PM[11] = 0.0
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    eng.set_option("topk_bf16x3", x3)
+    users = torch.as_tensor(np.random.default_rng(9).permutation(U).astype(np.int32), device="cuda")
+    out = {}
+    for prune in (0, 5, 1):
+        eng.set_option("topk_prune", prune)
+        s, i = eng.topk_users(users, k); eng.check()
+        assert eng.last_kernel() == ("m2d_topk_grouped_bf16x3" if x3 else "m2d_topk_grouped")
+        out[prune] = (s.cpu().numpy(), i.cpu().numpy(), eng.get_option("topk_tiles_scanned"), eng.get_option("topk_tiles_full"))
+    for prune in (5, 1):
+        assert np.array_equal(out[prune][1], out[0][1]) and np.array_equal(out[prune][0], out[0][0], equal_nan=True), prune
+    assert out[0][2] >= out[0][3] and out[1][2] == out[5][2] and out[1][2] < 0.6 * out[0][2], [o[2:] for o in out.values()]
+    _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:80], k, dup=40)
