@@ -61,7 +61,7 @@ if which in ("both", "topk"):
     eng = foodrec_amd.ScoringEngine(PM, RE, CE); eng.set_dish_categories(cats)
     users = torch.randperm(U, generator=g, device=dev)[:n].to(torch.int32)
     eng.topk_users(users[:1024], 10)                          # builds the retrieval tables
-    for name, x3, prune in (("topk_bf16x3", 1, 1), ("topk_bf16x3_every_tile", 1, 0), ("topk_f32", 0, 1)):
+    for name, x3, prune in (("topk_bf16x3", 1, 1), ("topk_bf16x3_every_tile", 1, 0), ("topk_f32", 0, 1), ("topk_f32_every_tile", 0, 0)):
         eng.set_option("topk_bf16x3", x3)
         eng.set_option("topk_prune", prune)
         avg, med = timed(lambda: eng.topk_users(users, 10))
@@ -69,11 +69,9 @@ if which in ("both", "topk"):
         kn = eng.last_kernel()
         first = launches.get(kn, 1 if x3 else 0) + WARM      # (the table-building call ran the default kernel once)
         launches[kn] = first + TIMED
-        flop = 2.0 * E * (3 if x3 else 1) * n * I
-        scanned = full = None
-        if x3:                                               # the pipelined kernel: flops of the tiles its blocks stepped through
-            scanned, full = eng.get_option("topk_tiles_scanned"), eng.get_option("topk_tiles_full")
-            flop = 2.0 * E * 3 * 256 * 32 * scanned
+        # flops of the tiles the blocks stepped through (256 user lanes x 32 dishes each; 3 MFMA passes in split bf16)
+        scanned, full = eng.get_option("topk_tiles_scanned"), eng.get_option("topk_tiles_full")
+        flop = 2.0 * E * (3 if x3 else 1) * 256 * 32 * scanned
         res[name] = {
             "kernel": eng.last_kernel(), "users": n, "dishes": I, "embed_size": E, "launches": TIMED, "warmup": WARM,
             "event_avg_ms": avg, "event_median_ms": med, "executed_flop_per_launch": flop,

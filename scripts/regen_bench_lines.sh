@@ -9,6 +9,9 @@ python bench.py --workload mlp --embed 128 --scaling-users 0 > $D/bench_mlp_e128
 python bench.py --config 3 --steps 2 --warmup 1 --no-cpu-baseline > $D/bench_config3.json 2>/dev/null; echo config3 rc=$?
 python bench.py --config 4 --steps 2 --warmup 1 --no-cpu-baseline > $D/bench_config4.json 2>/dev/null; echo config4 rc=$?
 python bench.py --workload topk --no-cpu-baseline > $D/bench_topk_100kdishes_e64.json 2>/dev/null; echo topk rc=$?
+python bench.py --workload topk --users 64657 --dishes 4548 --embed 200 --no-cpu-baseline > $D/bench_topk_refshape_e200.json 2>/dev/null; echo topk_e200 rc=$?
+python bench.py --workload topk --dishes 1000000 --no-cpu-baseline > $D/bench_topk_1Mdishes_e64.json 2>/dev/null; echo topk_1M rc=$?
+python bench.py --workload topk --dishes 1000000 --embed 128 --no-cpu-baseline > $D/bench_topk_1Mdishes_e128.json 2>/dev/null; echo topk_1M_e128 rc=$?
 python bench.py --workload train --learner sgd --steps 300 > $D/bench_train_sgd_refdefault.json 2>/dev/null; echo sgd rc=$?
 python bench.py --workload train --learner adam --steps 300 > $D/bench_train_adam_refdefault.json 2>/dev/null; echo adam rc=$?
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --no-cpu-baseline > $D/bench_dist1.json 2>/dev/null; echo dist1 rc=$?
