@@ -247,10 +247,12 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
  * picks between the two split-bf16 head kernels, same results within the split's rounding: 0 = matrix waves fed by
  * gather / DMA waves, 1 = every wave gathers its own rows.  "topk_grouped"
  * (default 1; see m2d_topk_users) and "topk_form" (0 / 2 = the pipelined split-bf16 retrieval kernel, 1 = its first
- * form; same results) select among retrieval kernels.  "topk_prune" (default 1): the pipelined retrieval kernel starts each
- * user's scan from a lower bound of its k-th score and steps through the tiles of the mask patterns that can reach its
- * top-k only (with 0/1 masks every dish of pattern P scores within alpha_P[u] +- |w_P[u]| max|RE[d]|; users are sorted by
- * their pattern mask so that a block's users share patterns); the lists are the same bit for bit with 0 (every tile).
+ * form; same results) select among retrieval kernels.  "topk_prune" (default 1): the pattern-grouped retrieval kernels
+ * (pipelined split-bf16 and exact f32) start each user's scan from a lower bound of its k-th score and step through the
+ * tiles of the mask patterns that can reach its top-k only (with 0/1 masks every dish of pattern P scores within
+ * alpha_P[u] +- |w_P[u]| max|RE[d]|; users are sorted by their pattern mask so that a block's users share patterns, and a
+ * launch's (user block, dish range) items are handed out longest first); the lists are the same bit for bit with 0 (every
+ * tile).  2 / 3 / 4 / 5 are A/B forms of the same: the bound only, no sort, the patterns only, the grid's launch order.
  * m2d_score_pairs* (the reference path) is always exact float32.  Unknown names: M2D_ERR_INVALID_ARG.
  * m2d_get_option also answers three diagnostics of the last m2d_topk_users call on the pattern-grouped kernels (they
  * synchronise the device): "topk_repaired" (users re-ranked in id order because their k-th score was tied),
