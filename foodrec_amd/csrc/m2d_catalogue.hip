@@ -824,78 +824,105 @@ __global__ __launch_bounds__(256) void m2d_topk_repair_merge(RepairArgs p)
     }
 }
 
-// listed users p.cap, p.cap + 1, ...: one block each, a thread takes every 256th dish (slow; degenerate tables only)
+// listed users p.cap, p.cap + 1, ...: one block each over the whole catalogue (slow; degenerate tables only).  The same
+// arithmetic as m2d_topk_repair_scan, step for step -- pattern sums, a float4 column per lane, the 16-lane rotation sum --
+// so a user's re-ranked scores do not depend on which of the two kernels its place in the list sent it to (the list's order
+// is the order of the compaction's atomics).
+template <bool HVR>
 __global__ __launch_bounds__(256) void m2d_topk_repair_rest(RepairArgs p)
 {
     extern __shared__ __align__(16) float rsm[];
-    const int C = p.C, E = p.E, k = p.k, W = (C + 1) * E;
+    constexpr int C = 4, NG = 16, NP = 1 << C;              // 16 groups of 16 lanes, a dish each
+    const int E = p.E, E4 = E >> 2, k = p.k, W = (C + 1) * E;
     float *um = rsm;                                        // [(C+1) E] this user's block
-    float *cem = um + W;                                    // [C E]
-    float *ls = cem + C * E;                                // [256][k] scores
-    int32_t *li = reinterpret_cast<int32_t *>(ls + 256 * k);
-    __shared__ float red_s[4];
-    __shared__ int32_t red_i[4], red_t[4];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float *wp = um + W;                                     // [NP][E]
+    float *ls = wp + NP * E;                                // [NG][k]
+    int32_t *li = reinterpret_cast<int32_t *>(ls + NG * k);
+    __shared__ float hc[C], alpha[NP];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, j = lane & 15, grp = t >> 4;
     const int count = p.tie_list[0];
-    for (int i = t; i < C * E; i += 256) cem[i] = p.ce[i];
     for (int f = p.cap + blockIdx.x; f < count; f += gridDim.x) {     // block-uniform
         const int64_t u = p.tie_list[1 + f];
         int64_t ul = (int64_t)p.users[u] - p.user_base;
         if (ul < 0 || ul >= p.U) ul = 0;                    // latched by the scan kernel
         __syncthreads();
         for (int i = t; i < W; i += 256) um[i] = p.pm[(size_t)ul * W + i];
-        float *ms = ls + (size_t)t * k;
-        int32_t *mi = li + (size_t)t * k;
-        for (int i = 0; i < k; ++i) { ms[i] = -INFINITY; mi[i] = -1; }
+        float slot_s = -INFINITY;
+        int32_t slot_i = -1;
         __syncthreads();
-        for (int64_t d = t; d < p.I; d += 256) {
-            const float *m = p.cats + (size_t)d * C;
-            const float *it = p.re + (size_t)d * E;
-            float n = 0.f, hs = 0.f, lo = 0.f;
-            for (int c = 0; c < C; ++c) n += m[c];                                   // :77
-            for (int c = 0; c < C; ++c) {
-                const float mc = m[c];
-                for (int e = 0; e < E; ++e) {
-                    if (!p.hv) hs = fmaf(um[e], mc * cem[c * E + e], hs);             // :67-75
-                    lo = fmaf(it[e], mc * um[(c + 1) * E + e], lo);                   // :82-90
-                }
-            }
-            if (p.hv)
-                for (int e = 0; e < E; ++e) hs = fmaf(um[e], p.hv[(size_t)d * E + e], hs);
-            const float sc = __fadd_rn(__fmul_rn(p.a, p.hv ? hs : hs / n), __fmul_rn(p.b, lo / n));   // :79, :92, :95-96
-            if (sc > ms[k - 1]) {                           // strict, dishes in ascending id: ties keep the lower id (NaN never enters)
-                int pos = k - 1;
-                while (pos > 0 && sc > ms[pos - 1]) { ms[pos] = ms[pos - 1]; mi[pos] = mi[pos - 1]; --pos; }
-                ms[pos] = sc;
-                mi[pos] = (int32_t)d;
-            }
+        for (int i = t; i < NP * E; i += 256) {
+            const int pt = i / E, e = i - pt * E;
+            float w = 0.f;
+            for (int c = 0; c < C; ++c) w += ((pt >> c) & 1) ? um[(c + 1) * E + e] : 0.f;
+            wp[i] = w;
+        }
+        {                                                   // wave c: <U_high, CE_c>
+            const int c = wave;
+            float q = 0.f;
+            for (int e = lane; e < E; e += 64) q = fmaf(um[e], p.ce[(size_t)c * E + e], q);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+            if (lane == 0) hc[c] = q;
         }
         __syncthreads();
-        int ptr = 0;
-        for (int o = 0; o < k; ++o) {
-            float bs = ptr < k ? ms[ptr] : 0.f;
-            int32_t bi = ptr < k ? mi[ptr] : -1;
-            int bt = t;
+        if (t < NP) {
+            float x = 0.f;
+            for (int c = 0; c < C; ++c) x += ((t >> c) & 1) ? hc[c] : 0.f;
+            alpha[t] = x / (float)__builtin_popcount(t);                                     // :79 (pattern 0: 0 / 0 = NaN)
+        }
+        __syncthreads();
+        const v4f *um4 = reinterpret_cast<const v4f *>(um), *wp4 = reinterpret_cast<const v4f *>(wp);
+        for (int64_t db = 0; db < p.I; db += NG) {          // wave-uniform trip count
+            const int64_t d = db + grp;
+            const bool ok = d < p.I;
+            const int64_t dd = ok ? d : 0;
+            const v4f m = *reinterpret_cast<const v4f *>(p.cats + (size_t)dd * C);
+            const int pt = (m.x != 0.f ? 1 : 0) | (m.y != 0.f ? 2 : 0) | (m.z != 0.f ? 4 : 0) | (m.w != 0.f ? 8 : 0);
+            float hs = 0.f, lo = 0.f;
+            for (int q = j; q < E4; q += 16) {
+                const v4f it = reinterpret_cast<const v4f *>(p.re)[(size_t)dd * E4 + q];
+                const v4f w = wp4[pt * E4 + q];
+                lo = fmaf(it.x, w.x, fmaf(it.y, w.y, fmaf(it.z, w.z, fmaf(it.w, w.w, lo))));
+                if (HVR) {
+                    const v4f hvv = reinterpret_cast<const v4f *>(p.hv)[(size_t)dd * E4 + q];
+                    const v4f uh = um4[q];
+                    hs = fmaf(uh.x, hvv.x, fmaf(uh.y, hvv.y, fmaf(uh.z, hvv.z, fmaf(uh.w, hvv.w, hs))));
+                }
+            }
+            lo = row16_sum(lo);
+            if (HVR) hs = row16_sum(hs);
+            const float n = (float)__builtin_popcount(pt);                                    // :77
+            float sc = __fadd_rn(__fmul_rn(p.a, HVR ? hs : alpha[pt]), __fmul_rn(p.b, lo / n));   // :79, :92, :95-96
+            sc = ok ? fmaxf(sc, -INFINITY) : -INFINITY;                                       // NaN -> -inf: never enters
+            const float left_s = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, INFINITY),
+                                                    __builtin_bit_cast(int, slot_s), 0x111, 0xf, 0xf, false));
+            const int32_t left_i = __builtin_amdgcn_update_dpp(-1, slot_i, 0x111, 0xf, 0xf, false);
+            const bool above_left = sc > left_s, above_me = sc > slot_s;                      // strict: ascending ids keep the lower id first
+            slot_i = above_left ? left_i : (above_me ? (int32_t)dd : slot_i);
+            slot_s = above_left ? left_s : (above_me ? sc : slot_s);
+        }
+        if (j < k) { ls[grp * k + j] = slot_s; li[grp * k + j] = slot_s > -INFINITY ? slot_i : -1; }
+        __syncthreads();
+        if (wave == 0) {                                    // the NG lists -> the user's final list, (score desc, id asc)
+            const bool live = lane < NG;
+            int ptr = 0;
+            for (int o = 0; o < k; ++o) {
+                float bs = (live && ptr < k) ? ls[lane * k + ptr] : 0.f;
+                int32_t bi = (live && ptr < k) ? li[lane * k + ptr] : -1;
+                int bl = lane;
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float xs = __shfl_xor(bs, off, 64);
-                const int32_t xi = __shfl_xor(bi, off, 64);
-                const int xt = __shfl_xor(bt, off, 64);
-                if (repair_ahead(xs, xi, bs, bi)) { bs = xs; bi = xi; bt = xt; }
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const float xs = __shfl_xor(bs, off, 64);
+                    const int32_t xi = __shfl_xor(bi, off, 64);
+                    const int xl = __shfl_xor(bl, off, 64);
+                    if (repair_ahead(xs, xi, bs, bi)) { bs = xs; bi = xi; bl = xl; }
+                }
+                if (lane == 0) {
+                    p.out_scores[u * k + o] = bi >= 0 ? bs : __builtin_nanf("");
+                    p.out_ids[u * k + o] = bi;
+                }
+                if (live && bi >= 0 && bl == lane) ++ptr;
             }
-            if (lane == 0) { red_s[wave] = bs; red_i[wave] = bi; red_t[wave] = bt; }
-            __syncthreads();
-            float fs = red_s[0];
-            int32_t fi = red_i[0];
-            int ft = red_t[0];
-            for (int w = 1; w < 4; ++w)
-                if (repair_ahead(red_s[w], red_i[w], fs, fi)) { fs = red_s[w]; fi = red_i[w]; ft = red_t[w]; }
-            if (t == 0) {
-                p.out_scores[u * k + o] = fi >= 0 ? fs : __builtin_nanf("");
-                p.out_ids[u * k + o] = fi;
-            }
-            if (fi >= 0 && ft == t) ++ptr;
-            __syncthreads();
         }
     }
 }
@@ -2740,8 +2767,8 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         r.part_i = reinterpret_cast<int32_t *>(r.part_s + (size_t)REPAIR_CAP * REPAIR_SPLITS * k);
         const int ub = (!HV && h->E <= 128) ? 4 : 2;                  // listed users per pass of the repair scan (LDS: 21 E + 128 k floats each)
         const size_t slds = (size_t)ub * ((size_t)(h->C + 1 + 16) * h->E + (size_t)2 * 64 * k) * sizeof(float);
-        const size_t rlds = ((size_t)(2 * h->C + 1) * h->E + (size_t)2 * 256 * k) * sizeof(float);
-        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_topk_repair_rest, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+        const size_t rlds = ((size_t)(h->C + 1 + 16) * h->E + (size_t)2 * 16 * k) * sizeof(float);
+        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_topk_repair_rest<HV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
         hipLaunchKernelGGL(m2d_topk_tie_compact, dim3((unsigned)((nU + 255) / 256)), dim3(256), 0, st, tie_final, nU, tie_list);
         if (ub == 4) {
             auto rk = m2d_topk_repair_scan<4, HV>;
@@ -2753,7 +2780,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
             hipLaunchKernelGGL(rk, dim3(REPAIR_SPLITS, 8), dim3(1024), slds, st, r);
         }
         hipLaunchKernelGGL(m2d_topk_repair_merge, dim3(16), dim3(256), 0, st, r);
-        hipLaunchKernelGGL(m2d_topk_repair_rest, dim3((unsigned)(h->num_cu * 2)), dim3(256), rlds, st, r);
+        hipLaunchKernelGGL(m2d_topk_repair_rest<HV>, dim3((unsigned)(h->num_cu * 2)), dim3(256), rlds, st, r);
         M2D_HIP_TRY(h, hipGetLastError());
     }
     hipLaunchKernelGGL(m2d_topk_fill_absent, dim3((unsigned)((nU + 127) / 128)), dim3(128), 0, st, final_s, final_i, nU, k,
