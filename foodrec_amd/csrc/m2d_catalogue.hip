@@ -547,12 +547,8 @@ __global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, co
 // Users with fewer than k ranked dishes (every finite-scored dish is already in their list, the rest of the
 // catalogue scored NaN -- an empty category mask, Model_Recommender.py:79 -- or -inf): append the dishes not
 // in the list in ascending id with a NaN score, which is where heapq.nlargest-style "NaN last" puts them.
-__global__ void m2d_topk_fill_absent(float *scores, int32_t *ids, int64_t nU, int k, int64_t I)
+__device__ __forceinline__ void fill_absent_user(float *s, int32_t *id, const int k, const int64_t I)
 {
-    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= nU) return;
-    float *s = scores + u * k;
-    int32_t *id = ids + u * k;
     int n = 0;
     while (n < k && id[n] >= 0) ++n;
     // bit-equal scores inside the list: ascending dish id, as heapq.nlargest leaves them (evaluate.py:63); the
@@ -575,6 +571,12 @@ __global__ void m2d_topk_fill_absent(float *scores, int32_t *ids, int64_t nU, in
     }
 }
 
+__global__ void m2d_topk_fill_absent(float *scores, int32_t *ids, int64_t nU, int k, int64_t I)
+{
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < nU) fill_absent_user(scores + u * k, ids + u * k, k, I);
+}
+
 // Users whose final k-th score is tied with a score that was left out (tie_list: a count and their positions in the
 // call, gathered from the final tie values by m2d_topk_tie_compact): the whole catalogue again in dish-id order, in plain
 // f32 -- Model_Recommender.py:67-96 with the sums over a 0/1 mask's categories taken first -- and a strict insertion, so
@@ -589,10 +591,15 @@ __global__ void m2d_topk_fill_absent(float *scores, int32_t *ids, int64_t nU, in
 constexpr int REPAIR_SPLITS = 64, REPAIR_CAP = 1024;
 
 // the users whose final tie value is set (not NaN), as a list: [0] count, [1 + f] position in the call
-__global__ __launch_bounds__(256) void m2d_topk_tie_compact(const float *tie_final, int64_t nU, int32_t *tie_list)
+// -- and the lists of everybody else finished on the way (m2d_topk_fill_absent's work; a listed user's list is finished by
+// the kernel that rewrites it)
+__global__ __launch_bounds__(256) void m2d_topk_tie_compact(const float *tie_final, int64_t nU, int32_t *tie_list, float *scores,
+                                                            int32_t *ids, int k, int64_t I)
 {
     const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (u < nU && tie_final[u] == tie_final[u]) tie_list[1 + atomicAdd(&tie_list[0], 1)] = (int32_t)u;
+    if (u >= nU) return;
+    if (tie_final[u] == tie_final[u]) tie_list[1 + atomicAdd(&tie_list[0], 1)] = (int32_t)u;
+    else fill_absent_user(scores + u * k, ids + u * k, k, I);
 }
 
 struct RepairArgs {
@@ -794,7 +801,8 @@ __global__ __launch_bounds__(1024) void m2d_topk_repair_scan(RepairArgs p)
     }
 }
 
-__global__ __launch_bounds__(256) void m2d_topk_repair_merge(RepairArgs p)
+// the partial lists of listed user f < cap (one wave per user) -> the user's final list
+__device__ __forceinline__ void repair_merge_phase(const RepairArgs &p)
 {
     const int lane = threadIdx.x & 63, k = p.k;
     const int count = min(p.tie_list[0], p.cap);
@@ -821,6 +829,7 @@ __global__ __launch_bounds__(256) void m2d_topk_repair_merge(RepairArgs p)
             }
             if (live && bi >= 0 && bl == lane) ++ptr;
         }
+        if (lane == 0) fill_absent_user(p.out_scores + u * k, p.out_ids + u * k, k, p.I);     // (its own stores, in program order)
     }
 }
 
@@ -828,11 +837,13 @@ __global__ __launch_bounds__(256) void m2d_topk_repair_merge(RepairArgs p)
 // arithmetic as m2d_topk_repair_scan, step for step -- pattern sums, a float4 column per lane, the 16-lane rotation sum --
 // so a user's re-ranked scores do not depend on which of the two kernels its place in the list sent it to (the list's order
 // is the order of the compaction's atomics).
+// The kernel also does the first tier's last step (m2d_topk_repair_merge's work, before its own loop): one launch less per call.
 template <bool HVR>
-__global__ __launch_bounds__(256) void m2d_topk_repair_rest(RepairArgs p)
+__global__ __launch_bounds__(256) void m2d_topk_repair_finish(RepairArgs p)
 {
     extern __shared__ __align__(16) float rsm[];
     constexpr int C = 4, NG = 16, NP = 1 << C;              // 16 groups of 16 lanes, a dish each
+    repair_merge_phase(p);
     const int E = p.E, E4 = E >> 2, k = p.k, W = (C + 1) * E;
     float *um = rsm;                                        // [(C+1) E] this user's block
     float *wp = um + W;                                     // [NP][E]
@@ -923,6 +934,7 @@ __global__ __launch_bounds__(256) void m2d_topk_repair_rest(RepairArgs p)
                 }
                 if (live && bi >= 0 && bl == lane) ++ptr;
             }
+            if (lane == 0) fill_absent_user(p.out_scores + u * k, p.out_ids + u * k, k, p.I);
         }
     }
 }
@@ -1271,11 +1283,20 @@ __device__ __forceinline__ float grouped_threshold_seed(const v4f *pmu, const in
 // patterns' tiles only.  16 lanes per user, a float4 column each.
 __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const float *ce, const int32_t *users, int64_t nU, int64_t U,
                                                           int64_t user_base, int E, const int32_t *grp, int k, float a, float b,
-                                                          int no_alpha, float *plan)
+                                                          int no_alpha, float *plan, int32_t *zero_tie, unsigned long long *zero_tiles,
+                                                          int32_t *zero_hist, int nhist)
 {
     const int lane = threadIdx.x & 63, j = lane & 15;
     const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
     const int E4 = E >> 2;
+    // the call's counters start at zero (the kernels that count run after this one): the tie list's length, the tiles-scanned
+    // diagnostic, the sort's histogram -- three memset launches less per call
+    {
+        const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (gid == 0) { *zero_tie = 0; *zero_tiles = 0ull; }
+        if (zero_hist)
+            for (int64_t i = gid; i < nhist; i += (int64_t)gridDim.x * 256) zero_hist[i] = 0;
+    }
     int64_t ul = 0;
     if (u < nU) {
         ul = (int64_t)users[u] - user_base;
@@ -2666,7 +2687,9 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     float *tie_final = h->topk_flags + (nsplit > 1 ? (size_t)nU * (nsplit + (nsplit > 64 ? nsplit / 64 : 0)) : 0);
     a.tie_val = h->topk_flags;
     int32_t *tie_list = reinterpret_cast<int32_t *>(h->topk_flags + tie_vals);
-    M2D_HIP_TRY(h, hipMemsetAsync(tie_list, 0, sizeof(int32_t), st));
+    const bool pipe = HV || h->opt_topk_form != 1;           // "topk_form", split-bf16 kernels: see below
+    const bool planned = !BF16X3 || pipe;                    // (the first-form bf16 kernel takes no plan)
+    if (!planned) M2D_HIP_TRY(h, hipMemsetAsync(tie_list, 0, sizeof(int32_t), st));
     h->topk_tie_final = tie_final;
     h->topk_flags_used = nU;
     const size_t tmp_entries = nsplit > 64 ? (size_t)nU * (nsplit / 64) * k : 0;
@@ -2688,8 +2711,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     int32_t *tmp_i = reinterpret_cast<int32_t *>(tmp_s ? tmp_s + tmp_entries : nullptr);
     // "topk_form" (split-bf16 kernels): 0 or 2 = pipelined form (E = 64: 2.55 ms against 3.3 at 100 k dishes; E = 128:
     // 38.3 ms against 45.4 at 1 M dishes), 1 = first form (kept as the A/B reference; it takes no plan)
-    const bool pipe = HV || h->opt_topk_form != 1;
-    if (!BF16X3 || pipe) {
+    if (planned) {
         // the call's plan: per user the scan-start bound, <U_high, CE_c> and the mask of patterns that can reach the
         // top-k; users sorted by mask so that a block's 256 users share their patterns (a single block: no sort)
         const size_t nitems = (size_t)ublocks * nsplit;
@@ -2704,11 +2726,12 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         int32_t *order = reinterpret_cast<int32_t *>(plan + (size_t)nU * 8), *hist = order + ((nU + 3) & ~(int64_t)3);      // hist: 16-B aligned
         unsigned long long *counter = reinterpret_cast<unsigned long long *>(hist + PLAN_KEYS);
         const bool prune = h->opt_topk_prune != 0;
+        const bool sorted = prune && !HV && nU > 32 * WAVES && h->opt_topk_prune != 3;      // 3: pruning without the sort (A/B)
         hipLaunchKernelGGL(m2d_topk_user_plan, dim3((unsigned)((nU * 16 + 255) / 256)), dim3(256), 0, st, h->pm, h->ce, users, nU, h->U,
-                           h->user_base, h->E, a.grp, (int)k, h->a, h->b, (HV || !prune) ? 1 : (h->opt_topk_prune == 2 ? 2 : (h->opt_topk_prune == 4 ? 4 : 0)), plan);
+                           h->user_base, h->E, a.grp, (int)k, h->a, h->b, (HV || !prune) ? 1 : (h->opt_topk_prune == 2 ? 2 : (h->opt_topk_prune == 4 ? 4 : 0)), plan,
+                           tie_list, counter, sorted ? hist : nullptr, PLAN_KEYS);
         a.plan = plan;
-        if (prune && !HV && nU > 32 * WAVES && h->opt_topk_prune != 3) {      // 3: pruning without the sort (A/B)
-            M2D_HIP_TRY(h, hipMemsetAsync(hist, 0, PLAN_KEYS * sizeof(int32_t), st));
+        if (sorted) {
             const size_t tab = (size_t)PLAN_KEYS * sizeof(int32_t);
             const unsigned sblocks = (unsigned)((nU + 1023) / 1024 < 4 * h->num_cu ? (nU + 1023) / 1024 : 4 * h->num_cu);
             M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_plan_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab));
@@ -2725,7 +2748,6 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
             hipLaunchKernelGGL(m2d_plan_items_sort, dim3(1), dim3(1024), 0, st, work, (int64_t)nitems, a.tiles, nsplit, items);
             a.items = items;
         }
-        M2D_HIP_TRY(h, hipMemsetAsync(counter, 0, sizeof(unsigned long long), st));
         a.tiles_scanned = counter;
         h->topk_tiles_counter = counter;
         h->topk_tiles_full = (int64_t)ublocks * a.tiles;
@@ -2768,8 +2790,9 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         const int ub = (!HV && h->E <= 128) ? 4 : 2;                  // listed users per pass of the repair scan (LDS: 21 E + 128 k floats each)
         const size_t slds = (size_t)ub * ((size_t)(h->C + 1 + 16) * h->E + (size_t)2 * 64 * k) * sizeof(float);
         const size_t rlds = ((size_t)(h->C + 1 + 16) * h->E + (size_t)2 * 16 * k) * sizeof(float);
-        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_topk_repair_rest<HV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
-        hipLaunchKernelGGL(m2d_topk_tie_compact, dim3((unsigned)((nU + 255) / 256)), dim3(256), 0, st, tie_final, nU, tie_list);
+        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_topk_repair_finish<HV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+        hipLaunchKernelGGL(m2d_topk_tie_compact, dim3((unsigned)((nU + 255) / 256)), dim3(256), 0, st, tie_final, nU, tie_list, final_s, final_i,
+                           (int)k, h->I);
         if (ub == 4) {
             auto rk = m2d_topk_repair_scan<4, HV>;
             M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
@@ -2779,13 +2802,9 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
             M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
             hipLaunchKernelGGL(rk, dim3(REPAIR_SPLITS, 8), dim3(1024), slds, st, r);
         }
-        hipLaunchKernelGGL(m2d_topk_repair_merge, dim3(16), dim3(256), 0, st, r);
-        hipLaunchKernelGGL(m2d_topk_repair_rest<HV>, dim3((unsigned)(h->num_cu * 2)), dim3(256), rlds, st, r);
+        hipLaunchKernelGGL(m2d_topk_repair_finish<HV>, dim3((unsigned)(h->num_cu * 2)), dim3(256), rlds, st, r);
         M2D_HIP_TRY(h, hipGetLastError());
     }
-    hipLaunchKernelGGL(m2d_topk_fill_absent, dim3((unsigned)((nU + 127) / 128)), dim3(128), 0, st, final_s, final_i, nU, k,
-                       h->I);
-    M2D_HIP_TRY(h, hipGetLastError());
     h->last_kernel = BF16X3 ? "m2d_topk_grouped_bf16x3" : "m2d_topk_grouped";      // both bf16 forms report this name
     return M2D_OK;
 }
