@@ -407,8 +407,14 @@ __global__ __launch_bounds__(256) void m2d_train_grad_fused(TrainArgs p)
                             (ul < 0 || ul >= p.U) ? uid : did, b);
             continue;
         }
-        const int su = p.accumulate ? train_claim(p.map_u, p.slot_u, cnt + 0, ul, lane) : 0;
-        const int sd = p.accumulate ? train_claim(p.map_d, p.slot_d, cnt + 1, did, lane) : 0;
+        // The pair's two claims go out together (lane 0: the user's slot, lane 1: the dish's) and are looked at only after the
+        // forward pass, whose row reads do not depend on them: one round trip to memory instead of four in front of the rows.
+        const bool claimer = p.accumulate && lane < 2;
+        int32_t *const cmap = lane == 0 ? p.map_u : p.map_d;
+        const int64_t crow = lane == 0 ? ul : (int64_t)did;
+        int seen = 0;
+        if (claimer) seen = atomicCAS(&cmap[crow], -1, -2);
+        const float y = p.labels[b];
         const float *m = p.cats + (size_t)b * C;
         const float *urow = p.pm + (size_t)ul * (C + 1) * E;
         const float *drow = p.re + (size_t)did * E;
@@ -427,7 +433,23 @@ __global__ __launch_bounds__(256) void m2d_train_grad_fused(TrainArgs p)
         hi = wave_sum(hi);
         lo = wave_sum(lo);
         const float s = __fadd_rn(__fmul_rn(p.a, hi / n), __fmul_rn(p.b, lo / n));  // :79, :93, :95-96
-        const float y = p.labels[b];
+        // -1: the row was free and this lane numbers it; anything else: the number, once it is there.  Two statements, in this
+        // order, not the two arms of one `if`: a wave whose lane 0 numbers a row while its lane 1 waits for another wave's
+        // number must publish BEFORE it waits -- with the arms in the other order two such waves, each holding the row the
+        // other waits for, would spin for ever (the arms of a divergent branch run one after the other).
+        int slot = seen;
+        if (claimer && seen == -1) {
+            slot = atomicAdd(cnt + lane, 1);
+            (lane == 0 ? p.slot_u : p.slot_d)[slot] = (int32_t)crow;
+            // relaxed, agent scope: the number itself is all a waiting wave takes from this one (slot_row is read by the apply
+            // launch).  Release / acquire here cost an L2 write-back per claim and an invalidate per look -- the XCDs' L2s
+            // are not coherent with each other -- for an ordering nobody uses.
+            __hip_atomic_store(&cmap[crow], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);            // (the compiler keeps the order; the wave issues its stores before the loads below)
+        if (claimer && seen != -1)
+            while (slot < 0) slot = __hip_atomic_load(&cmap[crow], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int su = __builtin_amdgcn_readlane(slot, 0), sd = __builtin_amdgcn_readlane(slot, 1);
         const float loss_b = fmaxf(s, 0.f) - s * y + log1pf(expf(-fabsf(s)));       // :101
         const float gs = (1.0f / (1.0f + expf(-s)) - y) * invB;                     // d mean / d s_b
         const float qh = gs * p.a / n, ql = gs * p.b / n;
@@ -562,18 +584,40 @@ __global__ __launch_bounds__(256) void m2d_train_apply_fused(ApplyArgs p)
         const int W = tb.W;
         const size_t base = (size_t)row * W;
         float *g = grow >= 0 ? tb.G + (size_t)grow * W : nullptr;
+        // rows of whole, 16-B aligned float4 (every embedding size that is a multiple of 4; the caller's table may start anywhere)
+        const bool vec = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(tb.var) & 15) == 0;
         if (ok && (g || r.rule == M2D_LEARNER_ADAM)) {     // Adam decays and moves every row; the others touch rows with a gradient
-            for (int e = lane; e < W; e += 64) {
-                float v = tb.var[base + e], a = one ? tb.s0[base + e] : 0.f, b = two ? tb.s1[base + e] : 0.f;
-                apply_one(r, g ? g[e] * scale : 0.f, v, a, b);
-                fin = fmaf(v, 0.f, fin);
-                tb.var[base + e] = v;
-                if (one) tb.s0[base + e] = a;
-                if (two) tb.s1[base + e] = b;
+            if (vec) {                                      // 16 B per lane: the dense Adam pass is a stream over var / m / v
+                for (int e = lane * 4; e < W; e += 256) {
+                    v4f v = *reinterpret_cast<const v4f *>(tb.var + base + e), a = v4f(0.f), b = v4f(0.f), gg = v4f(0.f);
+                    if (one) a = *reinterpret_cast<const v4f *>(tb.s0 + base + e);
+                    if (two) b = *reinterpret_cast<const v4f *>(tb.s1 + base + e);
+                    if (g) gg = *reinterpret_cast<const v4f *>(g + e) * scale;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float vv = v[j], aa = a[j], bb = b[j];
+                        apply_one(r, gg[j], vv, aa, bb);
+                        fin = fmaf(vv, 0.f, fin);
+                        v[j] = vv; a[j] = aa; b[j] = bb;
+                    }
+                    *reinterpret_cast<v4f *>(tb.var + base + e) = v;
+                    if (one) *reinterpret_cast<v4f *>(tb.s0 + base + e) = a;
+                    if (two) *reinterpret_cast<v4f *>(tb.s1 + base + e) = b;
+                }
+            } else {
+                for (int e = lane; e < W; e += 64) {
+                    float v = tb.var[base + e], a = one ? tb.s0[base + e] : 0.f, b = two ? tb.s1[base + e] : 0.f;
+                    apply_one(r, g ? g[e] * scale : 0.f, v, a, b);
+                    fin = fmaf(v, 0.f, fin);
+                    tb.var[base + e] = v;
+                    if (one) tb.s0[base + e] = a;
+                    if (two) tb.s1[base + e] = b;
+                }
             }
         }
         if (g && (tb.map || t == 2)) {                      // release: the gradient row back to zero, the slot back to free
-            for (int e = lane; e < W; e += 64) g[e] = 0.f;
+            if (vec) { for (int e = lane * 4; e < W; e += 256) *reinterpret_cast<v4f *>(g + e) = v4f(0.f); }
+            else { for (int e = lane; e < W; e += 64) g[e] = 0.f; }
             if (tb.map && lane == 0) tb.map[row] = -1;
         }
     }

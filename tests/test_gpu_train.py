@@ -364,3 +364,34 @@ def test_the_two_forms_of_a_step_can_alternate():
     assert eng.train_steps() == len(sizes)
     for got, ref in ((eng.pm, st.PM), (eng.re, st.RE), (eng.ce, st.CE)):
         assert np.abs(got.cpu().numpy() - ref).max() <= 1e-3 * 0.01 * len(sizes)
+
+
+@pytest.mark.timeout(120)
+def test_crossing_claims_do_not_wait_for_each_other():
+    """Small batches: a pair's wave numbers the rows it is first to meet and waits for the number of a row another wave met
+    first.  With a handful of users and dishes every wave both numbers and waits, in every combination -- wave A holding
+    the user wave B waits for while B holds the dish A waits for is the case that must not hang (a wave publishes its numbers
+    before it waits for anybody's).  300 steps at the fused form's largest batch, then the tables against the restatement."""
+    import torch
+    from oracle import train_oracle as T
+    U, I, C, E, B = 5, 4, 4, 64, 1024
+    PM, RE, CE, *_ = random_case(U, I, C, E, 1, seed=5)
+    eng = _engine(PM, RE, CE)
+    eng.train_begin("sgd", 0.05)
+    st = T.TrainState(PM, RE, CE, "sgd", 0.05)
+    dev = lambda x: torch.as_tensor(x, device="cuda")
+    rng = np.random.default_rng(3)
+    for step in range(300):
+        users = rng.integers(0, U, B).astype(np.int32); items = rng.integers(0, I, B).astype(np.int32)
+        cats = rng.integers(0, 2, (B, C)).astype(np.float32); cats[cats.sum(1) == 0, 0] = 1.0
+        labels = rng.integers(0, 2, B).astype(np.float32)
+        out = eng.train_step(dev(users), dev(items), dev(cats), dev(labels))
+        if step < 3:
+            ref_loss, ref_norm = st.step(users, items, cats, labels)
+            o = out.cpu().numpy(); eng.check()
+            assert abs(o[0] - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)) and abs(o[1] - ref_norm) <= 2e-5 * max(1.0, ref_norm), step
+            if step == 2:
+                for got, ref in ((eng.pm, st.PM), (eng.re, st.RE), (eng.ce, st.CE)):
+                    assert np.abs(got.cpu().numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    torch.cuda.synchronize(); eng.check()
+    assert eng.train_steps() == 300
