@@ -365,25 +365,8 @@ __global__ __launch_bounds__(256) void m2d_train_cleanup(int32_t *map, const int
 }
 
 // ---- the fused form for small batches (see the header comment) ---------------------------------------------------------
-// A row's slot in the compact gradient buffer, claimed by the first wave that meets the row: -1 free, -2 being claimed.
-// A wave that finds -2 waits for the number; the claimer publishes it without waiting for anybody, so nobody waits long.
-__device__ __forceinline__ int train_claim(int32_t *map, int32_t *slot_row, int32_t *cnt, int64_t row, int lane)
-{
-    int s = 0;
-    if (lane == 0) {
-        const int seen = atomicCAS(&map[row], -1, -2);
-        if (seen == -1) {
-            s = atomicAdd(cnt, 1);
-            slot_row[s] = (int32_t)row;
-            __hip_atomic_store(&map[row], s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            s = seen;
-            while (s < 0) s = __hip_atomic_load(&map[row], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    return __builtin_amdgcn_readfirstlane(s);
-}
-
+// A row's slot in the compact gradient buffer is claimed by the first wave that meets the row (map entry -1 free, -2 being
+// claimed, else the slot number); a wave that finds -2 waits for the number.
 __global__ __launch_bounds__(256) void m2d_train_grad_fused(TrainArgs p)
 {
     extern __shared__ float dce_all[];                      // [4 waves][C, E] partial dCE
