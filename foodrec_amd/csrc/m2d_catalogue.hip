@@ -1241,18 +1241,26 @@ __device__ __forceinline__ void grouped_pattern_bounds(const float (&hc)[4], con
     }
 }
 
-// the same from 16 lanes that all hold hc and G: lane j works out pattern j, the bound and the mask are reduced over the 16
+// the same from 16 lanes that all hold hc and G: lane j works out pattern j (lo / hi: its own bounds), the bound is the
+// largest lo of the 16; grouped_mask_lanes: the patterns whose hi reaches a bound
 __device__ __forceinline__ void grouped_pattern_bounds_lanes(const float (&hc)[4], const float (&G)[10], const int32_t *grp, const int k,
-                                                             const float a, const float b, const int j, float &seed, uint32_t &mask)
+                                                             const float a, const float b, const int j, float &seed, float &lo, float &hi)
 {
-    float lo = -INFINITY, hi = -INFINITY;
+    lo = -INFINITY;
+    hi = -INFINITY;
     if (j >= 1) grouped_pattern_terms(hc, G, grp, j, k, a, b, lo, hi);
-    seed = fmaxf(lo, -INFINITY);                            // a NaN bound is ignored
+    lo = fmaxf(lo, -INFINITY);                              // a NaN bound is ignored
+    seed = lo;
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) seed = fmaxf(seed, __shfl_xor(seed, off, 64));
-    mask = (j >= 1 && !(hi < seed)) ? (1u << j) : 0u;      // NaN bounds keep their pattern
+}
+
+__device__ __forceinline__ uint32_t grouped_mask_lanes(const float hi, const float seed, const int j)
+{
+    uint32_t mask = (j >= 1 && !(hi < seed)) ? (1u << j) : 0u;      // NaN bounds keep their pattern
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) mask |= __shfl_xor(mask, off, 64);
+    return mask;
 }
 
 __device__ __forceinline__ float grouped_threshold_seed(const v4f *pmu, const int Sr, const float (&hc)[4], const GroupedArgs &p)
@@ -1277,14 +1285,17 @@ __device__ __forceinline__ float grouped_threshold_seed(const v4f *pmu, const in
     return seed;
 }
 
+constexpr int PLAN_PROBES = 64;                            // most rows of the user's best pattern scored for the scan-start bound
+
 // The plan of a retrieval call, one record of 8 floats per user: [0] scan-start bound, [1..4] <U_high, CE_c>, [5] the
 // relevant-pattern mask (bits), for the pipelined kernel -- which takes its users in the order m2d_plan_* sort them into
 // (by mask), so that the 256 users of a block share their relevant patterns and the block steps through those
 // patterns' tiles only.  16 lanes per user, a float4 column each.
+template <int CH>                                           // float4 columns a lane holds of a row: E <= 64 CH
 __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const float *ce, const int32_t *users, int64_t nU, int64_t U,
                                                           int64_t user_base, int E, const int32_t *grp, int k, float a, float b,
                                                           int no_alpha, float *plan, int32_t *zero_tie, unsigned long long *zero_tiles,
-                                                          int32_t *zero_hist, int nhist)
+                                                          int32_t *zero_hist, int nhist, const float *probe_rows, int probe_width, int nprobe)
 {
     const int lane = threadIdx.x & 63, j = lane & 15;
     const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
@@ -1329,9 +1340,65 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
 #pragma unroll
         for (int i = 0; i < 10; ++i) G[i] += __shfl_xor(G[i], off, 64);
     }
-    float seed;
-    uint32_t mask;
-    grouped_pattern_bounds_lanes(hc, G, grp, k, a, b, j, seed, mask);
+    float seed, lo, hi;
+    grouped_pattern_bounds_lanes(hc, G, grp, k, a, b, j, seed, lo, hi);
+    // A better bound from a few dishes: the pattern whose lower bound IS the bound (the user's best) holds its largest-norm
+    // rows first in the sorted table; the k-th largest exact score among the first 16 to 64 of them (more for larger catalogues) is a lower bound of
+    // the pattern's k-th score -- about alpha_P + 0.1 |w||r| where Cauchy-Schwarz gives alpha_P - |w||r| -- and fewer other
+    // patterns reach it (relevant patterns per user 1.9 -> 1.3 on the benchmark's tables; scripts/diag/two_phase_sim.py).
+    if (probe_rows && no_alpha != 1) {
+        const int g16 = lane & 48;                          // first lane of this user's 16
+        const unsigned long long best = __ballot(j >= 1 && lo == seed && seed > -INFINITY);
+        const int p1 = (int)((best >> g16) & 0xffffull) ? __builtin_ctz((unsigned)((best >> g16) & 0xffffull)) : 0;
+        const int nrow = p1 ? (grp[40 + p1] < nprobe ? grp[40 + p1] : nprobe) : 0;      // >= k: the bound was finite
+        const float alpha1 = __shfl(0.5f * (lo + hi), g16 + p1, 64);                          // (lo + hi) / 2 = alpha_P
+        const float reach1 = __shfl(0.5f * (hi - lo), g16 + p1, 64);                          // |w_P| max|r| + slack
+        // w_P1: this lane's float4 columns q = j, j + 16, ... (embedding sizes up to 256)
+        v4f wv[CH];
+        const float beta = b / (float)__builtin_popcount(p1 | (p1 == 0));
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            wv[i] = v4f{0.f, 0.f, 0.f, 0.f};
+            const int q = j + 16 * i;
+            if (q < E4) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if ((p1 >> c) & 1) wv[i] += pmu[(c + 1) * E4 + q];
+                wv[i] *= beta;
+            }
+        }
+        float slot = -INFINITY;                             // the probes' running top-16, entry j in lane j (k <= 16)
+        const v4f *rows = reinterpret_cast<const v4f *>(probe_rows) + (size_t)grp[p1] * (probe_width >> 2);
+        for (int i0 = 0; i0 < nprobe; i0 += 8) {            // uniform trip count (nprobe: a multiple of 8): the DPP rows see a full EXEC
+            float part[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {                   // eight rows in flight
+                const bool live = i0 + x < nrow;
+                part[x] = 0.f;
+#pragma unroll
+                for (int c4 = 0; c4 < CH; ++c4) {
+                    const int q = j + 16 * c4;
+                    if (live && q < E4) {
+                        const v4f r = rows[(size_t)(i0 + x) * (probe_width >> 2) + q];
+                        part[x] = fmaf(r.x, wv[c4].x, fmaf(r.y, wv[c4].y, fmaf(r.z, wv[c4].z, fmaf(r.w, wv[c4].w, part[x]))));
+                    }
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                float sc = alpha1 + row16_sum(part[x]);
+                sc = i0 + x < nrow ? fmaxf(sc, -INFINITY) : -INFINITY;
+                const float left = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, INFINITY),
+                                                      __builtin_bit_cast(int, slot), 0x111, 0xf, 0xf, false));
+                slot = sc > left ? left : (sc > slot ? sc : slot);
+            }
+        }
+        const float kth = __shfl(slot, g16 + k - 1, 64);
+        // the scan's own arithmetic (split bf16, or f32 in another order) may put these dishes a little lower: the same slack as the bounds'
+        const float probed = kth - (1e-4f * reach1 + 1e-6f * fabsf(alpha1) + 1e-30f);
+        if (p1 && nrow >= k && probed > seed) seed = probed;
+    }
+    uint32_t mask = grouped_mask_lanes(hi, seed, j);
     if (no_alpha == 1) { seed = -INFINITY; mask = 0xfffeu; }     // ingredient rows: the score has no alpha_P term to bound it with
     if (no_alpha == 2) mask = 0xfffeu;                        // option topk_prune = 2: the bound, but every pattern (A/B)
     if (no_alpha == 4) seed = -INFINITY;                      // option topk_prune = 4: the patterns, but no bound (A/B)
@@ -2727,9 +2794,17 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         unsigned long long *counter = reinterpret_cast<unsigned long long *>(hist + PLAN_KEYS);
         const bool prune = h->opt_topk_prune != 0;
         const bool sorted = prune && !HV && nU > 32 * WAVES && h->opt_topk_prune != 3;      // 3: pruning without the sort (A/B)
-        hipLaunchKernelGGL(m2d_topk_user_plan, dim3((unsigned)((nU * 16 + 255) / 256)), dim3(256), 0, st, h->pm, h->ce, users, nU, h->U,
-                           h->user_base, h->E, a.grp, (int)k, h->a, h->b, (HV || !prune) ? 1 : (h->opt_topk_prune == 2 ? 2 : (h->opt_topk_prune == 4 ? 4 : 0)), plan,
-                           tie_list, counter, sorted ? hist : nullptr, PLAN_KEYS);
+        {
+            const int pmode = (HV || !prune) ? 1 : (h->opt_topk_prune == 2 ? 2 : (h->opt_topk_prune == 4 ? 4 : 0));
+            const float *probes = (HV || !prune || h->opt_topk_prune == 6) ? nullptr : h->grp_rs;      // 6: Cauchy-Schwarz bounds only (A/B)
+            const dim3 pgrid((unsigned)((nU * 16 + 255) / 256));
+            // probe rows per user: each costs a row read per user (16: +18 us for 65 536 users) and buys a tighter bound -- 16 rows
+            // at 100 k dishes (0.71 ms; 32: 0.73), 32 at 1 M (3.83 ms; 16: 4.02)
+            const int nprobe = a.tiles < 8192 ? 16 : (a.tiles < 65536 ? 32 : PLAN_PROBES);
+            auto pk = h->E <= 64 ? m2d_topk_user_plan<1> : (h->E <= 128 ? m2d_topk_user_plan<2> : m2d_topk_user_plan<4>);
+            hipLaunchKernelGGL(pk, pgrid, dim3(256), 0, st, h->pm, h->ce, users, nU, h->U, h->user_base, h->E, a.grp, (int)k, h->a, h->b, pmode,
+                               plan, tie_list, counter, sorted ? hist : nullptr, PLAN_KEYS, probes, h->grp_ew, nprobe);
+        }
         a.plan = plan;
         if (sorted) {
             const size_t tab = (size_t)PLAN_KEYS * sizeof(int32_t);

@@ -21,7 +21,7 @@ if os.environ.get("PROBE_F32"):
 res = {}
 import itertools
 VARS = [int(v) for v in os.environ.get("PROBE_VARIANTS", "101 116").split()]
-for prune, var in [(0, 0), (5, 0), (1, 0)] + [(1, v) for v in VARS]:      # 5: pruned, grid launch order; 1: longest item first
+for prune, var in [(0, 0), (6, 0), (1, 0)] + [(1, v) for v in VARS]:      # 6: Cauchy-Schwarz bounds only; 1: + probe rows      # 5: pruned, grid launch order; 1: longest item first
     eng.set_option("topk_prune", prune); eng.set_option("variant", var)
     for _ in range(5):
         s1, i1 = eng.topk_users(users, 10)
@@ -36,4 +36,4 @@ for prune, var in [(0, 0), (5, 0), (1, 0)] + [(1, v) for v in VARS]:      # 5: p
     print("prune=%d  %.3f ms  %.2f T pairs/s  tiles scanned %d of %d (%.3f)  repaired %d  kernel %s" %
           (prune, ms, n * I / ms / 1e9, eng.get_option("topk_tiles_scanned"), eng.get_option("topk_tiles_full"),
            eng.get_option("topk_tiles_scanned") / max(1, eng.get_option("topk_tiles_full")), eng.get_option("topk_repaired"), eng.last_kernel()))
-print("lists identical with and without pruning:", bool(torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[5][1])))
+print("lists identical with and without pruning:", bool(torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[6][1])))
