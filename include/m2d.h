@@ -252,7 +252,8 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
  * tiles of the mask patterns that can reach its top-k only (with 0/1 masks every dish of pattern P scores within
  * alpha_P[u] +- |w_P[u]| max|RE[d]|; users are sorted by their pattern mask so that a block's users share patterns, and a
  * launch's (user block, dish range) items are handed out longest first); the lists are the same bit for bit with 0 (every
- * tile).  2 / 3 / 4 / 5 are A/B forms of the same: the bound only, no sort, the patterns only, the grid's launch order.
+ * tile).  2 / 3 / 4 / 5 / 6 are A/B forms of the same: the bound only, no sort, the patterns only, the grid's launch order,
+ * the bound without its probe rows (the k-th largest exact score among the first rows of the user's best pattern).
  * m2d_score_pairs* (the reference path) is always exact float32.  Unknown names: M2D_ERR_INVALID_ARG.
  * m2d_get_option also answers three diagnostics of the last m2d_topk_users call on the pattern-grouped kernels (they
  * synchronise the device): "topk_repaired" (users re-ranked in id order because their k-th score was tied),
