@@ -106,3 +106,33 @@ for name, tl in orders.items():
     for rule in ("max", "mid", "max+seed", "mid+seed"):
         f, ins = simulate(tl, rule)
         print("%-40s thr=%-5s tiles %5d  candidate tiles %.3f  insertions per lane %.1f" % (name, rule, len(tl), f, ins))
+
+# One pattern only (what a block of a pruned launch steps through: its users' best pattern), 32 users whose best pattern it
+# is, by threshold rule -- "exact" is the k-th largest of the two lanes' lists together, max_i min(a_i, b_{k-i}).
+if len(sys.argv) > 3:
+    q = int(sys.argv[3])
+    pool = (rng.standard_normal((4000, C + 1, E)) * s).astype(np.float32)
+    hcp = pool[:, 0] @ CE.T
+    aPp = np.full((4000, 16), -np.inf, np.float32)
+    for qq in range(1, 16):
+        cs = [c for c in range(C) if (qq >> c) & 1]
+        aPp[:, qq] = a * hcp[:, cs].sum(1) / len(cs)
+    pick = np.flatnonzero(aPp[:, 1:].argmax(1) + 1 == q)[:NU]
+    PM = pool[pick]
+    hc = PM[:, 0] @ CE.T
+    alpha = a * (hc @ cats.T) / n
+    low = np.einsum("uce,ie,ic->ui", PM[:, 1:], RE, cats) / n
+    score = alpha + b * low
+    cs = [c for c in range(C) if (q >> c) & 1]
+    wq = b * PM[:, 1:][:, cs].sum(1) / len(cs)
+    aq = a * hc[:, cs].sum(1) / len(cs)
+    sub = dish[pat == q]
+    tl = tiles_for(pat[pat == q] * 0, [bucket[pat == q], dish[pat == q]])
+    tl = np.where(tl >= 0, sub[np.maximum(tl, 0)], -1)
+    # scan-start bound: the k-th largest exact score among the pattern's first 16 rows (the plan's probe rows)
+    first = tl.reshape(-1)[:16]
+    seed = np.sort(score[:, first], axis=1)[:, -k].astype(np.float32)
+    print("pattern %d (%d dishes, %d tiles), %d users whose best pattern it is" % (q, len(sub), len(tl), len(pick)))
+    for rule in ("own+seed", "max+seed", "mid+seed", "exact+seed"):
+        f, ins = simulate(tl, rule)
+        print("  thr=%-10s candidate tiles %.3f  insertions per lane %.1f" % (rule, f, ins))
