@@ -2728,17 +2728,26 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     a.plan = nullptr; a.order = nullptr; a.tiles_scanned = nullptr; a.items = nullptr;
     const int64_t ublocks = (nU + 32 * WAVES - 1) / (32 * WAVES);
     int nsplit = pick_splits(h, ublocks, a.tiles, 2 * TPS, 512);
-    if ((!BF16X3 || (!HV && h->opt_topk_form != 1)) && h->opt_topk_prune != 0 && h->opt_variant < 100 && ublocks >= 6) {
+    if ((!BF16X3 || (!HV && h->opt_topk_form != 1)) && h->opt_topk_prune != 0 && h->opt_variant < 100) {
         // Pattern pruning makes the blocks unequal -- a block of users with one relevant pattern steps through a fifteenth of
         // the catalogue, one whose users need most patterns through all of it -- so a launch with many user blocks is cut into
         // dish ranges and the (block, range) items are handed out longest first (m2d_plan_items_*).  The longest item bounds
         // the launch, every piece starts its lists from the scan-start bound again (more pieces re-insert more): measured
         // best at 100 k dishes, E = 64 -- 16 / 32 user blocks: 32 ranges (0.30 / 0.33 ms; 8 ranges 0.56), 64 blocks: 16
         // (0.42 ms; 8: 0.59, 32: 0.49), 128 blocks: 12 (0.58 ms; 8: 0.62, 24: 0.68), 256 blocks: 8 (0.85 ms; 16: 1.0).
-        // 8 blocks: 64 (0.21 ms; 32: 0.25).  Fewer than 6 blocks: the split count of the unpruned launch.
-        nsplit = ublocks >= 192 ? 8 : (ublocks >= 96 ? 12 : (ublocks >= 48 ? 16 : (ublocks >= 24 ? 32 : (int)(512 / ublocks))));
-        const int64_t most = a.tiles / (4 * TPS);            // at least four stages per range
-        if (most < nsplit) nsplit = most > 1 ? (int)most : 1;
+        // 8 blocks: 64 (0.21 ms; 32: 0.25).  A handful of blocks (serving): most ranges hold no tile of the users' patterns and
+        // return at once, the others are short -- 1 user: 512 ranges 0.056 ms (192, the unpruned launch's count: 0.066), 32
+        // users 0.068 (0.091), 256 users: 256 ranges 0.101 (0.113), 1 024 users: 128 ranges 0.167 (0.185).
+        if (ublocks >= 6) {
+            nsplit = ublocks >= 192 ? 8 : (ublocks >= 96 ? 12 : (ublocks >= 48 ? 16 : (ublocks >= 24 ? 32 : (int)(512 / ublocks))));
+            const int64_t most = a.tiles / (4 * TPS);        // at least four stages per range
+            if (most < nsplit) nsplit = most > 1 ? (int)most : 1;
+        } else {
+            nsplit = ublocks == 1 ? (nU <= 64 ? 512 : 256) : (int)(512 / ublocks);
+            const int64_t most = a.tiles / 4;                // at least four tiles per range
+            if (most < nsplit) nsplit = most > 1 ? (int)most : 1;
+            if (nsplit > 64) nsplit &= ~63;                  // two-pass merge: whole groups of 64
+        }
     }
     a.nsplit = nsplit;
     // tie values (floats): per (user, split), per (user, group of 64 splits) when the merge takes two passes, per user;

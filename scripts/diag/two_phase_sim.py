@@ -81,3 +81,23 @@ for nprobe in (16, 32, 64, 128, 256):
     relp[:, 0] = False
     t, _ = scanned(relp)
     print("probe %3d dishes: %.3f of all tiles, %.2f patterns per user" % (nprobe, t / full, relp.sum(1).mean()))
+
+# Sort keys for the one-phase plan with 16 probe rows: the mask's value (now) against (best pattern, mask)
+thr0 = seed.copy()
+for q in range(1, 16):
+    us = np.flatnonzero(p1 == q)
+    if len(us) == 0: continue
+    d = np.flatnonzero(pat == q)
+    d = d[np.argsort(-norm[d])[:16]]
+    sc = aP[us, q][:, None] + W[q][us] @ RE[d].T
+    thr0[us] = np.maximum(seed[us], np.sort(sc, axis=1)[:, -k] * (1 - 1e-6) - 1e-6)
+relp = hi >= thr0[:, None]
+relp[:, 0] = False
+maskv = (relp * (1 << np.arange(16))[None, :]).sum(1)
+def scanned_key(key):
+    order = np.argsort(key, kind="stable")
+    return sum(tiles[relp[order[b0:b0 + 256]].any(0)].sum() for b0 in range(0, NU, 256))
+npat = relp.sum(1)
+for name, key in (("mask value", maskv), ("(best pattern, mask)", p1 * 65536 + maskv), ("(patterns, mask)", npat * 65536 + maskv),
+                  ("(best pattern, patterns, mask)", (p1 * 16 + npat) * 65536 + maskv)):
+    print("sort by %-32s %.4f of all tiles" % (name, scanned_key(key) / full))
