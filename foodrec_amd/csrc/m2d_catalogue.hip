@@ -2746,8 +2746,8 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
             nsplit = ublocks == 1 ? (nU <= 64 ? 512 : 256) : (int)(512 / ublocks);
             const int64_t most = a.tiles / 4;                // at least four tiles per range
             if (most < nsplit) nsplit = most > 1 ? (int)most : 1;
-            if (nsplit > 64) nsplit &= ~63;                  // two-pass merge: whole groups of 64
         }
+        if (nsplit > 64) nsplit &= ~63;                      // two-pass merge: whole groups of 64 (6 or 7 blocks: 85 / 73 -> 64)
     }
     a.nsplit = nsplit;
     // tie values (floats): per (user, split), per (user, group of 64 splits) when the merge takes two passes, per user;

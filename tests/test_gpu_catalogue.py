@@ -432,3 +432,24 @@ def test_launch_order_and_the_exact_kernels_plan(E, x3):
         assert np.array_equal(out[prune][1], out[0][1]) and np.array_equal(out[prune][0], out[0][0], equal_nan=True), prune
     assert out[0][2] >= out[0][3] and out[1][2] == out[5][2] and out[1][2] < 0.6 * out[0][2], [o[2:] for o in out.values()]
     _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:80], k, dup=40)
+
+
+@pytest.mark.parametrize("E,x3,nU", [(64, 1, 1723), (32, 0, 1400), (64, 1, 1100)])
+def test_more_than_64_dish_ranges_come_in_whole_groups(E, x3, nU):
+    """Six or seven user blocks over a catalogue large enough for 512 / blocks = 85 / 73 dish ranges: the two-pass merge of
+    more than 64 partial lists takes whole groups of 64, so the launch runs 64 (a randomized soak found 73 ranges shifting
+    every user's list by one row); five blocks take 102 -> 64 by the serving rule.  Same lists as the plain scan."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    U, I, k = 3000, 27000, 10
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=E + nU, n_nan=3, dup=20)
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    eng.set_option("topk_bf16x3", x3)
+    users = torch.as_tensor(np.random.default_rng(nU).permutation(U)[:nU].astype(np.int32), device="cuda")
+    eng.set_option("topk_prune", 0); eng.set_option("variant", 101)
+    s0, i0 = eng.topk_users(users, k); eng.check()
+    eng.set_option("topk_prune", 1); eng.set_option("variant", 0)
+    s1, i1 = eng.topk_users(users, k); eng.check()
+    assert torch.equal(i0, i1) and torch.equal(s0.nan_to_num(nan=-7.0), s1.nan_to_num(nan=-7.0))
+    _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:40], k, dup=20)
