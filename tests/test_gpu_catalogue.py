@@ -434,14 +434,15 @@ def test_launch_order_and_the_exact_kernels_plan(E, x3):
     _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:80], k, dup=40)
 
 
-@pytest.mark.parametrize("E,x3,nU", [(64, 1, 1723), (32, 0, 1400), (64, 1, 1100)])
-def test_more_than_64_dish_ranges_come_in_whole_groups(E, x3, nU):
+@pytest.mark.parametrize("E,x3,nU,I", [(200, 0, 1723, 27000), (200, 0, 1400, 27000), (128, 1, 1723, 40000), (64, 1, 1100, 27000)])
+def test_more_than_64_dish_ranges_come_in_whole_groups(E, x3, nU, I):
     """Six or seven user blocks over a catalogue large enough for 512 / blocks = 85 / 73 dish ranges: the two-pass merge of
     more than 64 partial lists takes whole groups of 64, so the launch runs 64 (a randomized soak found 73 ranges shifting
-    every user's list by one row); five blocks take 102 -> 64 by the serving rule.  Same lists as the plain scan."""
+    every user's list by one row); five blocks take 102 -> 64 by the serving rule.  (Stages of 2 / 4 tiles at E = 200 / 128
+    leave room for that many ranges of at least four stages in these catalogues.)  Same lists as the plain scan."""
     import torch
     from foodrec_amd import ScoringEngine
-    U, I, k = 3000, 27000, 10
+    U, k = 3000, 10
     PM, RE, CE, cats = _tables(U, I, 4, E, seed=E + nU, n_nan=3, dup=20)
     eng = ScoringEngine(PM, RE, CE)
     eng.set_dish_categories(cats)
