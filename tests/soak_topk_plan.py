@@ -20,6 +20,9 @@ for it in range(n):
     C = 4
     E = int(rng.choice([64, 64, 128, 32, 200, 16]))
     U = int(rng.integers(300, 40000)); I = int(rng.integers(200, 30000)); k = int(rng.choice([10, 10, 1, 5, 16]))
+    serving = it % 3 == 2                                                 # a few users over a larger catalogue: many dish ranges
+    if serving:
+        U = int(rng.integers(10, 4000)); I = int(rng.integers(20000, 150000))
     s = 1.0 / np.sqrt(E)
     PM = (rng.standard_normal((U, C + 1, E)) * s).astype(np.float32)
     RE = (rng.standard_normal((I, E)) * s).astype(np.float32)
@@ -40,7 +43,7 @@ for it in range(n):
     x3 = int(rng.integers(0, 2)) if E in (64, 128) else 0
     eng = ScoringEngine(PM.astype(np.float32), RE.astype(np.float32), CE.astype(np.float32)); eng.set_dish_categories(cats)
     eng.set_option("topk_bf16x3", x3)
-    nU = int(rng.integers(257, min(U, 30000) + 1))
+    nU = int(rng.integers(1, min(U, 2100) + 1)) if serving else int(rng.integers(257, min(U, 30000) + 1))
     users = rng.integers(0, U, nU).astype(np.int32)
     du = torch.as_tensor(users, device="cuda")
     eng.set_option("topk_prune", 0); eng.set_option("variant", 101)
