@@ -2818,8 +2818,8 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         if (sorted) {
             const size_t tab = (size_t)PLAN_KEYS * sizeof(int32_t);
             const unsigned sblocks = (unsigned)((nU + 1023) / 1024 < 4 * h->num_cu ? (nU + 1023) / 1024 : 4 * h->num_cu);
-            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_plan_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab));
-            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_plan_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tab));
+            M2D_HIP_TRY(h, m2d_lds_limit((const void *)m2d_plan_hist, (int)tab));
+            M2D_HIP_TRY(h, m2d_lds_limit((const void *)m2d_plan_scatter, (int)tab));
             hipLaunchKernelGGL(m2d_plan_hist, dim3(sblocks), dim3(1024), tab, st, plan, nU, hist);
             hipLaunchKernelGGL(m2d_plan_scan, dim3(1), dim3(1024), 0, st, hist);
             hipLaunchKernelGGL(m2d_plan_scatter, dim3(sblocks), dim3(1024), tab, st, plan, nU, hist, order);
@@ -2841,21 +2841,21 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     if constexpr (BF16X3) {
         if constexpr (HV) {
             auto kern = m2d_topk_grouped_bf16_pipe2<E, KR, 1, true>;
-            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            M2D_HIP_TRY(h, m2d_lds_limit((const void *)kern, (int)lds));
             hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);
         } else if (!pipe) {
             auto kern = m2d_topk_grouped_bf16<E, WAVES, KR>;
-            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            M2D_HIP_TRY(h, m2d_lds_limit((const void *)kern, (int)lds));
             hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, a);
         } else {
             static_assert(WAVES == 8, "the pipelined kernel is written for 256 users per block");
             auto kern = m2d_topk_grouped_bf16_pipe2<E, KR, 1>;
-            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            M2D_HIP_TRY(h, m2d_lds_limit((const void *)kern, (int)lds));
             hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);
         }
     } else {
         auto kern = m2d_topk_grouped<E8, WAVES, KR, PAD>;
-        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        M2D_HIP_TRY(h, m2d_lds_limit((const void *)kern, (int)lds));
         hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, a);
     }
     M2D_HIP_TRY(h, hipGetLastError());
@@ -2874,16 +2874,16 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         const int ub = (!HV && h->E <= 128) ? 4 : 2;                  // listed users per pass of the repair scan (LDS: 21 E + 128 k floats each)
         const size_t slds = (size_t)ub * ((size_t)(h->C + 1 + 16) * h->E + (size_t)2 * 64 * k) * sizeof(float);
         const size_t rlds = ((size_t)(h->C + 1 + 16) * h->E + (size_t)2 * 16 * k) * sizeof(float);
-        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_topk_repair_finish<HV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+        M2D_HIP_TRY(h, m2d_lds_limit((const void *)m2d_topk_repair_finish<HV>, (int)rlds));
         hipLaunchKernelGGL(m2d_topk_tie_compact, dim3((unsigned)((nU + 255) / 256)), dim3(256), 0, st, tie_final, nU, tie_list, final_s, final_i,
                            (int)k, h->I);
         if (ub == 4) {
             auto rk = m2d_topk_repair_scan<4, HV>;
-            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+            M2D_HIP_TRY(h, m2d_lds_limit((const void *)rk, (int)slds));
             hipLaunchKernelGGL(rk, dim3(REPAIR_SPLITS, 8), dim3(1024), slds, st, r);
         } else {
             auto rk = m2d_topk_repair_scan<2, HV>;
-            M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)rk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+            M2D_HIP_TRY(h, m2d_lds_limit((const void *)rk, (int)slds));
             hipLaunchKernelGGL(rk, dim3(REPAIR_SPLITS, 8), dim3(1024), slds, st, r);
         }
         hipLaunchKernelGGL(m2d_topk_repair_finish<HV>, dim3((unsigned)(h->num_cu * 2)), dim3(256), rlds, st, r);
@@ -2931,7 +2931,7 @@ int launch_mfma(m2d_engine *h, TopkArgs &a, float *final_s, int32_t *final_i, hi
         a.out_ids = final_i;
     }
     auto kern = m2d_topk_mfma<NB, WAVES, KR>;
-    M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    M2D_HIP_TRY(h, m2d_lds_limit((const void *)kern, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(WAVES * 64), lds, st, a);
     M2D_HIP_TRY(h, hipGetLastError());
     if (nsplit > 1) {

@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
+#include <unordered_map>
 
 #include "../../include/m2d.h"
 
@@ -128,6 +130,20 @@ struct m2d_engine {
             return M2D_ERR_HIP;                                                                \
         }                                                                                      \
     } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and size: a retrieval call makes six such calls, each a
+// trip into the runtime, for a value that does not change (8 us of a 50 us host-side call)
+static inline hipError_t m2d_lds_limit(const void *fn, int bytes)
+{
+    static std::mutex mu;
+    static std::unordered_map<const void *, int> seen;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = seen.find(fn);
+    if (it != seen.end() && it->second >= bytes) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) seen[fn] = bytes;
+    return e;
+}
 
 // ---- device helpers shared by the LDS-DMA kernels (m2d_catalogue.hip, m2d_mlp.hip) ----
 // vmcnt(0) twice over: the builtin is an s_waitcnt the compiler's own counter model sees (so it stops assuming that

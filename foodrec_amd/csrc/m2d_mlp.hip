@@ -1133,7 +1133,7 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
         const unsigned grid = (unsigned)(tiles_max < h->num_cu ? tiles_max : h->num_cu);
 #define M2D_MLP_PC_CASE(N)                                                                                  \
     if (kch == N) {                                                                                         \
-        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_mlp_pc<N>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+        M2D_HIP_TRY(h, m2d_lds_limit((const void *)m2d_mlp_pc<N>, \
                                            PC_LDS_BYTES));                                                  \
         hipLaunchKernelGGL((m2d_mlp_pc<N>), dim3(grid), dim3(512), PC_LDS_BYTES, stream, a);                \
     }
@@ -1217,7 +1217,7 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
         }
         int64_t blocks = (B + 3) / 4;
         if (blocks > (int64_t)h->num_cu * 4) blocks = (int64_t)h->num_cu * 4;
-        M2D_HIP_TRY(h, hipFuncSetAttribute((const void *)m2d_mlp_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        M2D_HIP_TRY(h, m2d_lds_limit((const void *)m2d_mlp_generic, (int)lds));
         hipLaunchKernelGGL(m2d_mlp_generic, dim3((unsigned)blocks), dim3(256), lds, stream, a);
         h->last_kernel = "m2d_mlp_generic";
     }
