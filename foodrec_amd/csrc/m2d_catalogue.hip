@@ -492,9 +492,35 @@ __global__ __launch_bounds__(256) void m2d_topk_generic(TopkArgs p, int K)
 // entries from ONE thread through a scratch-memory pointer array: ~0.2 ms for a single user with 64 splits, most
 // of that call's latency.)  Splits cover increasing dish ranges, so on equal scores the lower split (= lower lane)
 // wins, which keeps ties in ascending-id order.
+// (used by the kernels that finish a list: see m2d_topk_fill_absent below)
+__device__ __forceinline__ void fill_absent_user(float *s, int32_t *id, const int k, const int64_t I)
+{
+    int n = 0;
+    while (n < k && id[n] >= 0) ++n;
+    // bit-equal scores inside the list: ascending dish id, as heapq.nlargest leaves them (evaluate.py:63); the
+    // pattern-grouped kernels deliver them in scan order
+    for (int q = 1; q < n; ++q) {
+        for (int r = q; r > 0 && s[r - 1] == s[r] && id[r - 1] > id[r]; --r) {
+            const int32_t t = id[r - 1];
+            id[r - 1] = id[r];
+            id[r] = t;
+        }
+    }
+    for (int64_t d = 0; n < k && d < I; ++d) {
+        bool present = false;
+        for (int q = 0; q < n; ++q) present = present || (id[q] == (int32_t)d);
+        if (!present) {
+            id[n] = (int32_t)d;
+            s[n] = __builtin_nanf("");
+            ++n;
+        }
+    }
+}
+
 template <int LPU>
 __global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k,
-                                                             float *out_scores, int32_t *out_ids, const float *tie_in, float *tie_out)
+                                                             float *out_scores, int32_t *out_ids, const float *tie_in, float *tie_out,
+                                                             int32_t *tie_list, int64_t I)
 {
     const int lane = threadIdx.x & 63, w = lane & (LPU - 1);
     const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPU;
@@ -540,37 +566,21 @@ __global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, co
 #pragma unroll
         for (int off = LPU / 2; off >= 1; off >>= 1) tv |= __shfl_xor(tv, off, 64);
         const bool any = tv != 0;
-        if (u < nU && w == 0) tie_out[u] = any ? last : __builtin_nanf("");
+        if (u < nU && w == 0) {
+            tie_out[u] = any ? last : __builtin_nanf("");
+            // the final pass of a pattern-grouped call also does m2d_topk_tie_compact's work: a tied user joins the repair's
+            // list, everybody else's list is finished here (this lane wrote it: its own stores, in program order)
+            if (tie_list) {
+                if (any) tie_list[1 + atomicAdd(&tie_list[0], 1)] = (int32_t)u;
+                else fill_absent_user(out_scores + u * k, out_ids + u * k, k, I);
+            }
+        }
     }
 }
 
 // Users with fewer than k ranked dishes (every finite-scored dish is already in their list, the rest of the
 // catalogue scored NaN -- an empty category mask, Model_Recommender.py:79 -- or -inf): append the dishes not
 // in the list in ascending id with a NaN score, which is where heapq.nlargest-style "NaN last" puts them.
-__device__ __forceinline__ void fill_absent_user(float *s, int32_t *id, const int k, const int64_t I)
-{
-    int n = 0;
-    while (n < k && id[n] >= 0) ++n;
-    // bit-equal scores inside the list: ascending dish id, as heapq.nlargest leaves them (evaluate.py:63); the
-    // pattern-grouped kernels deliver them in scan order
-    for (int q = 1; q < n; ++q) {
-        for (int r = q; r > 0 && s[r - 1] == s[r] && id[r - 1] > id[r]; --r) {
-            const int32_t t = id[r - 1];
-            id[r - 1] = id[r];
-            id[r] = t;
-        }
-    }
-    for (int64_t d = 0; n < k && d < I; ++d) {
-        bool present = false;
-        for (int q = 0; q < n; ++q) present = present || (id[q] == (int32_t)d);
-        if (!present) {
-            id[n] = (int32_t)d;
-            s[n] = __builtin_nanf("");
-            ++n;
-        }
-    }
-}
-
 __global__ void m2d_topk_fill_absent(float *scores, int32_t *ids, int64_t nU, int k, int64_t I)
 {
     const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2652,12 +2662,13 @@ int ensure_grouped(m2d_engine *h, hipStream_t st)
 }
 
 void m2d_launch_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k, float *out_s, int32_t *out_i,
-                             hipStream_t st, const float *tie_in = nullptr, float *tie_out = nullptr)
+                             hipStream_t st, const float *tie_in = nullptr, float *tie_out = nullptr, int32_t *tie_list = nullptr,
+                             int64_t I = 0)
 {
     int lpu = 1;
     while (lpu < nsplit) lpu <<= 1;
     const unsigned grid = (unsigned)((nU * lpu + 255) / 256);
-#define M2D_MERGE(L) if (lpu == L) hipLaunchKernelGGL(m2d_topk_merge_splits<L>, dim3(grid), dim3(256), 0, st, ps, pi, nU, nsplit, k, out_s, out_i, tie_in, tie_out);
+#define M2D_MERGE(L) if (lpu == L) hipLaunchKernelGGL(m2d_topk_merge_splits<L>, dim3(grid), dim3(256), 0, st, ps, pi, nU, nsplit, k, out_s, out_i, tie_in, tie_out, tie_list, I);
     M2D_MERGE(1) M2D_MERGE(2) M2D_MERGE(4) M2D_MERGE(8) M2D_MERGE(16) M2D_MERGE(32) M2D_MERGE(64)
 #undef M2D_MERGE
 }
@@ -2668,16 +2679,16 @@ void m2d_launch_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int
 // lower-split-wins tie rule carries through both passes.
 // tie: [nU * nsplit] values of the splits, then room for the nU * (nsplit / 64) of the first pass, then the nU final ones
 void m2d_launch_merge_splits2(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k, float *tmp_s, int32_t *tmp_i,
-                              float *out_s, int32_t *out_i, hipStream_t st, float *tie, float *tie_final)
+                              float *out_s, int32_t *out_i, hipStream_t st, float *tie, float *tie_final, int32_t *tie_list, int64_t I)
 {
     if (nsplit <= 64) {
-        m2d_launch_merge_splits(ps, pi, nU, nsplit, k, out_s, out_i, st, tie, tie_final);
+        m2d_launch_merge_splits(ps, pi, nU, nsplit, k, out_s, out_i, st, tie, tie_final, tie_list, I);
         return;
     }
     const int G = nsplit / 64;
     float *tie_mid = tie + (size_t)nU * nsplit;
     m2d_launch_merge_splits(ps, pi, nU * G, 64, k, tmp_s, tmp_i, st, tie, tie_mid);      // a "user" of this pass is (user, group)
-    m2d_launch_merge_splits(tmp_s, tmp_i, nU, G, k, out_s, out_i, st, tie_mid, tie_final);
+    m2d_launch_merge_splits(tmp_s, tmp_i, nU, G, k, out_s, out_i, st, tie_mid, tie_final, tie_list, I);
 }
 
 // shared tail of every MFMA retrieval launch: dish-range splits -> partial lists in scratch.  The grouped kernels run
@@ -2860,7 +2871,8 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     }
     M2D_HIP_TRY(h, hipGetLastError());
     if (nsplit > 1) {
-        m2d_launch_merge_splits2(a.out_scores, a.out_ids, nU, nsplit, k, tmp_s, tmp_i, final_s, final_i, st, h->topk_flags, tie_final);
+        m2d_launch_merge_splits2(a.out_scores, a.out_ids, nU, nsplit, k, tmp_s, tmp_i, final_s, final_i, st, h->topk_flags, tie_final, tie_list,
+                                 h->I);
         M2D_HIP_TRY(h, hipGetLastError());
     }
     {   // users whose final k-th score is tied with a score left out: re-ranked in dish-id order (none is the common case)
@@ -2875,8 +2887,9 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         const size_t slds = (size_t)ub * ((size_t)(h->C + 1 + 16) * h->E + (size_t)2 * 64 * k) * sizeof(float);
         const size_t rlds = ((size_t)(h->C + 1 + 16) * h->E + (size_t)2 * 16 * k) * sizeof(float);
         M2D_HIP_TRY(h, m2d_lds_limit((const void *)m2d_topk_repair_finish<HV>, (int)rlds));
-        hipLaunchKernelGGL(m2d_topk_tie_compact, dim3((unsigned)((nU + 255) / 256)), dim3(256), 0, st, tie_final, nU, tie_list, final_s, final_i,
-                           (int)k, h->I);
+        if (nsplit == 1)                                     // (with dish ranges the last merge pass has listed the tied users)
+            hipLaunchKernelGGL(m2d_topk_tie_compact, dim3((unsigned)((nU + 255) / 256)), dim3(256), 0, st, tie_final, nU, tie_list, final_s,
+                               final_i, (int)k, h->I);
         if (ub == 4) {
             auto rk = m2d_topk_repair_scan<4, HV>;
             M2D_HIP_TRY(h, m2d_lds_limit((const void *)rk, (int)slds));
