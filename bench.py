@@ -318,7 +318,7 @@ def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10):
                           "frac_if_every_tile_were_scanned": 3 * 2.0 * E * n_users * I / ms / 1e9 / 2500.0,
                           "dtype": "split bf16 (x = hi + lo, 3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
                           "note": "pipelined kernel; `frac` prices the flops EXECUTED: users are sorted by the mask patterns that "
-                                  "can reach their top-k and a block steps through those patterns' tiles only (rigorous bounds; "
+                                  "can reach their top-k and a block steps through those patterns' tiles only (Cauchy-Schwarz bounds widened by the f32 / split-bf16 rounding of the sums of absolute terms; "
                                   "DESIGN.md 4.4), so most (user, dish) pairs are decided without being multiplied -- pairs_per_s "
                                   "counts every pair of the catalogue"} if x3 else
                          {"bound": "mfma", "achieved": flops / ms / 1e9, "peak": 157.3, "unit": "TFLOP/s",

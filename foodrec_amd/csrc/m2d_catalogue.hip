@@ -1204,65 +1204,96 @@ struct GroupedArgs {
 // puts k scores at or above that bound, and the user's final k-th score cannot be below the largest such bound.  The
 // model blends 0.99 high level + 0.01 low level (Model_Recommender.py:95-96), so alpha_P dominates: for most users the
 // bound of their best pattern is above every score of the other fourteen, and the scan inserts half as often (110 -> 60
-// insertions per lane at 100 k dishes, scripts/diag/topk_scan_sim.py).  |w_P|^2 comes from the 4 x 4 Gram matrix of the
-// user's low-level rows; the margin covers the kernels' rounding (split-bf16 products: ~2e-5 of |w||r|).
-// From <U_high, CE_c> (hc) and the Gram matrix of the low-level rows (G: 00 01 02 03 11 12 13 22 23 33): the scan-start
-// bound, and the patterns that can hold a score at or above it -- a pattern whose UPPER bound alpha_P + |w_P| max|r| is
-// below the bound cannot reach the user's top-k and need not be scanned at all.
-__device__ __forceinline__ void grouped_pattern_terms(const float (&hc)[4], const float (&G)[10], const int32_t *grp, const int pt,
-                                                      const int k, const float a, const float b, float &lo, float &hi)
+// insertions per lane at 100 k dishes, scripts/diag/topk_scan_sim.py).  A pattern whose UPPER bound is below the scan-start
+// bound cannot reach the user's top-k and is not scanned at all.
+//
+// What the bounds have to hold for is the score AS A SCAN KERNEL COMPUTES IT (pruned and unpruned calls must return the
+// same bits), so they are widened by what f32 / split-bf16 arithmetic can do -- measured against the sums of ABSOLUTE
+// terms, not against results that may have cancelled (u = 2^-24; gamma_n = n u bounds any summation order of n terms):
+//   * alpha_P = (a / n) sum_{c in P} <U_high, CE_c>: each dot product is off by at most gamma_(E+8) ha_c, ha_c = sum_e |U_high,e
+//     CE_c,e| (plan and scan kernels may sum in different orders), the few operations after it by 7 u: |alpha~ - alpha| <=
+//     (gamma_(E+8) + 7 u) A,  A = (a / n) sum_{c in P} ha_c;
+//   * |w_P|^2 = (b / n)^2 |sum_{c in P} U_low,c|^2 from the f32 Gram matrix G: every G_cd is off by at most gamma_(E+8)
+//     sum_e |U_c,e U_d,e| <= gamma |U_c| |U_d|, the ten-term sum by gamma_10 more, so the true value is at most
+//     w2 + gam S^2,  S = sum_{c in P} sqrt(G_cc)  (when the rows cancel, w2 itself can come out 0 or negative while the
+//     true |w_P| is sqrt(gam) S -- the term restores it);
+//   * the scan's operand w~ = fl(beta fl(sum_c U_low,c)) is off by at most 5 u (b / n) sum_c |U_c,e| per element: at most
+//     5 u W in a score,  W = (b / n) S max|r|  (again the absolute sum, |w_P| may have cancelled);
+//   * the contraction: exact-f32 MFMA chains starting from alpha, gamma_(E+1) (|alpha| + |w~||r|); split bf16, 3 x 2^-18
+//     |w~||r| for the dropped lo x lo products and the splits' own rounding, gamma_E |w~||r| for the f32 accumulation, u
+//     |score| for the final alpha + acc; the f32 row norms behind max|r| are off by gamma_(E/64+7) / 2.
+// With gam = 2 (E + 32) u all of it fits in  slack = 1e-4 reach + gam (A + W):  every score a scan kernel computes for a dish
+// of pattern P lies in [alpha~ - reach - slack, alpha~ + reach + slack], reach = (b / n) sqrt(w2 + gam S^2) max|r| (1 + gam).
+// On the benchmark's tables the slack is 5e-4 of the reach (A ~ 0.6, W ~ 0.03, reach ~ 0.014): the bounds prune what they
+// pruned before.
+struct PatternBound {
+    float alpha, reach, slack;                              // lo = alpha - reach - slack, hi = alpha + reach + slack
+};
+
+__device__ __forceinline__ PatternBound grouped_pattern_terms(const float (&hc)[4], const float (&ha)[4], const float (&G)[10], const int32_t *grp,
+                                                              const int pt, const int k, const float a, const float b, const int E, float &lo,
+                                                              float &hi)
 {
     const int rows = grp[40 + pt];                          // wave-uniform
     const float rmax = __int_as_float(grp[GRP_RMAX + pt]);
     const float inv_n = 1.0f / (float)__builtin_popcount(pt);
-    float hs = 0.f, w2 = 0.f;
+    const float gam = (float)(E + 32) * 1.1920929e-7f;      // 2 (E + 32) 2^-24
+    float hs = 0.f, as = 0.f, w2 = 0.f, S = 0.f;
     int i = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         hs += ((pt >> c) & 1) ? hc[c] : 0.f;
+        as += ((pt >> c) & 1) ? ha[c] : 0.f;
+        S += ((pt >> c) & 1) ? sqrtf(G[i]) : 0.f;            // G[i] here: the diagonal entry G_cc (a sum of squares)
 #pragma unroll
         for (int d = c; d < 4; ++d, ++i) w2 += (((pt >> c) & 1) && ((pt >> d) & 1)) ? (c == d ? G[i] : 2.f * G[i]) : 0.f;
     }
-    const float alpha = a * (hs * inv_n);
-    const float reach = (b * inv_n) * sqrtf(fmaxf(w2, 0.f)) * rmax;
-    const float slack = 1e-4f * reach + 1e-6f * fabsf(alpha) + 1e-30f;        // the kernels' rounding, generously
-    lo = alpha - reach - slack;                              // k dishes at or above this ...
-    hi = alpha + reach + slack;                              // ... no dish of the pattern above this
+    PatternBound pb;
+    pb.alpha = a * (hs * inv_n);                            // the scan kernels' own expression, bit for bit
+    const float A = fabsf(a) * inv_n * as, W = fabsf(b) * inv_n * S * rmax;
+    pb.reach = (fabsf(b) * inv_n) * sqrtf(fmaxf(w2, 0.f) + gam * (S * S)) * rmax * (1.0f + gam);
+    pb.slack = 1e-4f * pb.reach + gam * (A + W) + 1e-30f;
+    lo = pb.alpha - pb.reach - pb.slack;                    // k dishes at or above this ...
+    hi = pb.alpha + pb.reach + pb.slack;                    // ... no dish of the pattern above this
     if (rows < k) lo = -INFINITY;                            // (branches, not selects: a wave-uniform select between a vector value and
     if (rows <= 0) hi = -INFINITY;                           //  a constant sent hipcc 7.2 into "Illegal instruction detected")
+    return pb;
 }
 
-__device__ __forceinline__ void grouped_pattern_bounds(const float (&hc)[4], const float (&G)[10], const int32_t *grp, const int k,
-                                                       const float a, const float b, float &seed, uint32_t &mask)
+__device__ __forceinline__ void grouped_pattern_bounds(const float (&hc)[4], const float (&ha)[4], const float (&G)[10], const int32_t *grp,
+                                                       const int k, const float a, const float b, const int E, float &seed, uint32_t &mask)
 {
     seed = -INFINITY;
 #pragma unroll 1
     for (int pt = 1; pt < 16; ++pt) {
         float lo, hi;
-        grouped_pattern_terms(hc, G, grp, pt, k, a, b, lo, hi);
+        grouped_pattern_terms(hc, ha, G, grp, pt, k, a, b, E, lo, hi);
         seed = fmaxf(seed, lo);                              // a NaN bound is ignored
     }
     mask = 0u;
 #pragma unroll 1
     for (int pt = 1; pt < 16; ++pt) {
         float lo, hi;
-        grouped_pattern_terms(hc, G, grp, pt, k, a, b, lo, hi);
+        grouped_pattern_terms(hc, ha, G, grp, pt, k, a, b, E, lo, hi);
         mask |= !(hi < seed) ? (1u << pt) : 0u;              // NaN bounds keep their pattern
     }
 }
 
-// the same from 16 lanes that all hold hc and G: lane j works out pattern j (lo / hi: its own bounds), the bound is the
+// the same from 16 lanes that all hold hc, ha and G: lane j works out pattern j (lo / hi: its own bounds), the bound is the
 // largest lo of the 16; grouped_mask_lanes: the patterns whose hi reaches a bound
-__device__ __forceinline__ void grouped_pattern_bounds_lanes(const float (&hc)[4], const float (&G)[10], const int32_t *grp, const int k,
-                                                             const float a, const float b, const int j, float &seed, float &lo, float &hi)
+__device__ __forceinline__ PatternBound grouped_pattern_bounds_lanes(const float (&hc)[4], const float (&ha)[4], const float (&G)[10],
+                                                                     const int32_t *grp, const int k, const float a, const float b, const int E,
+                                                                     const int j, float &seed, float &lo, float &hi)
 {
     lo = -INFINITY;
     hi = -INFINITY;
-    if (j >= 1) grouped_pattern_terms(hc, G, grp, j, k, a, b, lo, hi);
+    PatternBound pb{0.f, 0.f, 0.f};
+    if (j >= 1) pb = grouped_pattern_terms(hc, ha, G, grp, j, k, a, b, E, lo, hi);
     lo = fmaxf(lo, -INFINITY);                              // a NaN bound is ignored
     seed = lo;
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) seed = fmaxf(seed, __shfl_xor(seed, off, 64));
+    return pb;
 }
 
 __device__ __forceinline__ uint32_t grouped_mask_lanes(const float hi, const float seed, const int j)
@@ -1275,14 +1306,20 @@ __device__ __forceinline__ uint32_t grouped_mask_lanes(const float hi, const flo
 
 __device__ __forceinline__ float grouped_threshold_seed(const v4f *pmu, const int Sr, const float (&hc)[4], const GroupedArgs &p)
 {
-    float G[10];
+    float G[10], ha[4] = {0.f, 0.f, 0.f, 0.f};
+    const v4f *ce4 = reinterpret_cast<const v4f *>(p.ce);
 #pragma unroll
     for (int i = 0; i < 10; ++i) G[i] = 0.f;
 #pragma unroll 1
     for (int q = 0; q < Sr; ++q) {
         v4f u[4];
+        const v4f uh = pmu[q];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) u[c] = pmu[(c + 1) * Sr + q];
+        for (int c = 0; c < 4; ++c) {
+            u[c] = pmu[(c + 1) * Sr + q];
+            const v4f w = ce4[c * Sr + q];
+            ha[c] += (fabsf(uh.x * w.x) + fabsf(uh.y * w.y)) + (fabsf(uh.z * w.z) + fabsf(uh.w * w.w));
+        }
         int i = 0;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -1291,7 +1328,7 @@ __device__ __forceinline__ float grouped_threshold_seed(const v4f *pmu, const in
     }
     float seed;
     uint32_t mask;
-    grouped_pattern_bounds(hc, G, p.grp, p.k, p.a, p.b, seed, mask);
+    grouped_pattern_bounds(hc, ha, G, p.grp, p.k, p.a, p.b, Sr * 4, seed, mask);
     return seed;
 }
 
@@ -1325,7 +1362,7 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
     }
     const v4f *pmu = reinterpret_cast<const v4f *>(pm) + (size_t)ul * (5 * E4);
     const v4f *ce4 = reinterpret_cast<const v4f *>(ce);
-    float hc[4] = {0.f, 0.f, 0.f, 0.f}, G[10];
+    float hc[4] = {0.f, 0.f, 0.f, 0.f}, ha[4] = {0.f, 0.f, 0.f, 0.f}, G[10];     // ha: the same sums over |terms| (the bounds' rounding margin)
 #pragma unroll
     for (int i = 0; i < 10; ++i) G[i] = 0.f;
     for (int q = j; q < E4; q += 16) {
@@ -1335,6 +1372,7 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
         for (int c = 0; c < 4; ++c) {
             const v4f w = ce4[c * E4 + q];
             hc[c] += (uh.x * w.x + uh.y * w.y) + (uh.z * w.z + uh.w * w.w);
+            ha[c] += (fabsf(uh.x * w.x) + fabsf(uh.y * w.y)) + (fabsf(uh.z * w.z) + fabsf(uh.w * w.w));
             r[c] = pmu[(c + 1) * E4 + q];
         }
         int i = 0;
@@ -1346,12 +1384,15 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) hc[c] += __shfl_xor(hc[c], off, 64);
+        for (int c = 0; c < 4; ++c) {
+            hc[c] += __shfl_xor(hc[c], off, 64);
+            ha[c] += __shfl_xor(ha[c], off, 64);
+        }
 #pragma unroll
         for (int i = 0; i < 10; ++i) G[i] += __shfl_xor(G[i], off, 64);
     }
     float seed, lo, hi;
-    grouped_pattern_bounds_lanes(hc, G, grp, k, a, b, j, seed, lo, hi);
+    const PatternBound pb = grouped_pattern_bounds_lanes(hc, ha, G, grp, k, a, b, E, j, seed, lo, hi);
     // A better bound from a few dishes: the pattern whose lower bound IS the bound (the user's best) holds its largest-norm
     // rows first in the sorted table; the k-th largest exact score among the first 16 to 64 of them (more for larger catalogues) is a lower bound of
     // the pattern's k-th score -- about alpha_P + 0.1 |w||r| where Cauchy-Schwarz gives alpha_P - |w||r| -- and fewer other
@@ -1361,8 +1402,8 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
         const unsigned long long best = __ballot(j >= 1 && lo == seed && seed > -INFINITY);
         const int p1 = (int)((best >> g16) & 0xffffull) ? __builtin_ctz((unsigned)((best >> g16) & 0xffffull)) : 0;
         const int nrow = p1 ? (grp[40 + p1] < nprobe ? grp[40 + p1] : nprobe) : 0;      // >= k: the bound was finite
-        const float alpha1 = __shfl(0.5f * (lo + hi), g16 + p1, 64);                          // (lo + hi) / 2 = alpha_P
-        const float reach1 = __shfl(0.5f * (hi - lo), g16 + p1, 64);                          // |w_P| max|r| + slack
+        const float alpha1 = __shfl(pb.alpha, g16 + p1, 64);                                  // alpha_P as the scan kernels compute it
+        const float slack1 = __shfl(pb.slack, g16 + p1, 64);                                  // what arithmetic can move a score of P by
         // w_P1: this lane's float4 columns q = j, j + 16, ... (embedding sizes up to 256)
         v4f wv[CH];
         const float beta = b / (float)__builtin_popcount(p1 | (p1 == 0));
@@ -1404,8 +1445,9 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
             }
         }
         const float kth = __shfl(slot, g16 + k - 1, 64);
-        // the scan's own arithmetic (split bf16, or f32 in another order) may put these dishes a little lower: the same slack as the bounds'
-        const float probed = kth - (1e-4f * reach1 + 1e-6f * fabsf(alpha1) + 1e-30f);
+        // the k probe rows that scored kth or more here score kth - 2 slack or more in the scan: slack bounds the distance of a
+        // computed score from the exact one for the scan kernels' arithmetic, and for this loop's (the same operand, f32 fma chains)
+        const float probed = kth - 2.f * slack1;
         if (p1 && nrow >= k && probed > seed) seed = probed;
     }
     uint32_t mask = grouped_mask_lanes(hi, seed, j);

@@ -250,7 +250,8 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
  * form; same results) select among retrieval kernels.  "topk_prune" (default 1): the pattern-grouped retrieval kernels
  * (pipelined split-bf16 and exact f32) start each user's scan from a lower bound of its k-th score and step through the
  * tiles of the mask patterns that can reach its top-k only (with 0/1 masks every dish of pattern P scores within
- * alpha_P[u] +- |w_P[u]| max|RE[d]|; users are sorted by their pattern mask so that a block's users share patterns, and a
+ * alpha_P[u] +- |w_P[u]| max|RE[d]|, widened by what f32 / split-bf16 arithmetic can move a computed score by, measured
+ * against the sums of absolute terms so that cancelling rows keep their margin; users are sorted by their pattern mask so that a block's users share patterns, and a
  * launch's (user block, dish range) items are handed out longest first); the lists are the same bit for bit with 0 (every
  * tile).  2 / 3 / 4 / 5 / 6 are A/B forms of the same: the bound only, no sort, the patterns only, the grid's launch order,
  * the bound without its probe rows (the k-th largest exact score among the first rows of the user's best pattern).
