@@ -2699,7 +2699,22 @@ int ensure_grouped(m2d_engine *h, hipStream_t st)
     // w_P = sum of the pattern's U_low rows leaves out the 0 * U_low[c] products of the other categories: with inf / NaN in
     // a table those are NaN in the reference formula, and the dense kernel (which multiplies them) serves the call
     h->grp_nonfinite = host[3] != 0;
+    h->grp_nonfinite_known = true;
     h->grp_valid = true;
+    return M2D_OK;
+}
+
+// m2d_write_memory adds into Personal_Memory: the sorted dish rows stay valid, but the device word "a table value is
+// inf / NaN" may have been set by its row check -- read it again before choosing between the pattern-grouped kernels
+// (which leave out the 0 * U_low[c] products) and the dense one
+int refresh_grouped_nonfinite(m2d_engine *h, hipStream_t st)
+{
+    if (h->grp_nonfinite_known) return M2D_OK;
+    int32_t word = 0;
+    M2D_HIP_TRY(h, hipMemcpyAsync(&word, h->nonfinite_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    M2D_HIP_TRY(h, hipStreamSynchronize(st));
+    h->grp_nonfinite = word != 0;
+    h->grp_nonfinite_known = true;
     return M2D_OK;
 }
 
@@ -3017,6 +3032,7 @@ int m2d_launch_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32
     if (h->C == 4 && (!h->dish_high || (hv_ok && !padded)) && k <= 16 && roww != 0 &&
         h->opt_topk_grouped != 0 && h->opt_variant != 7 && h->opt_variant != 8 && h->opt_variant != 9) {
         if ((rc = ensure_grouped(h, stream)) != M2D_OK) return rc;
+        if ((rc = refresh_grouped_nonfinite(h, stream)) != M2D_OK) return rc;
         if (hv_ok && h->grp_binary && h->grp_tiles > 0 && !h->grp_nonfinite) {
             if (h->E == 32)
                 return k <= 10 ? launch_grouped<8, 8, 10, true, true>(h, users, nU, k, out_scores, out_ids, stream)

@@ -6,7 +6,9 @@
 
 #include <mutex>
 #include <string>
+#include <map>
 #include <unordered_map>
+#include <utility>
 
 #include "../../include/m2d.h"
 
@@ -79,7 +81,8 @@ struct m2d_engine {
     int64_t grp_tiles = 0, grp_cap_rows = 0;
     int grp_ew = 0;                     // row width of grp_rs: E, or 2 E with the ingredient extension ([H[d] | RE[d]])
     bool grp_valid = false, grp_binary = false;
-    bool grp_nonfinite = false;         // *nonfinite_dev as read when the tables were built (every writer invalidates them)
+    bool grp_nonfinite = false;         // *nonfinite_dev as last read by the retrieval launcher (with the table build, or again
+    bool grp_nonfinite_known = false;   //  after a writer that leaves the sorted dish rows alone: m2d_write_memory on Personal_Memory)
 
     // training step: optimizer slots and gradient scratch, created by m2d_train_begin
     m2d_train_state *train = nullptr;
@@ -133,15 +136,21 @@ struct m2d_engine {
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and size: a retrieval call makes six such calls, each a
 // trip into the runtime, for a value that does not change (8 us of a 50 us host-side call)
+// (The attribute belongs to the function ON A DEVICE, and a process may hold engines on several -- m2d_create(device): the
+// cache is keyed by the current device as well; every entry point has already made the engine's device current.)
 static inline hipError_t m2d_lds_limit(const void *fn, int bytes)
 {
     static std::mutex mu;
-    static std::unordered_map<const void *, int> seen;
+    static std::map<std::pair<int, const void *>, int> seen;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lock(mu);
-    auto it = seen.find(fn);
+    const auto key = std::make_pair(dev, fn);
+    auto it = seen.find(key);
     if (it != seen.end() && it->second >= bytes) return hipSuccess;
-    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) seen[fn] = bytes;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) seen[key] = bytes;
     return e;
 }
 

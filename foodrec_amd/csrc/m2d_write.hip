@@ -182,7 +182,10 @@ int m2d_launch_write_memory(m2d_engine *h, const int32_t *users, const int32_t *
                             const float *sign, const float *labels, int64_t B, int32_t L, float *gm, float beta_1,
                             float beta_2, float alpha, int32_t which, double *out_sums, hipStream_t stream)
 {
-    if (which & M2D_WRITE_PERSONAL) h->user_high_valid = false;   // Personal_Memory is about to change
+    if (which & M2D_WRITE_PERSONAL) {
+        h->user_high_valid = false;                             // Personal_Memory is about to change
+        h->grp_nonfinite_known = false;                         // ... and may receive inf / NaN: retrieval reads the device word again
+    }
     WriteArgs a;
     a.pm = const_cast<float *>(h->pm); a.re = h->re; a.ce = h->ce; a.gm = gm;
     a.users = users; a.items = items; a.cats = cats; a.sign = sign; a.labels = labels;
