@@ -1197,7 +1197,17 @@ struct GroupedArgs {
     const int32_t *order;      // [nU] position in the launch -> index into users / plan (users sorted by pattern mask), or null
     unsigned long long *tiles_scanned;   // diagnostic: 32-dish tiles the blocks stepped through
     const int32_t *items;      // [user blocks x nsplit] launch order of a pruned scan: block * nsplit + split, longest first; or null
+    int32_t *shared_thr;       // word 6 of the plan records (stride 8): the user's running threshold over ALL dish ranges, as an
+                               // ordered key (thr_key); null = every (block, range) item keeps to its own lists
 };
+
+// float <-> int32 with the same order (an involution): thresholds of a user's dish ranges meet in one atomicMax word
+__device__ __forceinline__ int32_t thr_key(const float f)
+{
+    const int32_t b = __float_as_int(f);
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float thr_unkey(const int32_t k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
 
 // A threshold to start the scan from, known before any dish is scored.  With 0/1 masks score(u, d) = alpha_P[u] +
 // <w_P[u], RE[d]> >= alpha_P[u] - |w_P[u]| max_{d in P} |RE[d]| (Cauchy-Schwarz), so a pattern that holds at least k dishes
@@ -1456,7 +1466,9 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
     if (no_alpha == 4) seed = -INFINITY;                      // option topk_prune = 4: the patterns, but no bound (A/B)
     if (u < nU && j == 0) {
         float *o = plan + (size_t)u * 8;
-        o[0] = seed; o[1] = hc[0]; o[2] = hc[1]; o[3] = hc[2]; o[4] = hc[3]; o[5] = __uint_as_float(mask); o[6] = 0.f; o[7] = 0.f;
+        o[0] = seed; o[1] = hc[0]; o[2] = hc[1]; o[3] = hc[2]; o[4] = hc[3]; o[5] = __uint_as_float(mask);
+        o[6] = __int_as_float(thr_key(seed));               // the dish ranges' shared running threshold starts at the bound
+        o[7] = 0.f;
     }
 }
 
@@ -2152,7 +2164,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
 
     // The users of a launch come in the order the call's plan sorted them into (by relevant-pattern mask, p.order):
     // uidx = the user's index in the CALL (users, plan, outputs), wherever the launch placed it.
-    int64_t uidx[G];
+    int32_t uidx[G];                                       // 32-bit on purpose (a call holds < 2^31 users): a register less across the scan
     bool uvalid[G];
     const v4f *pmu[G];
     float hc[G][C];                                        // <U_high, CE_c>   Model_Recommender.py:67-75 (from the plan)
@@ -2162,7 +2174,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     for (int g = 0; g < G; ++g) {
         const int64_t pos = (((int64_t)bx * WAVES + wave) * G + g) * 32 + j;
         uvalid[g] = pos < p.nU;
-        uidx[g] = uvalid[g] ? (p.order ? (int64_t)p.order[pos] : pos) : 0;
+        uidx[g] = uvalid[g] ? (p.order ? p.order[pos] : (int32_t)pos) : 0;
         int64_t ul = 0;
         if (uvalid[g]) {
             const int32_t uid = p.users[uidx[g]];
@@ -2170,8 +2182,8 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
             if (ul < 0 || ul >= p.U) {
                 if (atomicCAS(&p.err[0], 0, M2D_ERR_BAD_USER_ID) == 0) {
                     p.err[1] = uid;
-                    p.err[2] = (int32_t)(uidx[g] & 0xffffffff);
-                    p.err[3] = (int32_t)(uidx[g] >> 32);
+                    p.err[2] = uidx[g];
+                    p.err[3] = 0;
                 }
                 ul = 0;
             }
@@ -2181,6 +2193,8 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
 #pragma unroll
         for (int c = 0; c < C; ++c) hc[g][c] = rec[1 + c];
         seed[g] = uvalid[g] ? rec[0] : INFINITY;            // a lane without a user never has a candidate
+        if (p.shared_thr && uvalid[g])                      // what the user's other dish ranges have reached so far (see exchange_thresholds)
+            seed[g] = fmaxf(seed[g], thr_unkey(__hip_atomic_load(p.shared_thr + (size_t)uidx[g] * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
         umask_lane |= uvalid[g] ? __float_as_uint(rec[5]) : 0u;
     }
     // the block's patterns: the union over its users.  Tiles of every other pattern are not even fetched.
@@ -2341,7 +2355,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     }
 
 #if M2D_DIAG & 16
-    unsigned long long t_body = 0, t_slow = 0, t_bar = 0, n_slow = 0, n_step = 0, n_ins = 0, t0_, t1_;
+    unsigned long long t_body = 0, t_slow = 0, t_bar = 0, n_slow = 0, n_step = 0, n_ins = 0, t0_, t1_, t_slow_first = 0, n_slow_first = 0;
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
@@ -2356,6 +2370,34 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         const auto sm = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
         thr[g] = fmaxf(fmaxf(fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])),
                              fminf(__uint_as_float(sm[0]), __uint_as_float(sm[1]))), seed[g]);
+    };
+
+    // A launch cut into dish ranges runs a user's ranges as separate workgroups, each with lists of its own -- and each
+    // used to climb from the scan-start bound on its own, re-inserting what the others had long outgrown (8 ranges: about
+    // five times the insertions of one scan).  Any threshold of any range is a lower bound of the user's FINAL k-th score
+    // (k dishes at or above it exist), so the ranges meet in one word per user, plan record word 6: once per stage a lane
+    // sends its threshold there (agent-scope atomic max on the ordered key) and takes what comes back -- the largest any
+    // range had sent -- as its floor from the NEXT stage on: the answer has a whole stage to arrive and is never waited
+    // for.  What the word holds when a lane looks depends on timing; the lists do not: a dish of the final top-k scores at or
+    // above every lower bound of the k-th score, reaches its range's insertion whatever the floor, and stays in that
+    // range's list; tie events at the final k-th value likewise involve scores at or above every floor.
+    int32_t pend_key[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) pend_key[g] = thr_key(-INFINITY);
+    auto exchange_thresholds = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            seed[g] = fmaxf(seed[g], thr_unkey(pend_key[g]));
+            thr[g] = fmaxf(thr[g], seed[g]);
+            if (uvalid[g]) {
+                int32_t *word = p.shared_thr + (size_t)uidx[g] * 8;
+                if (thr[g] > seed[g]) {                     // news: above everything this lane has heard or said (seed = that floor)
+                    pend_key[g] = __hip_atomic_fetch_max(word, thr_key(thr[g]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    seed[g] = thr[g];
+                } else                                      // nothing to say: a read leaves the line shared between the XCDs' L2s
+                    pend_key[g] = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     };
 
     // the interleaved body: M(q-1) into accN, L(q), the compares + max tree of tile q-2 (accP), and -- INS -- the
@@ -2423,6 +2465,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
             ps_m1 = ps_0;
             ps_0 = ps_p1;
             ps_p1 = next_stage();
+            if (p.shared_thr) exchange_thresholds();
         }
         if (KS > AR && sub == 1) {
             // With more k-steps than fragment sets (E = 128: KS = 8, AR = 4) a tile's last KS - AR k-steps are read one step
@@ -2549,7 +2592,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
                 cand[g] = rowmap[g] != 0u;
                 multi |= __ballot((rowmap[g] & (rowmap[g] - 1u)) != 0u);                      // two or more bits set
             }
-            if (multi != 0ull) {                           // immediate path: some lane holds two or more candidates of this tile
+            if ((M2D_DIAG & 64) ? false : multi != 0ull) { // immediate path: some lane holds two or more candidates of this tile
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     // Two ways to get them in.  Row by row: every row in which SOME lane has a candidate is inserted by the
@@ -2601,11 +2644,12 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
                     px[g] = cand[g] ? mx[g] + alpha_prev[g] : -INFINITY;
                     pid[g] = sbase + (r & 3) + 8 * (r >> 2);
                 }
-                pend = true;
+                pend = (M2D_DIAG & 128) ? (__ballot(px[0] == 12345.678f) != 0ull) : true;
             }
 #if M2D_DIAG & 16
             asm volatile("" ::"v"(thr[0]), "v"(px[0]));
             STAMP(t1_); t_slow += t1_ - t0_; ++n_slow;
+            if (q <= TPS + 2) { t_slow_first += t1_ - t0_; ++n_slow_first; }
 #endif
         }
     };
@@ -2622,6 +2666,14 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
             tie_mask[g] = tie_update(tie_mask[g], fmaxf(px[g], -INFINITY), ol, rs[g][KR - 1]);
         }
     }
+    if (p.shared_thr && n > 0) {                           // what this range ends with: ranges of the user that start later begin there
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            share_threshold(g);
+            if (uvalid[g])
+                __hip_atomic_fetch_max(p.shared_thr + (size_t)uidx[g] * 8, thr_key(thr[g]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     wait_all_vmem();                                       // no LDS-DMA may land after the lists are published below
     __syncthreads();
     if (p.tiles_scanned && threadIdx.x == 0) atomicAdd(p.tiles_scanned, (unsigned long long)n);
@@ -2630,6 +2682,9 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
         unsigned long long *d = p.dbg + ((size_t)(by * ((p.nU + 255) / 256) + bx) * WAVES + wave) * 8;
         d[0] = t_body; d[1] = n_ins; d[2] = t_bar; d[3] = t_slow; d[4] = n_slow; d[5] = n_step;
         d[6] = __builtin_amdgcn_s_memtime() - clk0; d[7] = __builtin_amdgcn_s_memrealtime() - rt0;
+#if M2D_DIAG & 32
+        d[7] = t_slow_first; d[1] = n_slow_first;          // candidate handling of an item's first stage (steps 1 .. TPS + 2)
+#endif
     }
 #endif
 
@@ -2793,7 +2848,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     a.grp = h->grp_work + (size_t)((h->I + 255) / 256) * GRP_KEYS;
     a.users = users; a.nU = nU; a.U = h->U; a.user_base = h->user_base; a.k = k; a.tiles = h->grp_tiles;
     a.a = h->a; a.b = h->b; a.err = h->err_dev; a.dbg = g_m2d_diag_buffer; a.e_real = h->E;
-    a.plan = nullptr; a.order = nullptr; a.tiles_scanned = nullptr; a.items = nullptr;
+    a.plan = nullptr; a.order = nullptr; a.tiles_scanned = nullptr; a.items = nullptr; a.shared_thr = nullptr;
     const int64_t ublocks = (nU + 32 * WAVES - 1) / (32 * WAVES);
     int nsplit = pick_splits(h, ublocks, a.tiles, 2 * TPS, 512);
     if ((!BF16X3 || (!HV && h->opt_topk_form != 1)) && h->opt_topk_prune != 0 && h->opt_variant < 100) {
@@ -2883,6 +2938,8 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
                                plan, tie_list, counter, sorted ? hist : nullptr, PLAN_KEYS, probes, h->grp_ew, nprobe);
         }
         a.plan = plan;
+        // dish ranges of a user share their thresholds (pipelined kernel; "topk_prune" = 7 keeps them apart: A/B)
+        if (BF16X3 && pipe && nsplit > 1 && h->opt_topk_prune != 7) a.shared_thr = reinterpret_cast<int32_t *>(plan) + 6;
         if (sorted) {
             const size_t tab = (size_t)PLAN_KEYS * sizeof(int32_t);
             const unsigned sblocks = (unsigned)((nU + 1023) / 1024 < 4 * h->num_cu ? (nU + 1023) / 1024 : 4 * h->num_cu);

@@ -20,8 +20,9 @@ if os.environ.get("PROBE_F32"):
     eng.set_option("topk_bf16x3", 0)                      # the exact-f32 kernel
 res = {}
 import itertools
+PRUNES = [int(v) for v in os.environ.get("PROBE_PRUNES", "1").split()]
 VARS = [int(v) for v in os.environ.get("PROBE_VARIANTS", "101 116").split()]
-for prune, var in [(0, 0), (6, 0), (1, 0)] + [(1, v) for v in VARS]:      # 6: Cauchy-Schwarz bounds only; 1: + probe rows      # 5: pruned, grid launch order; 1: longest item first
+for prune, var in [(0, 0), (6, 0), (1, 0)] + [(pr, v) for v in VARS for pr in PRUNES]:      # 6: Cauchy-Schwarz bounds only; 1: + probe rows      # 5: pruned, grid launch order; 1: longest item first
     eng.set_option("topk_prune", prune); eng.set_option("variant", var)
     for _ in range(5):
         s1, i1 = eng.topk_users(users, 10)

@@ -66,6 +66,10 @@ int main(int argc, char **argv)
         hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
         double m = 0, e = 0, b = 0, sl = 0, ns = 0, st = 0, ck = 0, rt = 0, nw = 0, maxck = 0;
         for (int w = 0; w < 65536; ++w) { m += hd[w*8]; e += hd[w*8+1]; b += hd[w*8+2]; sl += hd[w*8+3]; ns += hd[w*8+4]; st += hd[w*8+5]; ck += hd[w*8+6]; rt += hd[w*8+7]; nw += hd[w*8+6] != 0; if ((double)hd[w*8+6] > maxck) maxck = (double)hd[w*8+6]; }
+#if M2D_DIAG & 32
+        printf("first stage of an item (steps 1 .. 10): %.0f candidate steps per wave-item, %.0f cycles each; whole item: %.0f candidate steps, %.0f cycles each\n", e / nw, e ? rt / e : 0.0, ns / nw, ns ? sl / ns : 0.0);
+        rt = 0;
+#endif
         if (rt > 0) printf("in-kernel clock: %.0f waves, %.0f s_memtime ticks per wave (longest %.0f) over %.1f us (s_memrealtime, 100 MHz) = %.3f GHz; all waves together %.3e ticks\n", nw, ck / nw, maxck, rt / nw / 100.0, ck / rt * 0.1, ck);
         // pipelined bf16 kernel: d[0] = interleaved body, d[1] = sorted_insert calls, d[2] = stage wait + barrier, d[3] = slow path
         printf("per step per wave (cycles): body %.0f  slow path %.0f (%.1f%% of steps, %.0f each, %.2f inserts each)  wait+barrier %.0f  [%.0f steps/wave]\n",

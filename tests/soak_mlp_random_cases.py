@@ -10,7 +10,7 @@ from oracle import m2d_oracle as oracle
 from helpers import assert_scores_close
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-seed0 = int(time.time())
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())      # [cases] [first seed]
 print("seed0", seed0)
 for it in range(n):
     rng = np.random.default_rng(seed0 + it)

@@ -13,7 +13,7 @@ from helpers import TOL, assert_scores_close
 
 dev = lambda a: torch.as_tensor(a, device="cuda")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-seed0 = int(time.time())
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())      # [cases] [first seed]
 print("seed0", seed0)
 
 

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""One-off randomized soak of the retrieval call's plan -- scan-start bounds, pattern pruning, users sorted by mask, (user block,
-dish range) items handed out longest first -- on calls large enough to use all of it (test infrastructure, not collected by
-pytest: seeds come from the clock).  Every option form and split count must return the lists of the plain scan (`topk_prune` = 0,
-one dish range) bit for bit; a few users per case are checked against the float64 restatement, tie order included.
-Usage on the GPU box: python tests/soak_topk_plan.py [cases]."""
+"""Randomized soak of the retrieval call's plan -- scan-start bounds, pattern pruning, users sorted by mask, (user block,
+dish range) items handed out longest first, thresholds shared between a user's dish ranges -- on calls large enough to use all
+of it; every fourth case draws its tables from tests/test_gpu_prune_adversarial.py (cancelling rows, equal alpha, ...).
+Every option form and split count must return the lists of the plain scan (`topk_prune` = 0, one dish range) bit for bit; a
+few users per case are checked against the float64 restatement, tie order included.  Test infrastructure: seeds come from
+the clock unless given; tests/test_gpu_soaks.py runs 20 fixed-seed cases under pytest.
+Usage on the GPU box: python tests/soak_topk_plan.py [cases] [first seed]."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +13,7 @@ import numpy as np, torch
 from foodrec_amd import ScoringEngine
 from oracle import m2d_oracle as oracle
 from helpers import TOL, assert_scores_close
+from test_gpu_prune_adversarial import adversarial_tables
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())      # [cases] [first seed]
@@ -40,6 +43,13 @@ for it in range(n):
         cats[rng.choice(I, min(I, 7), replace=False)] = 0                 # empty masks: 0 / 0 = NaN, ranked last
     if style == 3:
         PM[rng.integers(0, U, 5)] = 0.0                                   # users whose every score ties inside a pattern
+    adv = None
+    if it % 4 == 1:                                                       # tables built against the pruning bounds' rounding margins
+        adv = str(rng.choice(["anti", "anti_alpha0", "anti_equal_alpha", "equal_alpha", "anti_mixed", "same", "hc_cancel", "tiny_low"]))
+        PM, RE, CE, cats = adversarial_tables(adv, E, U, I, seed0 + it, eps=float(rng.choice([1e-3, 1e-4, 1e-5, 1e-6])),
+                                              low_scale=float(rng.choice([1.0, 6.0, 30.0])),
+                                              pats_per_dish=[3, 12, 15] if rng.integers(0, 2) else None)
+        style = 10
     x3 = int(rng.integers(0, 2)) if E in (64, 128) else 0
     eng = ScoringEngine(PM.astype(np.float32), RE.astype(np.float32), CE.astype(np.float32)); eng.set_dish_categories(cats)
     eng.set_option("topk_bf16x3", x3)
@@ -51,7 +61,7 @@ for it in range(n):
     s0, i0 = s0.cpu().numpy(), i0.cpu().numpy()
     kern = eng.last_kernel()
     rep0 = eng.get_option("topk_repaired")
-    forms = [(1, 0), (5, 0), (int(rng.choice([2, 3, 4])), 0), (1, 100 + int(rng.integers(2, 40))), (0, 0)]
+    forms = [(1, 0), (5, 0), (int(rng.choice([2, 3, 4, 7])), 0), (1, 100 + int(rng.integers(2, 40))), (0, 0)]      # 7: dish ranges keep their thresholds apart
     for prune, var in forms:
         eng.set_option("topk_prune", prune); eng.set_option("variant", var)
         s1, i1 = eng.topk_users(du, k); eng.check()
@@ -79,6 +89,6 @@ for it in range(n):
             tied_out = [d for d in np.flatnonzero(ref32 == ref32[g[nv - 1]]) if d not in set(g.tolist())]
             if x3 == 0 and tied_out and (ref32[g] == ref32[g[nv - 1]]).any():
                 pass                                                       # (f64 -> f32 equality is not the kernel's: informative only)
-    print("ok", it, kern, "E%d U%d I%d k%d nU%d style%d repaired %d" % (E, U, I, k, nU, style, eng.get_option("topk_repaired")), flush=True)
+    print("ok", it, kern, "E%d U%d I%d k%d nU%d style%d %s repaired %d" % (E, U, I, k, nU, style, adv or "", eng.get_option("topk_repaired")), flush=True)
     eng.close()
 print("all", n, "cases agree")

@@ -263,8 +263,12 @@ def test_retrieval_after_write_memory_added_inf_takes_the_dense_kernel():
     assert np.isinf(pmt[:8, 1, 2].cpu().numpy()).all()
     s1, i1 = eng.topk_users(users, k); eng.check()
     assert eng.last_kernel() == "m2d_topk_mfma"
-    s1, i1, i0 = s1.cpu().numpy(), i1.cpu().numpy(), i0.cpu().numpy()
-    assert np.array_equal(i0[8:], i1[8:])                                      # users that were not written to: same lists
+    s1, i1, s0, i0 = s1.cpu().numpy(), i1.cpu().numpy(), s0.cpu().numpy(), i0.cpu().numpy()
+    # users that were not written to: the same lists (another kernel, another rounding: where two dishes change places their
+    # scores are closer than the split-bf16 product's error)
+    differ = i0[8:] != i1[8:]
+    assert differ.mean() < 0.02 and np.all(np.abs(s0[8:] - s1[8:])[differ] <= 3e-5)
+    assert np.all(np.abs(s0[8:] - s1[8:]) <= 3e-5)
     it = torch.arange(I, dtype=torch.int32, device="cuda")
     ct = torch.as_tensor(dish_cats, device="cuda")
     for u in range(8):
