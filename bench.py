@@ -402,45 +402,54 @@ def sharded_topk_leg(torch, dist, eng, U, I, C, E, dev, user_base, n_users, worl
 
 def sharded_all_users_leg(torch, dist, sh, I, k, round_users, repeats=1, warm_rounds=2):
     """The user-sharded top-k path as north_star states it: every rank ranks EVERY user of its shard over the replicated
-    catalogue (rounds of `round_users` users, foodrec_amd.sharding.topk_local_rounds), then ONE all-gather of
-    [shard, k] x (f32 score, i32 id) per rank.  `sh` is a UserShardedScorer; `dist` is None in a single-process run (no
-    peers, no collective).  Wall time = max over ranks, median over repeats."""
+    catalogue in rounds of `round_users` users and the ranks exchange their final lists -- [shard, k] x (f32 score, i32 id)
+    per rank -- by all-gather, one piece per round, each issued asynchronously while the next round is being ranked
+    (foodrec_amd.sharding.UserShardedScorer.topk_all_users): only the last round's exchange is exposed.  `sh` is a
+    UserShardedScorer; `dist` is None in a single-process run (no peers, no collective).  Wall time = max over ranks,
+    median over repeats; `allgather_exposed_ms` = what the stream still waited for after the last round's kernels."""
     clk = _Clock(torch, sh.device)
     per_round = min(int(round_users), max(sh.count, 1))
+    first = torch.arange(sh.base, sh.base + min(per_round, sh.count), dtype=torch.int32, device=sh.device)
     if sh.count:
-        sh.topk_local(k, torch.arange(sh.base, sh.base + min(per_round, sh.count), dtype=torch.int32, device=sh.device))   # builds the retrieval tables
+        sh.topk_local(k, first)                            # builds the retrieval tables
         for _ in range(warm_rounds):
-            sh.topk_local(k, torch.arange(sh.base, sh.base + min(per_round, sh.count), dtype=torch.int32, device=sh.device))
-    if dist is not None:                                  # the collective's buffers and connections, once, at its real size
-        sh._gather_topk(torch.zeros((sh.count, k), dtype=torch.float32, device=sh.device),
-                        torch.zeros((sh.count, k), dtype=torch.int32, device=sh.device), sh.per, k)
-    walls, tk, ag = [], [], []
+            sh.topk_local(k, first)
+    if dist is not None:                                  # the collective's buffers and connections, once, at their real sizes
+        sh.topk_all_users(k, round_users=round_users)
+    walls, exposed = [], []
     ok = True
     for _ in range(repeats):
         clk.sync()
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
-        e0 = clk.mark()
-        s, ids = sh.topk_local_rounds(k, round_users)
-        e1 = clk.mark()
-        gs, gi = sh._gather_topk(s, ids, sh.per, k) if dist is not None else (s, ids)
-        e2 = clk.mark()
+        if dist is not None:
+            gs, gi = sh.topk_all_users(k, round_users=round_users)
+        else:
+            gs, gi = sh.topk_local_rounds(k, round_users)
         clk.sync()
-        t = torch.tensor([time.perf_counter() - t0, clk.ms(e0, e1), clk.ms(e1, e2)], dtype=torch.float64, device=sh.device)
+        ex = 0.0
+        if dist is not None and getattr(sh, "last_allgather_events", None):
+            ex = sh.last_allgather_events[0].elapsed_time(sh.last_allgather_events[1])
+        t = torch.tensor([time.perf_counter() - t0, ex], dtype=torch.float64, device=sh.device)
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        w, a_, b_ = (float(x) for x in t.tolist())
-        walls.append(w); tk.append(a_); ag.append(b_)
-        lo = sh.rank * sh.per
-        ok = ok and bool(torch.equal(gi[lo:lo + sh.count], ids) and torch.equal(gs[lo:lo + sh.count].view(torch.int32), s.view(torch.int32)))
+        w, e_ = (float(x) for x in t.tolist())
+        walls.append(w); exposed.append(e_)
+        if sh.count:                                       # this rank's first round, ranked again on its own, sits where it should
+            cs, ci = sh.topk_local(k, first)
+            lo = sh.rank * sh.per if dist is not None else 0
+            ok = ok and bool(torch.equal(gi[lo:lo + first.numel()], ci) and
+                             torch.equal(gs[lo:lo + first.numel()].view(torch.int32), cs.view(torch.int32)))
     if sh.scorer is not None:
         sh.scorer.check()
     wall = median(walls)
     total_users = sh.num_users_total
     return {"path": "sharded_topk_allgather", "users_total": total_users, "users_per_gpu": sh.per, "dishes": I, "k": k,
             "round_users": int(round_users), "rounds_per_gpu": -(-sh.per // int(round_users)), "repeats": repeats,
-            "wall_ms": wall * 1e3, "topk_ms": median(tk), "allgather_ms": median(ag),
+            "wall_ms": wall * 1e3, "allgather_exposed_ms": median(exposed) if dist is not None else 0.0,
+            "allgather": ("one asynchronous all-gather per round, overlapped with the next round's ranking; exposed = the last "
+                          "round's exchange and its copy into the result") if dist is not None else "none (single process)",
             "allgather_bytes_per_rank": sh.per * k * 8 if dist is not None else 0,
             "users_per_s_whole_job": total_users / wall, "pairs_per_s_whole_job": total_users * I / wall,
             "own_slice_roundtrip_ok": ok}
@@ -478,6 +487,10 @@ def scaling_path_block(torch, dist, foodrec_amd, dev, world, rank, users_total, 
         out["roofline_frac_of_mfma_peak"] = (out["roofline_frac_of_mfma_peak"] * sc_ / fl_) if fl_ else out["roofline_frac_of_mfma_peak"]
         out["roofline_note"] = ("fraction of the dense bf16 MFMA peak on the flops executed (tiles stepped through x 3 MFMAs); "
                                 "pairs_per_s_whole_job counts every (user, dish) pair of the catalogue")
+    # pairs DECIDED (every pair of the catalogue: most by a bound, without being multiplied) and pairs MULTIPLIED (the tiles
+    # the blocks stepped through; the last round's share stands for the shard)
+    out["pairs_decided_per_s_whole_job"] = out["pairs_per_s_whole_job"]
+    out["pairs_multiplied_per_s_whole_job"] = out["pairs_per_s_whole_job"] * (out.get("scanned_fraction_last_round") or 1.0)
     # the exact-f32 kernel on one round of this shard's users (every rank at once; max over ranks)
     clk = _Clock(torch, dev)
     eng.set_option("topk_bf16x3", 0)
@@ -1120,11 +1133,22 @@ def main():
                                 "traffic": None, "step_avg_ms": avg_ms, "flop_per_pair_executed": fl / units,
                                 "dense_equivalent_tflops": 2.0 * K * units / (avg_ms * 1e-3) / 1e12,
                                 "scanned_fraction": scanned_frac, "frac_if_every_tile_were_scanned": tf_all / peak,
-                                "note": "`frac` prices the flops EXECUTED (the tiles the blocks stepped through); `value` counts every "
-                                        "(user, dish) pair of the catalogue -- most are decided by a bound, without being multiplied",
+                                "note": "`frac` prices the flops EXECUTED (the tiles the blocks stepped through), and `value` counts the pairs "
+                                        "of those tiles; pairs_decided_per_s counts every (user, dish) pair of the catalogue -- most are "
+                                        "decided by a bound, without being multiplied",
                                 "dtype": ("split bf16 (3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)" if x3 else
                                           "f32 (v_mfma_f32_32x32x2_f32, exact)")}
             line["dtype"] = "bf16x3" if x3 else "f32"
+            # "scored" is claimed only for the pairs that were multiplied: the tiles the blocks stepped through.  Every pair
+            # of the catalogue is DECIDED (ranked or excluded by a bound) at the rate beside it.
+            decided = line["value"]
+            line["pairs_decided_per_s"] = decided
+            line["value"] = decided * (scanned_frac if scanned_frac is not None else 1.0)
+            line["value_is"] = ("(user, dish) pairs multiplied per second, whole job: every pair of the catalogue is decided at "
+                                "pairs_decided_per_s, the share `roofline.scanned_fraction` of them by being scored -- the others by "
+                                "a bound on their mask pattern's scores (DESIGN.md 4.4)")
+            if sharded is not None and getattr(sharded, "last_allgather_events", None):
+                line["allgather_exposed_ms"] = sharded.last_allgather_events[0].elapsed_time(sharded.last_allgather_events[1])
             line["roofline"]["allgather_bytes_per_rank"] = tk_users.numel() * 80 if use_dist else 0
             line["roofline"]["repaired_users_last_launch"] = eng.get_option("topk_repaired")
         if not a.no_side and wl == "pairs":
@@ -1183,6 +1207,14 @@ def main():
                 line["with_ingredient_table"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if scaling is not None:
             line["scaling_path"] = scaling                              # ("scaling" itself is the contract's "weak" / "strong" string)
+            # the same as scalars of the line itself (a record that keeps only top-level scalar keys keeps these): the path
+            # north_star's ">= 6x at 8 GPUs" speaks of
+            line.update({"topk_path_ms": scaling.get("wall_ms"),
+                         "topk_path_pairs_decided_per_s": scaling.get("pairs_decided_per_s_whole_job"),
+                         "topk_path_pairs_multiplied_per_s": scaling.get("pairs_multiplied_per_s_whole_job"),
+                         "topk_path_allgather_exposed_ms": scaling.get("allgather_exposed_ms"),
+                         "topk_path_dtype": "bf16x3" if str(scaling.get("kernel", "")).endswith("bf16x3") else "f32",
+                         "topk_path_users_total": scaling.get("users_total"), "topk_path_dishes": scaling.get("dishes")})
         if topk_ag is not None:
             line["sharded_topk_allgather"] = topk_ag
         if routed is not None:

@@ -222,12 +222,74 @@ class UserShardedScorer:
             return s, ids
         return self._gather_topk(s, ids, users.numel(), k)
 
-    def topk_all_users(self, k: int, round_users: Optional[int] = None):
-        """Per-user top-k for EVERY user, on every rank: one all-gather of ``[shard, k] x (f32, i32)``.
-        Shards are padded to the common size ``per`` for the collective and trimmed afterwards.  `round_users`: the
-        local part runs in rounds of that many users (`topk_local_rounds`)."""
-        s, ids = self.topk_local_rounds(k, round_users) if round_users else self.topk_local(k)
-        if self._solo:
-            return s, ids
-        gs, gi = self._gather_topk(s, ids, self.per, k)
-        return gs[: self.num_users_total], gi[: self.num_users_total]
+    def topk_all_users(self, k: int, round_users: Optional[int] = None, pipelined: Optional[bool] = None):
+        """Per-user top-k for EVERY user, on every rank: ``[num_users_total, k]`` scores and dish ids, rank r's users at rows
+        ``[r * per, r * per + count_r)``.  Shards are padded to the common size ``per`` for the collective and trimmed
+        afterwards.  `round_users`: the local part runs in rounds of that many users.  With rounds the all-gather is
+        pipelined (`pipelined`, default on): round r's ``[rows, k] x (f32, i32)`` piece is gathered asynchronously while
+        round r + 1 is being ranked, so only the last round's exchange is exposed; `pipelined=False` ranks the whole shard
+        first and gathers once (the same result, bit for bit -- tests/test_sharding_gloo.py)."""
+        if pipelined is None:
+            pipelined = bool(round_users)
+        if self._solo or not (pipelined and round_users):
+            s, ids = self.topk_local_rounds(k, round_users) if round_users else self.topk_local(k)
+            if self._solo:
+                return s, ids
+            gs, gi = self._gather_topk(s, ids, self.per, k)
+            return gs[: self.num_users_total], gi[: self.num_users_total]
+        return self._topk_all_users_pipelined(k, int(round_users))
+
+    def _topk_all_users_pipelined(self, k: int, round_users: int):
+        """Rounds of `round_users` rows of the padded shard (every rank runs the same number of rounds of the same sizes, an
+        empty or short shard pads with (NaN, -1)): rank the round into this rank's piece, hand the piece to an asynchronous
+        all-gather -- the collective's stream waits for the ranking kernels queued so far and runs beside the next round's --
+        and, one round later, copy the gathered round into the result.  Two staging buffers alternate; the copy of round
+        r - 1 is queued (behind its all-gather, in front of round r + 1's kernels) before round r + 1 may overwrite a piece."""
+        world, per, dev = self.world, self.per, self.device
+        out_s = torch.empty((world, per, k), dtype=torch.float32, device=dev)
+        out_i = torch.empty((world, per, k), dtype=torch.int32, device=dev)
+        rows_max = min(round_users, per)
+        pieces = [torch.empty((2, rows_max, k), dtype=torch.int32, device=dev) for _ in range(2)]
+        stages = [torch.empty((world * 2, rows_max, k), dtype=torch.int32, device=dev) for _ in range(2)]     # rank-major pieces
+        into = getattr(self.scorer, "topk_users_into", None) if self.scorer is not None else None
+        pending = None                                          # (work, stage, lo, rows) of the round in flight
+        self.last_allgather_events = None
+
+        def finish(p):
+            work, stage, lo, rows = p
+            work.wait()                                         # the current stream waits for the collective; the host does not
+            stage = stage.view(world, 2, rows, k)
+            out_s[:, lo:lo + rows] = stage[:, 0].view(torch.float32)
+            out_i[:, lo:lo + rows] = stage[:, 1]
+
+        for r, lo in enumerate(range(0, per, round_users)):
+            rows = min(round_users, per - lo)                   # the same on every rank
+            n = max(0, min(rows, self.count - lo))              # rows of this round that hold users of this shard
+            piece, stage = pieces[r & 1], stages[r & 1]
+            ps, pi = piece[0, :rows].view(torch.float32), piece[1, :rows]
+            if n < rows:
+                ps[n:] = float("nan")
+                pi[n:] = -1
+            if n > 0:
+                users = torch.arange(self.base + lo, self.base + lo + n, dtype=torch.int32, device=dev)
+                if into is not None:
+                    into(users, k, ps[:n], pi[:n])
+                else:
+                    rs, ri = self.scorer.topk_users(users, k)
+                    ps[:n] = rs
+                    pi[:n] = ri
+            if pending is not None:
+                finish(pending)
+            src = piece if rows == rows_max else piece[:, :rows].contiguous()
+            dst = stage if rows == rows_max else torch.empty((world * 2, rows, k), dtype=torch.int32, device=dev)
+            work = dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True)
+            pending = (work, dst, lo, rows)
+        if dev.type == "cuda":                                  # bench.py: what of the exchange is NOT hidden behind ranking
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            finish(pending)
+            ev1.record()
+            self.last_allgather_events = (ev0, ev1)
+        else:
+            finish(pending)
+        return (out_s.view(world * per, k)[: self.num_users_total], out_i.view(world * per, k)[: self.num_users_total])

@@ -120,10 +120,11 @@ def _legs_worker(rank, world, port, out_dir):
             assert key in r1, key
         assert r1["own_slice_roundtrip_ok"] is True and r1["allgather_bytes_per_rank"] == 9 * k * 8
         assert r1["pairs_per_s_whole_job"] > 0
-        # (ii) scaling_path's leg: EVERY user of the shard in rounds (here of 7 users: 4 rounds), one all-gather
+        # (ii) scaling_path's leg: EVERY user of the shard in rounds (here of 7 users: 4 rounds), an all-gather per round issued
+        # asynchronously behind the next round's ranking
         sh = UserShardedScorer(eng, U, device=dev, always_collective=True)
         r2 = b.sharded_all_users_leg(torch, dist, sh, I, k, round_users=7, repeats=2)
-        for key in ("path", "users_total", "users_per_gpu", "rounds_per_gpu", "wall_ms", "topk_ms", "allgather_ms",
+        for key in ("path", "users_total", "users_per_gpu", "rounds_per_gpu", "wall_ms", "allgather_exposed_ms", "allgather",
                     "allgather_bytes_per_rank", "pairs_per_s_whole_job", "own_slice_roundtrip_ok"):
             assert key in r2, key
         assert r2["path"] == "sharded_topk_allgather" and r2["rounds_per_gpu"] == 4 and r2["users_total"] == U
@@ -131,7 +132,9 @@ def _legs_worker(rank, world, port, out_dir):
         # what the rounds produce is what one call produces, on every rank
         s_all, i_all = sh.topk_all_users(k, round_users=7)
         s_one, i_one = sh.topk_all_users(k)
+        s_two, i_two = sh.topk_all_users(k, round_users=7, pipelined=False)
         assert torch.equal(i_all, i_one) and torch.equal(s_all, s_one) and i_all.shape == (U, k)
+        assert torch.equal(i_all, i_two) and torch.equal(s_all, s_two)
         # (iii) pairs routed to the owners of their users
         r3 = b.routed_pairs_leg(torch, dist, eng, U_per, I, C, dev, world, 300, repeats=2)
         for key in ("pairs_per_gpu", "wall_ms_median", "pairs_per_s_whole_job", "own_pairs_match_local_scoring"):

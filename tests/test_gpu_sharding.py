@@ -60,6 +60,12 @@ def test_sharded_scorer_wraps_a_real_engine(nccl_world1, base):
     s, ids = sh.topk_all_users(10)
     assert s.shape == (U, 10) and ids.dtype == torch.int32
     rs, ri = oracle.topk_catalogue(PM, RE, CE, dish_cats, np.arange(64), 10)
+    # ... in rounds, each round's piece gathered asynchronously (RCCL's stream) behind the next round's kernels: the same bits
+    for ru in (U // 3 + 1, 257, U + 5):
+        s2, i2 = sh.topk_all_users(10, round_users=ru)
+        s3, i3 = sh.topk_all_users(10, round_users=ru, pipelined=False)
+        assert torch.equal(i2, ids) and torch.equal(s2, s) and torch.equal(i3, ids) and torch.equal(s3, s), ru
+        assert sh.last_allgather_events is not None
     s, ids = s.cpu().numpy(), ids.cpu().numpy()
     for u in range(64):
         full = oracle.inference_f64(PM, RE, CE, np.full(I, u), np.arange(I), dish_cats)

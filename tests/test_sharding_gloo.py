@@ -89,6 +89,14 @@ def _worker(rank, world, port, U, out_dir):
         s, ids = sh.topk_all_users(5)
         rs, ri = oracle.topk_catalogue(PM, RE, CE, dish_cats, np.arange(U), 5, dtype=np.float32)
         assert s.shape == (U, 5) and np.array_equal(ids.numpy(), ri) and np.array_equal(s.numpy(), rs.astype(np.float32))
+        # rounds with the all-gather pipelined behind the next round's ranking (an uneven last round, rounds larger than the
+        # shard, a last shard that is short or empty) == rounds with one gather at the end == no rounds at all
+        for ru in (1, 2, 3, 4, 7, 64):
+            s2, i2 = sh.topk_all_users(5, round_users=ru)
+            s3, i3 = sh.topk_all_users(5, round_users=ru, pipelined=False)
+            for a, b in ((s2, s), (s3, s)):
+                assert a.shape == (U, 5) and np.array_equal(a.numpy(), b.numpy(), equal_nan=True)
+            assert np.array_equal(i2.numpy(), ids.numpy()) and np.array_equal(i3.numpy(), ids.numpy())
         # an id no shard owns: refused on EVERY rank (collective check), in both forms
         for bad_user in (U, -1, 10 * U + 7):
             for fn in (sh.score_pairs, sh.score_pairs_routed):
@@ -102,7 +110,7 @@ def _worker(rank, world, port, U, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,U", [(2, 37), (3, 10), (2, 1)])
+@pytest.mark.parametrize("world,U", [(2, 37), (3, 10), (2, 1), (3, 13)])
 def test_user_sharded_scorer_gloo(tmp_path, world, U):
     mp.spawn(_worker, args=(world, _free_port(), U, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(os.path.join(tmp_path, "ok%d" % r)) for r in range(world))
