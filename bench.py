@@ -277,8 +277,9 @@ def cpu_baseline(torch, PM, RE, CE, users, items, cats, budget_s):
                              "what": "oracle/m2d_oracle.c, fused scalar loop, OpenMP"}}, ref, Bc
 
 
-def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10):
-    """Outside the timed region: full-catalogue top-k (m2d_topk_users, fp32 MFMA) for n_users users."""
+def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10, keep=None):
+    """Outside the timed region: full-catalogue top-k (m2d_topk_users, fp32 MFMA) for n_users users.  `keep`: a dict that
+    receives the last call's lists (`compare_lists`)."""
     g = torch.Generator(device=dev)
     g.manual_seed(11)
     pat = torch.randint(1, 2 ** C, (I,), generator=g, device=dev, dtype=torch.int32)
@@ -293,10 +294,12 @@ def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10):
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
     for i in range(reps):
         evs[i].record()
-        eng.topk_users(users, k)
+        last = eng.topk_users(users, k)
     evs[reps].record()
     torch.cuda.synchronize()
     eng.check()
+    if keep is not None:
+        keep["scores"], keep["ids"] = last
     ms = median([evs[i].elapsed_time(evs[i + 1]) for i in range(reps)])
     kernel = eng.last_kernel()
     dense = 2.0 * (C + 1) * E * n_users * I                 # the [users x (C+1)E] . [(C+1)E x dishes] contraction
@@ -328,6 +331,22 @@ def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10):
                           "frac_if_every_tile_were_scanned": 2.0 * E * n_users * I / ms / 1e9 / 157.3,
                           "note": "`frac` prices the flops EXECUTED (tiles of the blocks' relevant patterns), as for the split-bf16 kernel"}),
             "kernel": kernel}
+
+
+def compare_lists(torch, a, b):
+    """Dish ids are index output: how the default (split-bf16) lists differ from the exact-f32 kernel's for the same users.
+    Where two dishes' scores sit inside the split's rounding (3e-5 max(1, |s|), tests/test_gpu_catalogue.py) the two kernels
+    may order them differently; `max_gap_at_mismatch` is the largest |score difference| between the two kernels at a
+    position that holds different dishes, relative to max(1, |score|)."""
+    ia, ib, sa, sb = a["ids"], b["ids"], a["scores"], b["scores"]
+    diff = ia != ib
+    rows = diff.any(dim=1)
+    gap = ((sa - sb).abs() / sb.abs().clamp(min=1.0))[diff]
+    return {"lists_identical_frac": 1.0 - float(rows.float().mean().item()), "lists_differing": int(rows.sum().item()),
+            "positions_differing": int(diff.sum().item()),
+            "max_gap_at_mismatch": float(gap.max().item()) if gap.numel() else 0.0,
+            "max_score_difference": float(((sa - sb).abs() / sb.abs().clamp(min=1.0)).nan_to_num(nan=0.0).max().item()),
+            "what": "default split-bf16 lists against the exact-f32 kernel's (option topk_bf16x3 = 0), same users and dishes"}
 
 
 class _Clock:
@@ -1176,12 +1195,16 @@ def main():
                                              % (probe["GBps"], "%.0f" % traffic_probe if traffic_probe else "unrecorded")})
         if a.topk_users > 0 and not a.no_side and wl == "pairs":
             in_flight["leg"] = "catalogue_topk"
-            line["catalogue_topk"] = catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U))
+            lists_x3, lists_f32 = {}, {}
+            line["catalogue_topk"] = catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U), keep=lists_x3)
             eng.set_option("topk_bf16x3", 0)            # the exact-f32 kernel's figure beside the split-bf16 one (same users, same dishes)
             try:
-                line["catalogue_topk"]["exact_f32"] = catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U))
+                line["catalogue_topk"]["exact_f32"] = catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U),
+                                                                         keep=lists_f32)
             finally:
                 eng.set_option("topk_bf16x3", 1)
+            line["catalogue_topk"]["index_exactness"] = compare_lists(torch, lists_x3, lists_f32)
+            del lists_x3, lists_f32
             eng.set_option("topk_prune", 0)             # ... and the same kernel made to step through every tile: the MFMA-bound form
             try:
                 line["catalogue_topk"]["every_tile"] = catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U))
