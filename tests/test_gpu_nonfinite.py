@@ -267,8 +267,8 @@ def test_retrieval_after_write_memory_added_inf_takes_the_dense_kernel():
     # users that were not written to: the same lists (another kernel, another rounding: where two dishes change places their
     # scores are closer than the split-bf16 product's error)
     differ = i0[8:] != i1[8:]
-    assert differ.mean() < 0.02 and np.all(np.abs(s0[8:] - s1[8:])[differ] <= 3e-5)
-    assert np.all(np.abs(s0[8:] - s1[8:]) <= 3e-5)
+    close = np.abs(s0[8:] - s1[8:]) <= 3e-5 * np.maximum(1.0, np.abs(s1[8:]))        # (dish I - 1 scores ~1e36 for everybody)
+    assert differ.mean() < 0.02 and np.all(close)
     it = torch.arange(I, dtype=torch.int32, device="cuda")
     ct = torch.as_tensor(dish_cats, device="cuda")
     for u in range(8):
