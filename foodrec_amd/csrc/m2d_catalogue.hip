@@ -22,6 +22,14 @@
 
 #include "m2d_engine.h"
 
+// What is written is what runs: no floating-point contraction in this file.  hipcc's default (-ffp-contract=fast) fuses a
+// multiply into a following add wherever it sees one -- ALSO through __fmul_rn / __fadd_rn, and not in every copy of an
+// unrolled loop: the repair scan's blend a * alpha + b * low came out as v_pk_mul + v_add for the first of a group's two
+// dishes in flight and as v_mul + v_fmac (one rounding fewer) for the second, so a re-ranked user's last score bit depended on
+// which of the two places a dish landed in (found when the scan's dish order began to depend on the listed users' masks).
+// Every fused multiply-add in this file is an explicit fmaf or an MFMA.
+#pragma clang fp contract(off)
+
 // Timing-only ablation hooks for scripts/diag/topk_diag.cpp (never defined in the product build):
 // bit 0 = no epilogue, bit 1 = no LDS-DMA refill, bit 2 = no per-stage barrier/wait, bit 3 = epilogue
 // fast path only (no insertions).  Outputs are wrong.
@@ -620,6 +628,11 @@ struct RepairArgs {
     int32_t C, E, k;
     int32_t cap;                                // listed users the scan / merge pair handles (the rest: m2d_topk_repair_rest)
     float a, b;
+    const float *rows;                          // the pattern-sorted f32 dish table (GroupedArgs::rs), row stride ew floats
+    const int32_t *perm;                        // slot -> dish id
+    const int32_t *grp;                         // [0..15] first slot of each pattern's group, [40..55] rows per pattern
+    const float *plan;                          // the call's plan records (word 5: relevant-pattern mask), or null = every pattern
+    int32_t ew;
     float *part_s;                              // [cap, REPAIR_SPLITS, k] partial lists
     int32_t *part_i;
     float *out_scores;                          // [nU, k]
@@ -655,8 +668,6 @@ __global__ __launch_bounds__(1024) void m2d_topk_repair_scan(RepairArgs p)
     __shared__ float hc[UB][C], alpha[UB][NP];              // <U_high, CE_c>; sum over the pattern's categories (:67-75)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, j = lane & 15, grp = t >> 4;
     const int count = min(p.tie_list[0], p.cap);
-    const int64_t per = (p.I + REPAIR_SPLITS - 1) / REPAIR_SPLITS;
-    const int64_t d0 = (int64_t)blockIdx.x * per, d1 = min(p.I, d0 + per);
     for (int f0 = blockIdx.y * UB; f0 < count; f0 += gridDim.y * UB) {   // block-uniform
         const int nu = min(UB, count - f0);
         __syncthreads();
@@ -697,90 +708,118 @@ __global__ __launch_bounds__(1024) void m2d_topk_repair_scan(RepairArgs p)
         }
         __syncthreads();
         const v4f *um4 = reinterpret_cast<const v4f *>(um), *wp4 = reinterpret_cast<const v4f *>(wp);
-        // the masks and the first 16 float4 columns of the NEXT step's dishes are fetched while this step's are scored (a step
-        // is one round trip to memory otherwise: 12 steps, 3 us each)
-        v4f m_n[ND], it_n[ND], hv_n[ND];
-        auto fetch = [&](const int64_t db) __attribute__((always_inline)) {
-#pragma unroll
-            for (int x = 0; x < ND; ++x) {
-                const int64_t d = db + x * NG + grp;
-                const int64_t da = d < d1 ? d : d0;
-                m_n[x] = *reinterpret_cast<const v4f *>(p.cats + (size_t)da * C);
-                if (j < E4) {
-                    it_n[x] = reinterpret_cast<const v4f *>(p.re)[(size_t)da * E4 + j];
-                    if (HVR) hv_n[x] = reinterpret_cast<const v4f *>(p.hv)[(size_t)da * E4 + j];
-                }
-            }
-        };
-        if (d0 < d1) fetch(d0);
-        for (int64_t db = d0; db < d1; db += ND * NG) {     // wave-uniform trip count: the shuffles see a full EXEC
-            int64_t dd[ND];
-            bool ok[ND];
-            int pt[ND];
-            float hs[ND][UB], lo[ND][UB];
-            v4f it0[ND], hv0[ND];
-#pragma unroll
-            for (int x = 0; x < ND; ++x) {
-                const int64_t d = db + x * NG + grp;
-                ok[x] = d < d1;
-                dd[x] = ok[x] ? d : d0;
-                const v4f m = m_n[x];
-                it0[x] = it_n[x];
-                hv0[x] = hv_n[x];
-                pt[x] = (m.x != 0.f ? 1 : 0) | (m.y != 0.f ? 2 : 0) | (m.z != 0.f ? 4 : 0) | (m.w != 0.f ? 8 : 0);
-#pragma unroll
-                for (int ub = 0; ub < UB; ++ub) hs[x][ub] = lo[x][ub] = 0.f;
-            }
-            if (db + ND * NG < d1) fetch(db + ND * NG);
-            for (int q = j; q < E4; q += 16) {
-                v4f it[ND], hvv[ND];
+        // The dishes come from the pattern-sorted f32 table (rows: exact copies of Recipe_Embedding's, [H[d] | RE[d]] with the
+        // ingredient extension; perm: slot -> dish id), group by group, and only the groups of patterns that can reach the top-k of
+        // one of this pass's users (the union of their plan masks -- the bounds hold for this kernel's f32 arithmetic as for the
+        // scan kernels', grouped_pattern_terms): a listed user has 1.3 relevant patterns on average, so a pass of four reads a
+        // third of the table.  The relevant rows are dealt out evenly to the REPAIR_SPLITS blocks.  Slots are not in id order
+        // across norm buckets, so an insertion compares (score desc, id asc) explicitly.
+        uint32_t rel = 0xfffeu;
+        if (p.plan) {
+            rel = 0u;
+            for (int ub = 0; ub < nu; ++ub) rel |= __float_as_uint(p.plan[(size_t)p.tie_list[1 + f0 + ub] * 8 + 5]);
+        }
+        int64_t R = 0;
+        for (int q = 1; q < NP; ++q) R += ((rel >> q) & 1u) ? p.grp[40 + q] : 0;
+        const int64_t per = (R + REPAIR_SPLITS - 1) / REPAIR_SPLITS;
+        const int64_t i0 = (int64_t)blockIdx.x * per, i1 = min(R, i0 + per);
+        const int EW4 = p.ew >> 2;
+        const v4f *rows4 = reinterpret_cast<const v4f *>(p.rows);
+        int64_t cum = 0;                                    // relevant rows in front of pattern q's group
+        for (int q = 1; q < NP; ++q) {                      // block-uniform
+            const int64_t rows_q = ((rel >> q) & 1u) ? p.grp[40 + q] : 0;
+            const int64_t lo_i = i0 > cum ? i0 : cum, hi_i = i1 < cum + rows_q ? i1 : cum + rows_q;
+            const int64_t d0 = p.grp[q] + (lo_i - cum), d1 = p.grp[q] + (hi_i - cum);     // this block's slots of the group
+            cum += rows_q;
+            if (lo_i >= hi_i) continue;
+            const float npat = (float)__builtin_popcount(q);                                 // :77
+            // the ids and the first 16 float4 columns of the NEXT step's dishes are fetched while this step's are scored (a step
+            // is one round trip to memory otherwise)
+            v4f it_n[ND], hv_n[ND];
+            int32_t id_n[ND];
+            auto fetch = [&](const int64_t db) __attribute__((always_inline)) {
 #pragma unroll
                 for (int x = 0; x < ND; ++x) {
-                    if (q == j) {
-                        it[x] = it0[x];
-                        hvv[x] = hv0[x];
-                    } else {
-                        it[x] = reinterpret_cast<const v4f *>(p.re)[(size_t)dd[x] * E4 + q];
-                        if (HVR) hvv[x] = reinterpret_cast<const v4f *>(p.hv)[(size_t)dd[x] * E4 + q];
+                    const int64_t d = db + x * NG + grp;
+                    const int64_t da = d < d1 ? d : d0;
+                    id_n[x] = p.perm[da];
+                    if (j < E4) {
+                        it_n[x] = rows4[(size_t)da * EW4 + (HVR ? E4 : 0) + j];
+                        if (HVR) hv_n[x] = rows4[(size_t)da * EW4 + j];
+                    }
+                }
+            };
+            fetch(d0);
+            for (int64_t db = d0; db < d1; db += ND * NG) { // wave-uniform trip count: the shuffles see a full EXEC
+                int64_t dd[ND];
+                int32_t did[ND];
+                bool ok[ND];
+                float hs[ND][UB], lo[ND][UB];
+                v4f it0[ND], hv0[ND];
+#pragma unroll
+                for (int x = 0; x < ND; ++x) {
+                    const int64_t d = db + x * NG + grp;
+                    ok[x] = d < d1;
+                    dd[x] = ok[x] ? d : d0;
+                    did[x] = id_n[x];
+                    it0[x] = it_n[x];
+                    hv0[x] = hv_n[x];
+#pragma unroll
+                    for (int ub = 0; ub < UB; ++ub) hs[x][ub] = lo[x][ub] = 0.f;
+                }
+                if (db + ND * NG < d1) fetch(db + ND * NG);
+                for (int c4 = j; c4 < E4; c4 += 16) {
+                    v4f it[ND], hvv[ND];
+#pragma unroll
+                    for (int x = 0; x < ND; ++x) {
+                        if (c4 == j) {
+                            it[x] = it0[x];
+                            hvv[x] = hv0[x];
+                        } else {
+                            it[x] = rows4[(size_t)dd[x] * EW4 + (HVR ? E4 : 0) + c4];
+                            if (HVR) hvv[x] = rows4[(size_t)dd[x] * EW4 + c4];
+                        }
+                    }
+#pragma unroll
+                    for (int ub = 0; ub < UB; ++ub) {
+                        if (ub < nu) {                      // block-uniform
+                            const v4f w = wp4[(ub * NP + q) * E4 + c4];
+#pragma unroll
+                            for (int x = 0; x < ND; ++x) {
+                                lo[x][ub] = fmaf(it[x].x, w.x, fmaf(it[x].y, w.y, fmaf(it[x].z, w.z, fmaf(it[x].w, w.w, lo[x][ub]))));
+                                if (HVR) {
+                                    const v4f uh = um4[ub * (W >> 2) + c4];
+                                    hs[x][ub] = fmaf(uh.x, hvv[x].x, fmaf(uh.y, hvv[x].y, fmaf(uh.z, hvv[x].z, fmaf(uh.w, hvv[x].w, hs[x][ub]))));
+                                }
+                            }
+                        }
                     }
                 }
 #pragma unroll
                 for (int ub = 0; ub < UB; ++ub) {
                     if (ub < nu) {                          // block-uniform
+                        // sum over the 16 lanes of a row: four rotations (DPP row_ror 8, 4, 2, 1; the same pairs as an xor butterfly,
+                        // so every lane ends with the same bits) -- no LDS round trip (ds_bpermute) per step
 #pragma unroll
                         for (int x = 0; x < ND; ++x) {
-                            const v4f w = wp4[(ub * NP + pt[x]) * E4 + q];
-                            lo[x][ub] = fmaf(it[x].x, w.x, fmaf(it[x].y, w.y, fmaf(it[x].z, w.z, fmaf(it[x].w, w.w, lo[x][ub]))));
-                            if (HVR) {
-                                const v4f uh = um4[ub * (W >> 2) + q];
-                                hs[x][ub] = fmaf(uh.x, hvv[x].x, fmaf(uh.y, hvv[x].y, fmaf(uh.z, hvv[x].z, fmaf(uh.w, hvv[x].w, hs[x][ub]))));
-                            }
+                            lo[x][ub] = row16_sum(lo[x][ub]);
+                            if (HVR) hs[x][ub] = row16_sum(hs[x][ub]);
                         }
-                    }
-                }
-            }
 #pragma unroll
-            for (int ub = 0; ub < UB; ++ub) {
-                if (ub < nu) {                              // block-uniform
-                    // sum over the 16 lanes of a row: four rotations (DPP row_ror 8, 4, 2, 1; the same pairs as an xor butterfly,
-                    // so every lane ends with the same bits) -- no LDS round trip (ds_bpermute) per step
-#pragma unroll
-                    for (int x = 0; x < ND; ++x) {
-                        lo[x][ub] = row16_sum(lo[x][ub]);
-                        if (HVR) hs[x][ub] = row16_sum(hs[x][ub]);
-                    }
-#pragma unroll
-                    for (int x = 0; x < ND; ++x) {          // ascending id inside a group: x = 0 first
-                        const float n = (float)__builtin_popcount(pt[x]);                    // :77 (an empty mask: 0 / 0 = NaN, never enters)
-                        float sc = __fadd_rn(__fmul_rn(p.a, HVR ? hs[x][ub] : alpha[ub][pt[x]]), __fmul_rn(p.b, lo[x][ub] / n));   // :79 (done above), :92, :95-96
-                        sc = ok[x] ? fmaxf(sc, -INFINITY) : -INFINITY;                       // NaN -> -inf: never enters
-                        // left neighbour's slot (lane j - 1 of the same 16-lane row; lane 0 sees +inf / -1)
-                        const float left_s = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, INFINITY),
-                                                                __builtin_bit_cast(int, slot_s[ub]), 0x111, 0xf, 0xf, false));
-                        const int32_t left_i = __builtin_amdgcn_update_dpp(-1, slot_i[ub], 0x111, 0xf, 0xf, false);
-                        const bool above_left = sc > left_s, above_me = sc > slot_s[ub];     // strict: equal scores keep the earlier (lower) id first
-                        slot_i[ub] = above_left ? left_i : (above_me ? (int32_t)dd[x] : slot_i[ub]);
-                        slot_s[ub] = above_left ? left_s : (above_me ? sc : slot_s[ub]);
+                        for (int x = 0; x < ND; ++x) {
+                            float sc = m2d_blend_unfused(p.a, HVR ? hs[x][ub] : alpha[ub][q], p.b, lo[x][ub] / npat);   // :79 (done above), :92, :95-96
+                            sc = ok[x] ? fmaxf(sc, -INFINITY) : -INFINITY;                   // NaN -> -inf: never enters
+                            const int32_t id = ok[x] ? did[x] : 0x7fffffff;
+                            // left neighbour's slot (lane j - 1 of the same 16-lane row; lane 0 sees +inf / -1)
+                            const float left_s = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, INFINITY),
+                                                                    __builtin_bit_cast(int, slot_s[ub]), 0x111, 0xf, 0xf, false));
+                            const int32_t left_i = __builtin_amdgcn_update_dpp(-1, slot_i[ub], 0x111, 0xf, 0xf, false);
+                            // (score desc, id asc); an empty slot holds (-inf, -1): any real score is above it, -inf never is
+                            const bool above_left = sc > left_s || (sc == left_s && sc > -INFINITY && id < left_i);
+                            const bool above_me = sc > slot_s[ub] || (sc == slot_s[ub] && sc > -INFINITY && id < slot_i[ub]);
+                            slot_i[ub] = above_left ? left_i : (above_me ? id : slot_i[ub]);
+                            slot_s[ub] = above_left ? left_s : (above_me ? sc : slot_s[ub]);
+                        }
                     }
                 }
             }
@@ -913,7 +952,7 @@ __global__ __launch_bounds__(256) void m2d_topk_repair_finish(RepairArgs p)
             lo = row16_sum(lo);
             if (HVR) hs = row16_sum(hs);
             const float n = (float)__builtin_popcount(pt);                                    // :77
-            float sc = __fadd_rn(__fmul_rn(p.a, HVR ? hs : alpha[pt]), __fmul_rn(p.b, lo / n));   // :79, :92, :95-96
+            float sc = m2d_blend_unfused(p.a, HVR ? hs : alpha[pt], p.b, lo / n);   // :79, :92, :95-96
             sc = ok ? fmaxf(sc, -INFINITY) : -INFINITY;                                       // NaN -> -inf: never enters
             const float left_s = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, INFINITY),
                                                     __builtin_bit_cast(int, slot_s), 0x111, 0xf, 0xf, false));
@@ -1381,7 +1420,7 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const v4f w = ce4[c * E4 + q];
-            hc[c] += (uh.x * w.x + uh.y * w.y) + (uh.z * w.z + uh.w * w.w);
+            hc[c] += fmaf(uh.x, w.x, uh.y * w.y) + fmaf(uh.z, w.z, uh.w * w.w);
             ha[c] += (fabsf(uh.x * w.x) + fabsf(uh.y * w.y)) + (fabsf(uh.z * w.z) + fabsf(uh.w * w.w));
             r[c] = pmu[(c + 1) * E4 + q];
         }
@@ -1389,7 +1428,7 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int d = c; d < 4; ++d, ++i) G[i] += (r[c].x * r[d].x + r[c].y * r[d].y) + (r[c].z * r[d].z + r[c].w * r[d].w);
+            for (int d = c; d < 4; ++d, ++i) G[i] += fmaf(r[c].x, r[d].x, r[c].y * r[d].y) + fmaf(r[c].z, r[d].z, r[c].w * r[d].w);
     }
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) {
@@ -2146,6 +2185,8 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
     constexpr int EU = HV ? E / 2 : E;                     // embedding width of the user tables
     constexpr int S4 = EU / 4;                             // float4 per f32 row of Personal_Memory
     constexpr int RPK = 16 / KS;                           // compares of the previous tile per k-step
+    constexpr bool SHARE = !(E == 128 && KR == 16 && !HV);  // thresholds shared between dish ranges (p.shared_thr) -- not in the one
+                                                           // instantiation where their registers do not fit (254 VGPRs + 4 spilled)
     constexpr int AR = KS < 4 ? KS : 4;                    // A-fragment register sets: the LDS reads run AR k-steps ahead
     static_assert(PIECES % WAVES == 0 && (WAVES * 64) % S8 == 0 && ((WAVES * 64 / S8) / RPB) % S8 == 0, "piece layout");
 
@@ -2193,7 +2234,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
 #pragma unroll
         for (int c = 0; c < C; ++c) hc[g][c] = rec[1 + c];
         seed[g] = uvalid[g] ? rec[0] : INFINITY;            // a lane without a user never has a candidate
-        if (p.shared_thr && uvalid[g])                      // what the user's other dish ranges have reached so far (see exchange_thresholds)
+        if (SHARE && p.shared_thr && uvalid[g])             // what the user's other dish ranges have reached so far (see exchange_thresholds)
             seed[g] = fmaxf(seed[g], thr_unkey(__hip_atomic_load(p.shared_thr + (size_t)uidx[g] * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
         umask_lane |= uvalid[g] ? __float_as_uint(rec[5]) : 0u;
     }
@@ -2465,7 +2506,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
             ps_m1 = ps_0;
             ps_0 = ps_p1;
             ps_p1 = next_stage();
-            if (p.shared_thr) exchange_thresholds();
+            if (SHARE && p.shared_thr) exchange_thresholds();
         }
         if (KS > AR && sub == 1) {
             // With more k-steps than fragment sets (E = 128: KS = 8, AR = 4) a tile's last KS - AR k-steps are read one step
@@ -2666,7 +2707,7 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
             tie_mask[g] = tie_update(tie_mask[g], fmaxf(px[g], -INFINITY), ol, rs[g][KR - 1]);
         }
     }
-    if (p.shared_thr && n > 0) {                           // what this range ends with: ranges of the user that start later begin there
+    if (SHARE && p.shared_thr && n > 0) {                  // what this range ends with: ranges of the user that start later begin there
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             share_threshold(g);
@@ -2994,6 +3035,8 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         r.pm = h->pm; r.re = h->re; r.ce = h->ce; r.cats = h->dish_cats; r.hv = HV ? h->dish_high : nullptr;
         r.users = users; r.tie_list = tie_list; r.nU = nU; r.U = h->U; r.I = h->I; r.user_base = h->user_base;
         r.C = h->C; r.E = h->E; r.k = k; r.a = h->a; r.b = h->b; r.out_scores = final_s; r.out_ids = final_i;
+        r.rows = h->grp_rs; r.perm = h->grp_perm; r.grp = a.grp; r.ew = h->grp_ew;
+        r.plan = (a.plan && h->opt_topk_prune != 9) ? a.plan : nullptr;      // "topk_prune" = 9: the repair reads every pattern (A/B)
         r.cap = h->opt_variant == 13 ? 2 : REPAIR_CAP;      // test hook: send all but two listed users to the one-block-per-user kernel
         r.part_s = h->topk_flags + tie_vals + 1 + (size_t)nU;
         r.part_i = reinterpret_cast<int32_t *>(r.part_s + (size_t)REPAIR_CAP * REPAIR_SPLITS * k);

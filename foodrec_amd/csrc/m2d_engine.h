@@ -154,6 +154,19 @@ static inline hipError_t m2d_lds_limit(const void *fn, int bytes)
     return e;
 }
 
+// a * x + b * y as TF's Mul, Mul, Add compute Model_Recommender.py:95-96: two rounded products, one rounded sum.
+// __fadd_rn(__fmul_rn(a, x), __fmul_rn(b, y)) does not guarantee that -- the device library's bodies carry the `contract` flag,
+// and hipcc 7.2 fused the second product into the add (v_fmac, one rounding fewer) in SOME copies of an unrolled loop: the same
+// (user, dish) then scored one ulp apart depending on the slot it was computed in (m2d_catalogue.hip, repair scan).  Plain
+// operators under `fp contract(off)` carry no such flag, also after inlining.
+__device__ __forceinline__ float m2d_blend_unfused(const float a, const float x, const float b, const float y)
+{
+#pragma clang fp contract(off)
+    const float p = a * x;
+    const float q = b * y;
+    return p + q;
+}
+
 // ---- device helpers shared by the LDS-DMA kernels (m2d_catalogue.hip, m2d_mlp.hip) ----
 // vmcnt(0) twice over: the builtin is an s_waitcnt the compiler's own counter model sees (so it stops assuming that
 // loads from a previous loop trip are still in flight), the asm one cannot be optimised away on the grounds that

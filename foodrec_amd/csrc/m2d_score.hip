@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4(ScoreArgs p)
             if constexpr (use_uh) my_high = fmaf(m.w, uhv.w, fmaf(m.z, uhv.z, fmaf(m.y, uhv.y, m.x * uhv.x)));
             const float high = HV ? my_high : my_high / n;                     // :79 (H[d] is already normalised)
             const float low = my_low / n;                                      // :92
-            float score = __fadd_rn(__fmul_rn(p.a, high), __fmul_rn(p.b, low));     // :95-96, no fma contraction
+            float score = m2d_blend_unfused(p.a, high, p.b, low);     // :95-96, no fma contraction
             if (bad) score = __builtin_nanf("");
             p.out[pi] = score;
         }
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_c4_small(ScoreArgs p)
             const float n = (m.x + m.y) + (m.z + m.w);                         // :77
             const float high = HV ? hs : hs / n;                               // :79
             const float low = ls / n;                                          // :92
-            float score = __fadd_rn(__fmul_rn(p.a, high), __fmul_rn(p.b, low));     // :95-96
+            float score = m2d_blend_unfused(p.a, high, p.b, low);     // :95-96
             if (bad) score = __builtin_nanf("");
             p.out[pi] = score;
         }
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_cn(ScoreArgs p)
         if (valid) {
             const float high = my_high / n;                                    // :79
             const float low = my_low / n;                                      // :92
-            float score = __fadd_rn(__fmul_rn(p.a, high), __fmul_rn(p.b, low));     // :95-96, no fma contraction
+            float score = m2d_blend_unfused(p.a, high, p.b, low);     // :95-96, no fma contraction
             if (bad) score = __builtin_nanf("");
             p.out[pi] = score;
         }
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void m2d_score_pairs_generic(ScoreArgs p)
         hs = group_sum<64>(hs);
         ls = group_sum<64>(ls);
         if (lane == 0) {
-            float score = __fadd_rn(__fmul_rn(p.a, p.hv ? hs : hs / n), __fmul_rn(p.b, ls / n));
+            float score = m2d_blend_unfused(p.a, p.hv ? hs : hs / n, p.b, ls / n);
             if (bad) score = __builtin_nanf("");
             p.out[pi] = score;
         }

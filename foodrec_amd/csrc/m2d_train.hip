@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void m2d_train_grad(TrainArgs p, int ce_lds)
         }
         hi = wave_sum(hi);
         lo = wave_sum(lo);
-        const float s = __fadd_rn(__fmul_rn(p.a, hi / n), __fmul_rn(p.b, lo / n));  // :79, :93, :95-96
+        const float s = m2d_blend_unfused(p.a, hi / n, p.b, lo / n);  // :79, :93, :95-96
         const float y = p.labels[b];
         const float loss_b = fmaxf(s, 0.f) - s * y + log1pf(expf(-fabsf(s)));       // :101
         const float gs = (1.0f / (1.0f + expf(-s)) - y) * invB;                     // d mean / d s_b
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void m2d_train_grad_fused(TrainArgs p)
         }
         hi = wave_sum(hi);
         lo = wave_sum(lo);
-        const float s = __fadd_rn(__fmul_rn(p.a, hi / n), __fmul_rn(p.b, lo / n));  // :79, :93, :95-96
+        const float s = m2d_blend_unfused(p.a, hi / n, p.b, lo / n);  // :79, :93, :95-96
         // -1: the row was free and this lane numbers it; anything else: the number, once it is there.  Two statements, in this
         // order, not the two arms of one `if`: a wave whose lane 0 numbers a row while its lane 1 waits for another wave's
         // number must publish BEFORE it waits -- with the arms in the other order two such waves, each holding the row the

@@ -1,4 +1,4 @@
-mkdir -p gpurun_out/r03/p2; export TMPDIR=/tmp
+mkdir -p gpurun_out/r04/p2; export TMPDIR=/tmp
 cat > /tmp/pp.py <<'PY'
 import sys, os
 sys.path.insert(0, os.getcwd())
@@ -19,11 +19,11 @@ for _ in range(12):
     eng.topk_users(users, 10)
 eng.check()
 PY
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03/p2 -- python3 /tmp/pp.py $1 $2 $3 > gpurun_out/r03/p2/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r04/p2 -- python3 /tmp/pp.py $1 $2 $3 > gpurun_out/r04/p2/log.txt 2>&1
 python3 - <<PY
 import csv,glob,collections
 d=collections.defaultdict(list)
-for f in glob.glob("gpurun_out/r03/p2/**/*kernel_trace.csv",recursive=True):
+for f in glob.glob("gpurun_out/r04/p2/**/*kernel_trace.csv",recursive=True):
     for r in csv.DictReader(open(f)):
         d[r["Kernel_Name"]].append((int(r["Start_Timestamp"]),int(r["End_Timestamp"])-int(r["Start_Timestamp"])))
 for k,v in sorted(d.items(), key=lambda kv:-sum(x[1] for x in kv[1])):
@@ -31,4 +31,4 @@ for k,v in sorted(d.items(), key=lambda kv:-sum(x[1] for x in kv[1])):
         last=[x[1] for x in sorted(v)[-10:]]
         print("%-70s n=%3d last10 avg %.1f us"%(k[:70],len(v),sum(last)/len(last)/1e3))
 PY
-rm -rf gpurun_out/r03/p2
+rm -rf gpurun_out/r04/p2

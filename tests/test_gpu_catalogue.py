@@ -454,3 +454,32 @@ def test_more_than_64_dish_ranges_come_in_whole_groups(E, x3, nU, I):
     s1, i1 = eng.topk_users(users, k); eng.check()
     assert torch.equal(i0, i1) and torch.equal(s0.nan_to_num(nan=-7.0), s1.nan_to_num(nan=-7.0))
     _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:40], k, dup=20)
+
+
+@pytest.mark.parametrize("E,x3", [(64, 1), (128, 1), (64, 0), (200, 0)])
+def test_re_ranked_scores_do_not_depend_on_where_a_dish_was_scored(E, x3):
+    """The tie repair scans the pattern-sorted table, the groups of its listed users' relevant patterns only ("topk_prune" = 9:
+    every group), so which block, lane group and in-flight slot scores a dish depends on who else is listed in the same pass.
+    The score must not: hipcc fused the blend's second product into its add in one of the two in-flight copies (one rounding
+    fewer; seen as one score of a re-ranked user one ulp apart between option forms).  Coarse tables: hundreds of listed users."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    U, I, k = 3000, 6000, 10
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=E + 5, dup=300)
+    PM, RE, CE = (np.round(PM * 16) / 16).astype(np.float32), (np.round(RE * 16) / 16).astype(np.float32), (np.round(CE * 16) / 16).astype(np.float32)
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    eng.set_option("topk_bf16x3", x3)
+    users = torch.as_tensor(np.random.default_rng(E).permutation(U).astype(np.int32), device="cuda")
+    out = {}
+    for prune, forced in ((0, 101), (1, 0), (9, 0), (1, 103), (9, 107), (1, 0)):
+        eng.set_option("topk_prune", prune); eng.set_option("variant", forced)
+        s, i = eng.topk_users(users, k); eng.check()
+        out.setdefault((prune, forced), []).append((s.cpu().numpy(), i.cpu().numpy(), eng.get_option("topk_repaired")))
+    s0, i0, rep = out[0, 101][0]
+    assert rep >= 100, rep                                 # the tables do send many users through the repair
+    for key, runs in out.items():
+        for s, i, r in runs:
+            assert np.array_equal(i, i0) and np.array_equal(s.view(np.int32), s0.view(np.int32)), (key, r, rep)
+    eng.set_option("topk_prune", 1); eng.set_option("variant", 0)
+    _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:40], k, dup=300)
