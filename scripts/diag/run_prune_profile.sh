@@ -15,6 +15,7 @@ cats = ((pat[:, None] >> torch.arange(C, device="cuda", dtype=torch.int32)[None,
 eng = foodrec_amd.ScoringEngine(PM, RE, CE); eng.set_dish_categories(cats)
 users = torch.randperm(U, generator=g, device="cuda")[:n].to(torch.int32)
 eng.set_option("variant", var)
+eng.set_option("topk_prune", int(os.environ.get("PRUNE", "1")))
 for _ in range(12):
     eng.topk_users(users, 10)
 eng.check()
