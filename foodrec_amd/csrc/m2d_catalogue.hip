@@ -2653,10 +2653,19 @@ __global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedAr
                         while (__ballot(rm != 0u) != 0ull) {        // wave-uniform; a lane's rows in ascending order
                             const bool has = rm != 0u;
                             const int r = __builtin_clz(rm | 1u) - 16;
-                            float xv = -INFINITY;
+                            // the lane's row r out of its sixteen accumulators: a binary tree of selects on the bits of r (four
+                            // lane masks + fifteen v_cndmask; sixteen compares + sixteen selects before)
+                            const unsigned long long b0 = __ballot((r & 1) != 0), b1 = __ballot((r & 2) != 0), b2 = __ballot((r & 4) != 0),
+                                                     b3 = __ballot((r & 8) != 0);
+                            float t8[8], t4[4], t2[2];
 #pragma unroll
-                            for (int q = 0; q < 16; ++q) xv = (has && r == q) ? accP[g][q] : xv;
-                            xv += alpha_prev[g];                    // (-inf stays -inf: a lane without a candidate inserts nothing)
+                            for (int q = 0; q < 8; ++q) t8[q] = __int_as_float(lane_select(b0, __float_as_int(accP[g][2 * q + 1]), __float_as_int(accP[g][2 * q])));
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) t4[q] = __int_as_float(lane_select(b1, __float_as_int(t8[2 * q + 1]), __float_as_int(t8[2 * q])));
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) t2[q] = __int_as_float(lane_select(b2, __float_as_int(t4[2 * q + 1]), __float_as_int(t4[2 * q])));
+                            float xv = __int_as_float(lane_select(b3, __float_as_int(t2[1]), __float_as_int(t2[0])));
+                            xv = has ? xv + alpha_prev[g] : -INFINITY;    // a lane without a candidate inserts nothing
                             const float ol = rs[g][KR - 1];
                             sorted_insert_inplace<KR>(rs[g], ri[g], xv, sbase + (r & 3) + 8 * (r >> 2));
                             tie_mask[g] = tie_update(tie_mask[g], xv, ol, rs[g][KR - 1]);
