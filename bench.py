@@ -315,7 +315,7 @@ def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10, ke
     if kernel.startswith("m2d_topk_grouped"):              # these kernels step through their blocks' relevant patterns only
         scanned, full = eng.get_option("topk_tiles_scanned"), eng.get_option("topk_tiles_full")
         if scanned > 0:
-            flops = 2.0 * E * 256 * 32 * scanned            # a block is 256 user lanes, a tile 32 dishes
+            flops = 2.0 * E * eng.get_option("topk_block_users") * 32 * scanned     # a block's user lanes (256, or 128) x a tile's 32 dishes
     return {"users": n_users, "dishes": I, "k": k, "median_ms": ms, "users_per_s": n_users / ms * 1e3,
             "pairs_per_s": n_users * I / ms * 1e3, "tflops": flops / ms / 1e9,
             "dense_equivalent_tflops": dense / ms / 1e9,

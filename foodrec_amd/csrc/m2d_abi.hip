@@ -763,6 +763,7 @@ int m2d_set_option(m2d_engine *h, const char *name, int64_t value)
     else if (!strcmp(name, "topk_bf16x3")) h->opt_topk_bf16x3 = (int)value;
     else if (!strcmp(name, "topk_form")) h->opt_topk_form = (int)value;
     else if (!strcmp(name, "topk_prune")) h->opt_topk_prune = (int)value;
+    else if (!strcmp(name, "topk_block")) h->opt_topk_block = (int)value;
     else if (!strcmp(name, "topk_grouped")) h->opt_topk_grouped = (int)value;
     else if (!strcmp(name, "mlp_bf16x3")) h->opt_mlp_bf16x3 = (int)value;
     else if (!strcmp(name, "mlp_form")) h->opt_mlp_form = (int)value;
@@ -783,6 +784,8 @@ int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value)
     else if (!strcmp(name, "topk_bf16x3")) *value = h->opt_topk_bf16x3;
     else if (!strcmp(name, "topk_form")) *value = h->opt_topk_form;
     else if (!strcmp(name, "topk_prune")) *value = h->opt_topk_prune;
+    else if (!strcmp(name, "topk_block")) *value = h->opt_topk_block;
+    else if (!strcmp(name, "topk_block_users")) *value = h->topk_block_users;
     else if (!strcmp(name, "topk_tiles_scanned") || !strcmp(name, "topk_tiles_full")) {
         // diagnostic (synchronises the device): 32-dish tiles the blocks of the last pipelined retrieval launch stepped
         // through, and what they would have stepped through without pattern pruning

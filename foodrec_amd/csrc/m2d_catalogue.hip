@@ -1705,6 +1705,9 @@ __device__ __forceinline__ void grouped_publish(float *ls, int32_t *li, const fl
     }
 }
 
+#ifndef M2D_TOPK_HALF_BLOCKS
+#define M2D_TOPK_HALF_BLOCKS 1                             // the launcher's own choice of 128-user blocks (see launch_grouped)
+#endif
 constexpr int grouped_tiles_per_stage(int E) { return E <= 32 ? 16 : (E == 64 ? 8 : (E == 128 ? 4 : 2)); }   // 64 KiB stages
 
 // PAD: the tables' embedding size is p.e_real <= E (a multiple of 4): the sorted dish rows are zero-padded to E floats
@@ -2169,14 +2172,18 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
 // Thresholds are one insertion stale when tile q-2 is compared: more candidates, never fewer.
 // HV = true: the ingredient extension.  Dish rows are [H[d] | RE[d]] (E = 2 x the embedding width) and the user operand
 // is [a U_high | w_P]: score = <a U_high, H[d]> + <w_P, RE[d]>, no alpha_P term.
-template <int E, int KR, int G, bool HV = false>
-__global__ __launch_bounds__(512 / G) void m2d_topk_grouped_bf16_pipe2(GroupedArgs p)
+// WAVES: 8 / G (a block of 256 users, 128 KiB of LDS, one block per CU), or 4 with G = 1: a block of 128 users over stages of
+// half the tiles (64 KiB of LDS), TWO blocks per CU -- a stage barrier then holds up four waves, not eight, and the CU's other
+// block keeps the matrix pipes busy meanwhile (launch_grouped: pruned launches, where the waves of a block are unequal).
+template <int E, int KR, int G, bool HV = false, int WAVES = 8 / G>
+__global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(GroupedArgs p)
 {
-    constexpr int C = 4, WAVES = 8 / G;
+    constexpr int C = 4;
     constexpr int KS = E / 16;                             // k-steps (16 k-values) per tile
     constexpr int S8 = E / 8;                              // 16-B slots per bf16 row
     constexpr int RPB = 256 / (E * 2) > 0 ? 256 / (E * 2) : 1;   // rows per 256-B bank row
-    constexpr int TPS = E == 64 ? 8 : 4;                   // tiles per stage: 64 KiB stages
+    constexpr int TPS = (E == 64 ? 8 : 4) * (WAVES * G) / 8;   // tiles per stage: 64 KiB stages (32 KiB for blocks of four waves)
+    static_assert(TPS >= 4, "a stage holds at least four tiles (its pieces are issued in the steps before its last)");
     constexpr int ROW_BYTES = E * 2, TILE_BYTES = 64 * ROW_BYTES, STAGE_BYTES = TPS * TILE_BYTES;
     constexpr int PIECES = STAGE_BYTES / 1024;
     constexpr int PPW = PIECES / WAVES;                    // 1-KiB DMA pieces per wave per stage
@@ -2890,8 +2897,21 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     static_assert(!HV || BF16X3, "the ingredient form exists for the pipelined split-bf16 kernel only");
     static_assert(!PAD || !BF16X3, "zero-padded rows are served by the exact-f32 kernel");
     constexpr int E = E8 * 8;
-    constexpr int TPS = grouped_tiles_per_stage(E);
+    const bool pipe = HV || h->opt_topk_form != 1;           // "topk_form", split-bf16 kernels: see below
+    // Blocks of 128 users (four waves, half-size stages, two blocks per CU) for pruned launches of the pipelined kernel at
+    // E = 64: a stage barrier holds up four waves instead of eight, the CU's other block runs meanwhile, and 128 users share
+    // fewer patterns than 256 (tiles stepped through 0.109 -> 0.100 of the catalogue).  Measured, k = 10: 65 536 users x 100 k
+    // dishes 0.629 -> 0.584 ms, 262 144 users 2.10 -> 1.99 ms, 16 384 users 0.384 -> 0.376 ms; but every block streams its own
+    // copy of the tiles, and once the catalogue image (8 KiB a tile) no longer sits in the Infinity Cache that costs more than
+    // the barriers did -- 1 M dishes: 65 536 users 3.19 -> 3.24 ms, 262 144 users 10.7 -> 11.4 ms -- so: catalogues up to 8 192
+    // tiles (64 MiB of image).  "topk_block" = 128 / 256 forces either.
+    const bool half_ok = BF16X3 && !HV && E == 64 && pipe;
+    const bool half = half_ok && (h->opt_topk_block == 128 || (h->opt_topk_block == 0 && M2D_TOPK_HALF_BLOCKS && h->opt_topk_prune != 0 &&
+                                                              h->opt_variant < 100 && nU >= 16384 && h->grp_tiles <= 8192));
+    const int WV = half ? 4 : WAVES;                         // waves per block
+    const int TPS = grouped_tiles_per_stage(E) * WV / WAVES;
     const size_t lds = (size_t)2 * TPS * 32 * E * sizeof(float);
+    h->topk_block_users = 32 * WV;
     GroupedArgs a;
     a.pm = h->pm; a.ce = h->ce; a.rs = h->grp_rs; a.rs16 = reinterpret_cast<const __bf16 *>(h->grp_rs16);
     a.perm = h->grp_perm; a.tile_info = h->grp_tile_info;
@@ -2899,7 +2919,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     a.users = users; a.nU = nU; a.U = h->U; a.user_base = h->user_base; a.k = k; a.tiles = h->grp_tiles;
     a.a = h->a; a.b = h->b; a.err = h->err_dev; a.dbg = g_m2d_diag_buffer; a.e_real = h->E;
     a.plan = nullptr; a.order = nullptr; a.tiles_scanned = nullptr; a.items = nullptr; a.shared_thr = nullptr;
-    const int64_t ublocks = (nU + 32 * WAVES - 1) / (32 * WAVES);
+    const int64_t ublocks = (nU + 32 * WV - 1) / (32 * WV);
     int nsplit = pick_splits(h, ublocks, a.tiles, 2 * TPS, 512);
     if ((!BF16X3 || (!HV && h->opt_topk_form != 1)) && h->opt_topk_prune != 0 && h->opt_variant < 100) {
         // Pattern pruning makes the blocks unequal -- a block of users with one relevant pattern steps through a fifteenth of
@@ -2913,6 +2933,9 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         // users 0.068 (0.091), 256 users: 256 ranges 0.101 (0.113), 1 024 users: 128 ranges 0.167 (0.185).
         if (ublocks >= 6) {
             nsplit = ublocks >= 192 ? 8 : (ublocks >= 96 ? 12 : (ublocks >= 48 ? 16 : (ublocks >= 24 ? 32 : (int)(512 / ublocks))));
+            // long catalogues: since a user's ranges share their thresholds, twice the ranges cost little and balance better
+            // (65 536 users x 1 M dishes: 8 ranges 3.41 ms, 16 ranges 3.19 ms, 24: 3.32; 262 144 users: 8 ranges 10.7, 16: 11.2)
+            if (BF16X3 && E == 64 && a.tiles >= 16384 && ublocks >= 192 && ublocks < 768) nsplit = 16;
             const int64_t most = a.tiles / (4 * TPS);        // at least four stages per range
             if (most < nsplit) nsplit = most > 1 ? (int)most : 1;
         } else {
@@ -2936,7 +2959,6 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     float *tie_final = h->topk_flags + (nsplit > 1 ? (size_t)nU * (nsplit + (nsplit > 64 ? nsplit / 64 : 0)) : 0);
     a.tie_val = h->topk_flags;
     int32_t *tie_list = reinterpret_cast<int32_t *>(h->topk_flags + tie_vals);
-    const bool pipe = HV || h->opt_topk_form != 1;           // "topk_form", split-bf16 kernels: see below
     const bool planned = !BF16X3 || pipe;                    // (the first-form bf16 kernel takes no plan)
     if (!planned) M2D_HIP_TRY(h, hipMemsetAsync(tie_list, 0, sizeof(int32_t), st));
     h->topk_tie_final = tie_final;
@@ -2975,7 +2997,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         int32_t *order = reinterpret_cast<int32_t *>(plan + (size_t)nU * 8), *hist = order + ((nU + 3) & ~(int64_t)3);      // hist: 16-B aligned
         unsigned long long *counter = reinterpret_cast<unsigned long long *>(hist + PLAN_KEYS);
         const bool prune = h->opt_topk_prune != 0;
-        const bool sorted = prune && !HV && nU > 32 * WAVES && h->opt_topk_prune != 3;      // 3: pruning without the sort (A/B)
+        const bool sorted = prune && !HV && nU > 32 * WV && h->opt_topk_prune != 3;      // 3: pruning without the sort (A/B)
         {
             const int pmode = (HV || !prune) ? 1 : (h->opt_topk_prune == 2 ? 2 : (h->opt_topk_prune == 4 ? 4 : 0));
             const float *probes = (HV || !prune || h->opt_topk_prune == 6) ? nullptr : h->grp_rs;      // 6: Cauchy-Schwarz bounds only (A/B)
@@ -3003,7 +3025,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         if (a.order && nitems > (size_t)h->num_cu && h->opt_topk_prune != 5) {      // 5: grid order (A/B)
             int32_t *work = reinterpret_cast<int32_t *>(counter + 1), *items = work + nitems;
             hipLaunchKernelGGL(m2d_plan_items_work, dim3((unsigned)((ublocks + 3) / 4)), dim3(256), 0, st, plan, order, nU, a.grp, a.tiles,
-                               nsplit, work, 32 * WAVES);
+                               nsplit, work, 32 * WV);
             hipLaunchKernelGGL(m2d_plan_items_sort, dim3(1), dim3(1024), 0, st, work, (int64_t)nitems, a.tiles, nsplit, items);
             a.items = items;
         }
@@ -3024,9 +3046,18 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
             hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, a);
         } else {
             static_assert(WAVES == 8, "the pipelined kernel is written for 256 users per block");
-            auto kern = m2d_topk_grouped_bf16_pipe2<E, KR, 1>;
-            M2D_HIP_TRY(h, m2d_lds_limit((const void *)kern, (int)lds));
-            hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);
+            if constexpr (E == 64) {
+                if (half) {
+                    auto kern4 = m2d_topk_grouped_bf16_pipe2<E, KR, 1, false, 4>;
+                    M2D_HIP_TRY(h, m2d_lds_limit((const void *)kern4, (int)lds));
+                    hipLaunchKernelGGL(kern4, grid, dim3(256), lds, st, a);
+                }
+            }
+            if (!half) {
+                auto kern = m2d_topk_grouped_bf16_pipe2<E, KR, 1>;
+                M2D_HIP_TRY(h, m2d_lds_limit((const void *)kern, (int)lds));
+                hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);
+            }
         }
     } else {
         auto kern = m2d_topk_grouped<E8, WAVES, KR, PAD>;

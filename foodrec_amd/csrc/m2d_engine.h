@@ -119,6 +119,8 @@ struct m2d_engine {
     int opt_topk_bf16x3 = 1;            // retrieval (build-defined) on split-bf16 MFMA; 0 = exact-f32 MFMA
     int opt_topk_grouped = 1;           // 0/1-mask catalogues: pattern-grouped retrieval (contraction over E); 0 = dense kernel
     int opt_topk_form = 0;              // split-bf16 retrieval kernel: 0 / 2 = pipelined form, 1 = first form
+    int opt_topk_block = 0;             // users per block of a pruned split-bf16 launch: 0 = the launcher's choice, 128 / 256 forced (A/B)
+    int topk_block_users = 256;         // what the last pattern-grouped launch used (the tile counters count tiles of blocks this size)
     int opt_topk_prune = 1;             // pipelined form: blocks step through the tiles of their users' relevant mask patterns only (0 = every tile)
 
     std::string last_error;

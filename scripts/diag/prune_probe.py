@@ -16,6 +16,8 @@ pat = torch.randint(1, 16, (I,), generator=g, device="cuda", dtype=torch.int32)
 cats = ((pat[:, None] >> torch.arange(C, device="cuda", dtype=torch.int32)[None, :]) & 1).float()
 eng = foodrec_amd.ScoringEngine(PM, RE, CE); eng.set_dish_categories(cats)
 users = torch.randperm(U, generator=g, device="cuda")[:n].to(torch.int32)
+if os.environ.get("PROBE_BLOCK"):
+    eng.set_option("topk_block", int(os.environ["PROBE_BLOCK"]))    # users per block of the pruned pipelined launch (128 / 256)
 if os.environ.get("PROBE_F32"):
     eng.set_option("topk_bf16x3", 0)                      # the exact-f32 kernel
 res = {}

@@ -69,9 +69,9 @@ if which in ("both", "topk"):
         kn = eng.last_kernel()
         first = launches.get(kn, 1 if x3 else 0) + WARM      # (the table-building call ran the default kernel once)
         launches[kn] = first + TIMED
-        # flops of the tiles the blocks stepped through (256 user lanes x 32 dishes each; 3 MFMA passes in split bf16)
+        # flops of the tiles the blocks stepped through (a block's 256 or 128 user lanes x 32 dishes each; 3 MFMA passes in split bf16)
         scanned, full = eng.get_option("topk_tiles_scanned"), eng.get_option("topk_tiles_full")
-        flop = 2.0 * E * (3 if x3 else 1) * 256 * 32 * scanned
+        flop = 2.0 * E * (3 if x3 else 1) * eng.get_option("topk_block_users") * 32 * scanned
         res[name] = {
             "kernel": eng.last_kernel(), "users": n, "dishes": I, "embed_size": E, "launches": TIMED, "warmup": WARM,
             "event_avg_ms": avg, "event_median_ms": med, "executed_flop_per_launch": flop,

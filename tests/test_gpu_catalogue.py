@@ -483,3 +483,29 @@ def test_re_ranked_scores_do_not_depend_on_where_a_dish_was_scored(E, x3):
             assert np.array_equal(i, i0) and np.array_equal(s.view(np.int32), s0.view(np.int32)), (key, r, rep)
     eng.set_option("topk_prune", 1); eng.set_option("variant", 0)
     _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:40], k, dup=300)
+
+
+@pytest.mark.parametrize("k", [10, 16])
+def test_blocks_of_128_users_return_the_same_lists(k):
+    """Pruned launches of the pipelined kernel over catalogues up to 8 192 tiles run blocks of 128 users (four waves, half-size
+    stages, two blocks per CU; option "topk_block" forces 128 / 256): another launch shape, the same lists bit for bit -- also
+    with a last block of 17 users, with dish ranges forced, and against the plain scan."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    U, I, E = 20000, 9000, 64
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=k + 300, n_nan=4, dup=60)
+    PM[5] = 0.0
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    users = torch.as_tensor(np.random.default_rng(k).permutation(U)[:128 * 140 + 17].astype(np.int32), device="cuda")
+    out = {}
+    for prune, block, forced in ((0, 0, 101), (1, 0, 0), (1, 128, 0), (1, 256, 0), (1, 128, 105), (0, 128, 0), (7, 128, 0)):
+        eng.set_option("topk_prune", prune); eng.set_option("topk_block", block); eng.set_option("variant", forced)
+        s, i = eng.topk_users(users, k); eng.check()
+        out[prune, block, forced] = (s.cpu().numpy(), i.cpu().numpy(), eng.get_option("topk_block_users"))
+    assert out[1, 0, 0][2] == 128 and out[1, 256, 0][2] == 256 and out[1, 128, 105][2] == 128 and out[0, 0, 101][2] == 256
+    s0, i0, _ = out[0, 0, 101]
+    for key, (s, i, _) in out.items():
+        assert np.array_equal(i, i0) and np.array_equal(s.view(np.int32), s0.view(np.int32)), key
+    eng.set_option("topk_prune", 1); eng.set_option("topk_block", 0); eng.set_option("variant", 0)
+    _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:50], k, dup=60)
