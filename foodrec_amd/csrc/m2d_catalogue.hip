@@ -2192,8 +2192,10 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
     constexpr int EU = HV ? E / 2 : E;                     // embedding width of the user tables
     constexpr int S4 = EU / 4;                             // float4 per f32 row of Personal_Memory
     constexpr int RPK = 16 / KS;                           // compares of the previous tile per k-step
-    constexpr bool SHARE = !(E == 128 && KR == 16 && !HV);  // thresholds shared between dish ranges (p.shared_thr) -- not in the one
-                                                           // instantiation where their registers do not fit (254 VGPRs + 4 spilled)
+    constexpr bool SHARE = !HV && E == 64;                   // thresholds shared between a user's dish ranges (p.shared_thr): compiled in
+                                                           // for E = 64 only -- at E = 128 (240-254 VGPRs) the code alone cost 3.5 % of a
+                                                           // pruned call and 6 % of an every-tile one and bought nothing (one instantiation
+                                                           // spilled), with the ingredient table (no plan bound to start from) 3 %
     constexpr int AR = KS < 4 ? KS : 4;                    // A-fragment register sets: the LDS reads run AR k-steps ahead
     static_assert(PIECES % WAVES == 0 && (WAVES * 64) % S8 == 0 && ((WAVES * 64 / S8) / RPB) % S8 == 0, "piece layout");
 
@@ -3011,7 +3013,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         }
         a.plan = plan;
         // dish ranges of a user share their thresholds (pipelined kernel; "topk_prune" = 7 keeps them apart: A/B)
-        if (BF16X3 && pipe && nsplit > 1 && h->opt_topk_prune != 7) a.shared_thr = reinterpret_cast<int32_t *>(plan) + 6;
+        if (BF16X3 && pipe && !HV && E == 64 && nsplit > 1 && h->opt_topk_prune != 7) a.shared_thr = reinterpret_cast<int32_t *>(plan) + 6;
         if (sorted) {
             const size_t tab = (size_t)PLAN_KEYS * sizeof(int32_t);
             const unsigned sblocks = (unsigned)((nU + 1023) / 1024 < 4 * h->num_cu ? (nU + 1023) / 1024 : 4 * h->num_cu);
