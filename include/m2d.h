@@ -254,11 +254,16 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
  * against the sums of absolute terms so that cancelling rows keep their margin; users are sorted by their pattern mask so that a block's users share patterns, and a
  * launch's (user block, dish range) items are handed out longest first); the lists are the same bit for bit with 0 (every
  * tile).  2 / 3 / 4 / 5 / 6 are A/B forms of the same: the bound only, no sort, the patterns only, the grid's launch order,
- * the bound without its probe rows (the k-th largest exact score among the first rows of the user's best pattern).
+ * the bound without its probe rows (the k-th largest exact score among the first rows of the user's best pattern); 7: a
+ * user's dish ranges keep their thresholds apart (by default they meet in one atomic-max word per user, E = 64); 9: the tie
+ * repair reads every pattern's dishes (by default only the patterns that can reach its users' top-k).  "topk_block"
+ * (default 0): users per block of a pruned pipelined launch -- 0 = the launcher's choice (128 for E = 64, at least 16 384
+ * users and catalogues up to 8 192 tiles, else 256), 128 / 256 forced; same lists.
  * m2d_score_pairs* (the reference path) is always exact float32.  Unknown names: M2D_ERR_INVALID_ARG.
  * m2d_get_option also answers three diagnostics of the last m2d_topk_users call on the pattern-grouped kernels (they
  * synchronise the device): "topk_repaired" (users re-ranked in id order because their k-th score was tied),
- * "topk_tiles_scanned" / "topk_tiles_full" (32-dish tiles the blocks stepped through / would have without pruning). */
+ * "topk_tiles_scanned" / "topk_tiles_full" (32-dish tiles the blocks stepped through / would have without pruning; a
+ * block holds "topk_block_users" users, 256 or 128, which m2d_get_option answers too). */
 int m2d_set_option(m2d_engine *h, const char *name, int64_t value);
 int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value);
 
