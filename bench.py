@@ -340,8 +340,8 @@ def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10, ke
 
 def compare_lists(torch, a, b):
     """Dish ids are index output: how the default (split-bf16) lists differ from the exact-f32 kernel's for the same users.
-    Where two dishes' scores sit inside the split's rounding (3e-5 max(1, |s|), tests/test_gpu_catalogue.py) the two kernels
-    may order them differently; `max_gap_at_mismatch` is the largest |score difference| between the two kernels at a
+    Both kernels finish near-tied lists in one arithmetic (m2d_topk_refine; option topk_refine), so they should not; without
+    it, where two dishes' scores sit inside the split's rounding the two kernels may order them differently; `max_gap_at_mismatch` is the largest |score difference| between the two kernels at a
     position that holds different dishes, relative to max(1, |score|)."""
     ia, ib, sa, sb = a["ids"], b["ids"], a["scores"], b["scores"]
     diff = ia != ib
@@ -1209,7 +1209,25 @@ def main():
             finally:
                 eng.set_option("topk_bf16x3", 1)
             line["catalogue_topk"]["index_exactness"] = compare_lists(torch, lists_x3, lists_f32)
+            line["catalogue_topk"]["index_exactness"].update({"refined_users": eng.get_option("topk_refined"),
+                                                               "refined_users_sent_to_the_repair": eng.get_option("topk_refine_repaired")})
             del lists_x3, lists_f32
+            eng.set_option("topk_refine", 0)            # ... and what finishing the near-tied lists in one arithmetic costs (same call without it)
+            try:
+                lists_off = {}
+                off = catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U), keep=lists_off)
+                line["catalogue_topk"]["refine_off"] = {"median_ms": off["median_ms"], "pairs_per_s": off["pairs_per_s"],
+                                                        "what": "option topk_refine = 0: the split-bf16 lists as the scan leaves them (round 3's "
+                                                                "behaviour); ids then differ from the exact-f32 kernel's wherever two scores sit inside "
+                                                                "the split's rounding"}
+                eng.set_option("topk_bf16x3", 0)
+                lists_f32_off = {}
+                catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U), keep=lists_f32_off)
+                line["catalogue_topk"]["refine_off"]["index_exactness"] = compare_lists(torch, lists_off, lists_f32_off)
+                del lists_off, lists_f32_off
+            finally:
+                eng.set_option("topk_bf16x3", 1)
+                eng.set_option("topk_refine", 1)
             eng.set_option("topk_prune", 0)             # ... and the same kernel made to step through every tile: the MFMA-bound form
             try:
                 line["catalogue_topk"]["every_tile"] = catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U))

@@ -132,6 +132,7 @@ void release(m2d_engine *h)
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->topk_flags) (void)hipFree(h->topk_flags);
     if (h->topk_plan) (void)hipFree(h->topk_plan);
+    if (h->topk_ex) (void)hipFree(h->topk_ex);
     if (h->err_dev) (void)hipFree(h->err_dev);
     if (h->err_host) (void)hipHostFree(h->err_host);
 }
@@ -764,6 +765,7 @@ int m2d_set_option(m2d_engine *h, const char *name, int64_t value)
     else if (!strcmp(name, "topk_form")) h->opt_topk_form = (int)value;
     else if (!strcmp(name, "topk_prune")) h->opt_topk_prune = (int)value;
     else if (!strcmp(name, "topk_block")) h->opt_topk_block = (int)value;
+    else if (!strcmp(name, "topk_refine")) h->opt_topk_refine = (int)value;
     else if (!strcmp(name, "topk_grouped")) h->opt_topk_grouped = (int)value;
     else if (!strcmp(name, "mlp_bf16x3")) h->opt_mlp_bf16x3 = (int)value;
     else if (!strcmp(name, "mlp_form")) h->opt_mlp_form = (int)value;
@@ -786,6 +788,16 @@ int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value)
     else if (!strcmp(name, "topk_prune")) *value = h->opt_topk_prune;
     else if (!strcmp(name, "topk_block")) *value = h->opt_topk_block;
     else if (!strcmp(name, "topk_block_users")) *value = h->topk_block_users;
+    else if (!strcmp(name, "topk_refine")) *value = h->opt_topk_refine;
+    else if (!strcmp(name, "topk_refined") || !strcmp(name, "topk_refine_repaired")) {
+        int32_t c[2] = {0, 0};
+        if (h->topk_refine_counter) {
+            if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+                hipMemcpy(c, h->topk_refine_counter, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess)
+                return M2D_ERR_HIP;
+        }
+        *value = !strcmp(name, "topk_refined") ? c[0] : c[1];
+    }
     else if (!strcmp(name, "topk_tiles_scanned") || !strcmp(name, "topk_tiles_full")) {
         // diagnostic (synchronises the device): 32-dish tiles the blocks of the last pipelined retrieval launch stepped
         // through, and what they would have stepped through without pattern pruning

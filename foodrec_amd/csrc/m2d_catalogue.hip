@@ -186,6 +186,44 @@ __device__ __forceinline__ unsigned long long tie_update(unsigned long long mask
     return (mask & ~__ballot(new_last != old_last)) | __ballot(tie_at_boundary(x, old_last, new_last));
 }
 
+// What a lane's list leaves out (round 4, index-exact lists): the best and the second-best score that reached the lane's
+// insertion and is not in its list -- refused at the list's end, or pushed off it.  A score within 2 delta of the user's final
+// k-th score always reaches an insertion (the threshold compares are relaxed by 2 delta), so if such a score exists outside the
+// final list, the largest one is here, whatever thresholds the launch's shape produced.
+struct LeftOut {
+    float s1;
+    int32_t i1;                                            // slot of s1 (a dish id once published)
+    float s2;
+    int32_t i2;
+    float s3;                                              // the third best such score (its dish is not kept: three that close go to the repair)
+};
+#define M2D_LEFTOUT_NONE LeftOut{-INFINITY, -1, -INFINITY, -1, -INFINITY}
+
+// (score, id) into the best three of a LeftOut
+__device__ __forceinline__ void left_out_merge(LeftOut &o, const float cs, const int32_t ci)
+{
+    const float c = fmaxf(cs, -INFINITY);                  // NaN (an empty slot): never
+    const bool a1 = c > o.s1, a2 = c > o.s2;
+    o.s3 = a2 ? o.s2 : fmaxf(o.s3, c);
+    o.i2 = a1 ? o.i1 : (a2 ? ci : o.i2);
+    o.s2 = a1 ? o.s1 : (a2 ? c : o.s2);
+    o.i1 = a1 ? ci : o.i1;
+    o.s1 = a1 ? c : o.s1;
+}
+
+// `keep_from` = the lane's last entry after the insertion, less 2 delta: the user's final k-th score is not below a lane's last
+// entry, so a score under keep_from can never come within 2 delta of it -- nearly every pushed-off entry, as lists' gaps are a
+// hundred times 2 delta.  One ballot then settles the wave (the bookkeeping itself is 14 VALU: it cost the scan 6 % when every
+// insertion paid it).
+__device__ __forceinline__ void left_out_note(LeftOut &o, const float x, const int32_t idx, const float old_last, const int32_t old_last_id,
+                                              const float keep_from)
+{
+    const float es = fminf(x, old_last);                   // what is out after this insertion: x itself, or the entry it pushed off
+    if (__ballot(es >= keep_from) == 0ull) return;          // wave-uniform
+    const bool refused = !(x > old_last);                  // the insertion is strict: an equal score stays out
+    left_out_merge(o, es >= keep_from ? es : -INFINITY, refused ? idx : old_last_id);
+}
+
 // NB = K / 8: float4 registers of the user operand per lane.  One stage = 32 dishes x KC floats.
 // KR > 0: the lane's running list (KR >= k slots) lives in REGISTERS and an insertion is a branch-free
 // compare-exchange sweep (about 8*KR VALU ops, no LDS latency chain), so every wave reaches the
@@ -528,7 +566,8 @@ __device__ __forceinline__ void fill_absent_user(float *s, int32_t *id, const in
 template <int LPU>
 __global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k,
                                                              float *out_scores, int32_t *out_ids, const float *tie_in, float *tie_out,
-                                                             int32_t *tie_list, int64_t I)
+                                                             int32_t *tie_list, int64_t I, const float *ex_in = nullptr, float *ex_out = nullptr,
+                                                             const float *plan = nullptr, int32_t *rcount = nullptr)
 {
     const int lane = threadIdx.x & 63, w = lane & (LPU - 1);
     const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPU;
@@ -540,6 +579,10 @@ __global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, co
     int32_t hi = live ? id[0] : -1;                          // -1: this list is exhausted (or the lane is idle)
     float last = 0.f;
     int32_t last_i = -1;
+    // (the final pass of a call that finishes near-tied lists -- m2d_topk_refine -- also does m2d_topk_refine_flag's work)
+    const float d2 = (plan && rcount && u < nU) ? 2.f * plan[(size_t)u * 8 + 7] : 0.f;
+    int n_real = 0;
+    bool near = false;
     for (int o = 0; o < k; ++o) {                           // wave-uniform trip count: the shuffles see a full EXEC
         float bs = hs;
         int32_t bi = hi;
@@ -562,6 +605,10 @@ __global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, co
             hi = ptr < k ? id[ptr] : -1;
             hs = ptr < k ? s[ptr] : 0.f;
         }
+        if (bi >= 0 && bs == bs) {
+            near = near || (n_real > 0 && last - bs < d2);
+            ++n_real;
+        }
         last = bs;
         last_i = bi;
     }
@@ -574,15 +621,52 @@ __global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, co
 #pragma unroll
         for (int off = LPU / 2; off >= 1; off >>= 1) tv |= __shfl_xor(tv, off, 64);
         const bool any = tv != 0;
+        bool to_repair = false;
+        int refine_ent = -1;
+        if (ex_in) {
+            // what the merged list leaves out (LeftOut, grouped_publish): the best two of every split's own left-out scores and
+            // of what this merge left behind in the splits' lists (two entries of each suffice)
+            LeftOut o = M2D_LEFTOUT_NONE;
+            if (live) {
+                const float *e = ex_in + ((size_t)u * nsplit + w) * 8;
+                o.s1 = fmaxf(e[0], -INFINITY); o.i1 = __float_as_int(e[1]); o.s2 = fmaxf(e[2], -INFINITY); o.i2 = __float_as_int(e[3]);
+                o.s3 = fmaxf(e[4], -INFINITY);
+                for (int q = 0; q < 3; ++q)                  // what this merge left behind in the split's list: three entries suffice
+                    if (hi >= 0 && ptr + q < k && id[ptr + q] >= 0) left_out_merge(o, s[ptr + q], id[ptr + q]);
+            }
+#pragma unroll
+            for (int off = LPU / 2; off >= 1; off >>= 1) {
+                const float o1 = __shfl_xor(o.s1, off, 64), o2 = __shfl_xor(o.s2, off, 64), o3 = __shfl_xor(o.s3, off, 64);
+                const int32_t j1 = __shfl_xor(o.i1, off, 64), j2 = __shfl_xor(o.i2, off, 64);
+                left_out_merge(o, o1, j1);
+                left_out_merge(o, o2, j2);
+                left_out_merge(o, o3, -1);
+            }
+            if (u < nU && w == 0) {
+                float *e = ex_out + (size_t)u * 8;
+                e[0] = o.s1; e[1] = __int_as_float(o.i1); e[2] = o.s2; e[3] = __int_as_float(o.i2); e[4] = o.s3;
+            }
+            if (rcount && plan && !any && n_real > 0) {      // m2d_topk_refine_flag's decision, from the values at hand
+                int nex = 0;
+                if (n_real == k) {
+                    const float lim = last - d2;
+                    nex = (o.s1 >= lim && o.i1 >= 0 ? 1 : 0) + (o.s2 >= lim && o.i2 >= 0 ? 1 : 0);
+                    to_repair = o.s3 >= lim;
+                }
+                if (!to_repair && (near || nex > 0)) refine_ent = (int32_t)u | (nex << 30);
+            }
+        }
         if (u < nU && w == 0) {
             tie_out[u] = any ? last : __builtin_nanf("");
             // the final pass of a pattern-grouped call also does m2d_topk_tie_compact's work: a tied user joins the repair's
             // list, everybody else's list is finished here (this lane wrote it: its own stores, in program order)
             if (tie_list) {
-                if (any) tie_list[1 + atomicAdd(&tie_list[0], 1)] = (int32_t)u;
+                if (any || to_repair) tie_list[1 + atomicAdd(&tie_list[0], 1)] = (int32_t)u;
                 else fill_absent_user(out_scores + u * k, out_ids + u * k, k, I);
+                if (to_repair) atomicAdd(&rcount[1], 1);
             }
         }
+        if (rcount && tie_list && u < nU && w == 0) rcount[8 + u] = refine_ent;      // a word per user, no atomics (m2d_topk_refine compacts)
     }
 }
 
@@ -631,8 +715,9 @@ struct RepairArgs {
     const float *rows;                          // the pattern-sorted f32 dish table (GroupedArgs::rs), row stride ew floats
     const int32_t *perm;                        // slot -> dish id
     const int32_t *grp;                         // [0..15] first slot of each pattern's group, [40..55] rows per pattern
-    const float *plan;                          // the call's plan records (word 5: relevant-pattern mask), or null = every pattern
+    const float *plan;                          // the call's plan records (words 1-4: <U_high, CE_c>, word 5: relevant-pattern mask), or null
     int32_t ew;
+    int32_t all_patterns;                       // 1: the scan reads every pattern's dishes whatever the masks say (A/B)
     float *part_s;                              // [cap, REPAIR_SPLITS, k] partial lists
     int32_t *part_i;
     float *out_scores;                          // [nU, k]
@@ -646,6 +731,27 @@ __device__ __forceinline__ float row16_sum(float x)
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xf, 0xf, false));
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false));
     return x;
+}
+
+// The ranking arithmetic of the tie repair and of m2d_topk_refine ("c" in their comments).  With the call's plan at hand the
+// high-level part is alpha_P EXACTLY as the scan kernels form it -- a (hs inv_n) from the plan's <U_high, CE_c> words -- so that
+// a scan kernel's score and c differ only by what the low-level contraction's arithmetic does (split bf16: ~1e-5 of |w||r|),
+// not by two summation orders of the thirty-times larger high-level dot products: that is what keeps the near-tie margin
+// (plan word 7) small enough for a few per cent of the users.  Without a plan (the first-form split-bf16 kernel, the
+// ingredient table): the reference's blend of the two normalised sums, Model_Recommender.py:79, :92, :95-96.
+__device__ __forceinline__ float repair_alpha(const float a, const float (&hc)[4], const int pt)
+{
+    float hs = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) hs += ((pt >> c) & 1) ? hc[c] : 0.f;
+    const float inv_n = 1.0f / (float)__builtin_popcount(pt);
+    return a * (hs * inv_n);                                // the scan kernels' expression, bit for bit (pattern 0: 0 * inf = NaN)
+}
+
+__device__ __forceinline__ float repair_score_planned(const float alpha_scan, const float b, const float low_over_n)
+{
+    const float q = b * low_over_n;                         // (no contraction in this file)
+    return alpha_scan + q;
 }
 
 __device__ __forceinline__ bool repair_ahead(float s, int32_t i, float t, int32_t j)
@@ -691,20 +797,27 @@ __global__ __launch_bounds__(1024) void m2d_topk_repair_scan(RepairArgs p)
             for (int c = 0; c < C; ++c) w += ((pt >> c) & 1) ? um[ub * W + (c + 1) * E + e] : 0.f;
             wp[i] = w;
         }
+        const bool planned = p.plan != nullptr && !HVR;
         for (int x = wave; x < nu * C; x += 16) {           // a wave per (user, category): <U_high, CE_c>
             const int ub = x / C, c = x - ub * C;
             float q = 0.f;
-            for (int e = lane; e < E; e += 64) q = fmaf(um[ub * W + e], p.ce[(size_t)c * E + e], q);
+            if (planned) q = p.plan[(size_t)p.tie_list[1 + f0 + ub] * 8 + 1 + c];            // the scan kernels' own value
+            else {
+                for (int e = lane; e < E; e += 64) q = fmaf(um[ub * W + e], p.ce[(size_t)c * E + e], q);
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+                for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+            }
             if (lane == 0) hc[ub][c] = q;
         }
         __syncthreads();
         if (t < nu * NP) {
             const int ub = t / NP, pt = t - ub * NP;
-            float x = 0.f;
-            for (int c = 0; c < C; ++c) x += ((pt >> c) & 1) ? hc[ub][c] : 0.f;
-            alpha[ub][pt] = x / (float)__builtin_popcount(pt);                               // :79 (pattern 0: 0 / 0 = NaN)
+            if (planned) alpha[ub][pt] = repair_alpha(p.a, hc[ub], pt);
+            else {
+                float x = 0.f;
+                for (int c = 0; c < C; ++c) x += ((pt >> c) & 1) ? hc[ub][c] : 0.f;
+                alpha[ub][pt] = x / (float)__builtin_popcount(pt);                           // :79 (pattern 0: 0 / 0 = NaN)
+            }
         }
         __syncthreads();
         const v4f *um4 = reinterpret_cast<const v4f *>(um), *wp4 = reinterpret_cast<const v4f *>(wp);
@@ -715,7 +828,7 @@ __global__ __launch_bounds__(1024) void m2d_topk_repair_scan(RepairArgs p)
         // third of the table.  The relevant rows are dealt out evenly to the REPAIR_SPLITS blocks.  Slots are not in id order
         // across norm buckets, so an insertion compares (score desc, id asc) explicitly.
         uint32_t rel = 0xfffeu;
-        if (p.plan) {
+        if (p.plan && !p.all_patterns) {
             rel = 0u;
             for (int ub = 0; ub < nu; ++ub) rel |= __float_as_uint(p.plan[(size_t)p.tie_list[1 + f0 + ub] * 8 + 5]);
         }
@@ -807,7 +920,8 @@ __global__ __launch_bounds__(1024) void m2d_topk_repair_scan(RepairArgs p)
                         }
 #pragma unroll
                         for (int x = 0; x < ND; ++x) {
-                            float sc = m2d_blend_unfused(p.a, HVR ? hs[x][ub] : alpha[ub][q], p.b, lo[x][ub] / npat);   // :79 (done above), :92, :95-96
+                            float sc = planned ? repair_score_planned(alpha[ub][q], p.b, lo[x][ub] / npat)
+                                               : m2d_blend_unfused(p.a, HVR ? hs[x][ub] : alpha[ub][q], p.b, lo[x][ub] / npat);   // :79 (done above), :92, :95-96
                             sc = ok[x] ? fmaxf(sc, -INFINITY) : -INFINITY;                   // NaN -> -inf: never enters
                             const int32_t id = ok[x] ? did[x] : 0x7fffffff;
                             // left neighbour's slot (lane j - 1 of the same 16-lane row; lane 0 sees +inf / -1)
@@ -916,19 +1030,26 @@ __global__ __launch_bounds__(256) void m2d_topk_repair_finish(RepairArgs p)
             for (int c = 0; c < C; ++c) w += ((pt >> c) & 1) ? um[(c + 1) * E + e] : 0.f;
             wp[i] = w;
         }
+        const bool planned = p.plan != nullptr && !HVR;
         {                                                   // wave c: <U_high, CE_c>
             const int c = wave;
             float q = 0.f;
-            for (int e = lane; e < E; e += 64) q = fmaf(um[e], p.ce[(size_t)c * E + e], q);
+            if (planned) q = p.plan[(size_t)u * 8 + 1 + c];
+            else {
+                for (int e = lane; e < E; e += 64) q = fmaf(um[e], p.ce[(size_t)c * E + e], q);
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+                for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+            }
             if (lane == 0) hc[c] = q;
         }
         __syncthreads();
         if (t < NP) {
-            float x = 0.f;
-            for (int c = 0; c < C; ++c) x += ((t >> c) & 1) ? hc[c] : 0.f;
-            alpha[t] = x / (float)__builtin_popcount(t);                                     // :79 (pattern 0: 0 / 0 = NaN)
+            if (planned) alpha[t] = repair_alpha(p.a, hc, t);
+            else {
+                float x = 0.f;
+                for (int c = 0; c < C; ++c) x += ((t >> c) & 1) ? hc[c] : 0.f;
+                alpha[t] = x / (float)__builtin_popcount(t);                                 // :79 (pattern 0: 0 / 0 = NaN)
+            }
         }
         __syncthreads();
         const v4f *um4 = reinterpret_cast<const v4f *>(um), *wp4 = reinterpret_cast<const v4f *>(wp);
@@ -952,7 +1073,8 @@ __global__ __launch_bounds__(256) void m2d_topk_repair_finish(RepairArgs p)
             lo = row16_sum(lo);
             if (HVR) hs = row16_sum(hs);
             const float n = (float)__builtin_popcount(pt);                                    // :77
-            float sc = m2d_blend_unfused(p.a, HVR ? hs : alpha[pt], p.b, lo / n);   // :79, :92, :95-96
+            float sc = planned ? repair_score_planned(alpha[pt], p.b, lo / n)
+                               : m2d_blend_unfused(p.a, HVR ? hs : alpha[pt], p.b, lo / n);   // :79, :92, :95-96
             sc = ok ? fmaxf(sc, -INFINITY) : -INFINITY;                                       // NaN -> -inf: never enters
             const float left_s = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, INFINITY),
                                                     __builtin_bit_cast(int, slot_s), 0x111, 0xf, 0xf, false));
@@ -985,6 +1107,191 @@ __global__ __launch_bounds__(256) void m2d_topk_repair_finish(RepairArgs p)
             }
             if (lane == 0) fill_absent_user(p.out_scores + u * k, p.out_ids + u * k, k, p.I);
         }
+    }
+}
+
+
+// ---- m2d_topk_refine: near-tied lists are finished in the tie repair's arithmetic ----------------------------------------------
+// A scan kernel's score s~ lies within delta_u (plan record word 7) of the same score c in the repair's plain-f32 arithmetic
+// (m2d_topk_repair_scan: the ranking every kernel's lists are DEFINED by).  Where every gap between neighbouring entries of a
+// user's final list, and between its last entry and the best score left out, is above 2 delta_u, the list is already c's
+// ranking.  Elsewhere -- a few per cent of the users -- the candidates (the list, plus the best left-out dish if it is that
+// close) are scored again in that arithmetic, step for step (pattern sums of the low-level rows, a float4 column per lane,
+// the 16-lane rotation sum, m2d_blend_unfused), and sorted (score desc, id asc); a user with TWO left-out scores that close
+// joins the repair's list and is re-ranked over its relevant patterns.  So the split-bf16 kernel (the default) and the
+// exact-f32 kernel return the same dish ids: the difference between their products only ever decided near-ties.
+// One wave per user; most leave after reading their list.  Tie-listed users are skipped (the repair rewrites them).
+struct RefineArgs {
+    const float *pm, *re, *ce, *cats, *plan, *tie_final, *ex;
+    const int32_t *users;
+    int32_t *tie_list, *counter;                            // counter: [0] users refined, [1] sent on to the repair, [2] length of the list at [8..]
+    int64_t nU, U, I, user_base;
+    int32_t E, k;
+    float a, b;
+    float *out_scores;
+    int32_t *out_ids;
+};
+
+// one thread per user: is the list near-tied?  -> the user's word at counter[8 + u] (position in the call | left-out dishes to take
+// along << 30, or -1), or -- three left-out scores that close -- the repair's list.  (Launches with dish ranges decide this in their last merge pass.)
+__device__ __forceinline__ int32_t refine_flag_user(const RefineArgs &p, const int64_t u)
+{
+    const int k = p.k;
+    const float *os = p.out_scores + (size_t)u * k;
+    const int32_t *oi = p.out_ids + (size_t)u * k;
+    const float d2 = 2.f * p.plan[(size_t)u * 8 + 7];
+    int n = 0;
+    bool near = false;
+    float prev = 0.f;
+    for (int q = 0; q < k; ++q) {                           // ranked entries come first (NaN / absent ones behind them)
+        const float sv = os[q];
+        if (oi[q] < 0 || sv != sv) break;
+        near = near || (q > 0 && prev - sv < d2);
+        prev = sv;
+        ++n;
+    }
+    int nex = 0;
+    if (n == k) {                                           // a full list: how many left-out scores are within 2 delta of its last
+        const float *ex = p.ex + (size_t)u * 8;
+        const float lim = prev - d2;
+        nex = (ex[0] >= lim && __float_as_int(ex[1]) >= 0 ? 1 : 0) + (ex[2] >= lim && __float_as_int(ex[3]) >= 0 ? 1 : 0);
+        if (ex[4] >= lim) {                                 // three of them: the repair ranks this user over its patterns
+            p.tie_list[1 + atomicAdd(&p.tie_list[0], 1)] = (int32_t)u;
+            atomicAdd(&p.counter[1], 1);
+            return -1;
+        }
+    }
+    if (n == 0 || !(near || nex > 0)) return -1;
+    return (int32_t)u | (nex << 30);
+}
+
+__global__ __launch_bounds__(256) void m2d_topk_refine_flag(RefineArgs p)
+{
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= p.nU) return;
+    int32_t ent = -1;
+    if (!(p.tie_final[u] == p.tie_final[u])) ent = refine_flag_user(p, u);                 // (tie-listed: the repair rewrites that list)
+    p.counter[8 + u] = ent;
+}
+
+// 32 lanes per listed user, a lane per candidate (k <= 16 list entries + at most two left-out dishes): the candidate's score in
+// the repair's arithmetic.  A lane emulates the sixteen lanes the repair gives a dish: partial j = the fma chain over float4
+// columns j, j + 16, ... of the row (it.x w.x first ... as there), then the rotation sum's tree -- (p_j + p_j+8), then + the
+// same of j + 4, of j + 2, of j + 1; the adds commute, so the tree does not depend on the rotations' direction.
+template <int CH>                                           // float4 columns per emulated lane: E <= 64 CH
+__global__ __launch_bounds__(256) void m2d_topk_refine(RefineArgs p)
+{
+    constexpr int C = 4;
+    const int lane = threadIdx.x & 63, half = lane >> 5, i = lane & 31;
+    const int k = p.k, E = p.E, E4 = E >> 2, W = (C + 1) * E;
+    // a block takes 64 users: their words are compacted in LDS (a list with one global counter cost 40 us of serialised atomics)
+    __shared__ int32_t s_list[64];
+    __shared__ int s_count;
+    __shared__ v4f s_w[8][32];                              // per half-wave: the pattern's low-level operand, a float4 column per lane
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int64_t uu = (int64_t)blockIdx.x * 64 + threadIdx.x;
+        const int32_t e = uu < p.nU ? p.counter[8 + uu] : -1;
+        if (e != -1) s_list[atomicAdd(&s_count, 1)] = e;
+    }
+    __syncthreads();
+    const int count = s_count;
+    if (count == 0) return;
+    if (threadIdx.x == 0) atomicAdd(&p.counter[0], count);
+    for (int f = (threadIdx.x >> 6) * 2 + half; f < ((count + 1) & ~1); f += 8) {
+        const bool fvalid = f < count;                      // (both halves of a wave run the same trip count: the shuffles below see a full EXEC)
+        const int32_t ent = fvalid ? s_list[f] : 0;
+        const int64_t u = ent & 0x3fffffff;
+        const int nex = fvalid ? (int)((uint32_t)ent >> 30) : 0;
+        float *os = p.out_scores + (size_t)u * k;
+        int32_t *oi = p.out_ids + (size_t)u * k;
+        const float sv = (fvalid && i < k) ? os[i] : 0.f;
+        const int32_t iv = (fvalid && i < k) ? oi[i] : -1;
+        const bool real = i < k && iv >= 0 && sv == sv;
+        const unsigned long long rb = __ballot(real);
+        const int n = __builtin_popcount((uint32_t)(rb >> (32 * half)));
+        const int nc = n + nex;
+        const float *ex = p.ex + (size_t)u * 8;
+        int32_t d = iv;
+        if (fvalid && i >= n && i < nc) d = __float_as_int(ex[1 + 2 * (i - n)]);
+        const bool mine = fvalid && i < nc;
+        float sc = -INFINITY;
+        int64_t ul = fvalid ? (int64_t)p.users[u] - p.user_base : 0;
+        if (ul < 0 || ul >= p.U) ul = 0;                    // latched by the scan kernel
+        const v4f *um4 = reinterpret_cast<const v4f *>(p.pm + (size_t)ul * W);
+        float hc[C];                                        // <U_high, CE_c>: the plan's words, as in the planned repair (repair_alpha)
+#pragma unroll
+        for (int c = 0; c < C; ++c) hc[c] = p.plan[(size_t)u * 8 + 1 + c];
+        int pt = 0;
+        if (mine) {
+            const v4f m = *reinterpret_cast<const v4f *>(p.cats + (size_t)d * C);
+            pt = (m.x != 0.f ? 1 : 0) | (m.y != 0.f ? 2 : 0) | (m.z != 0.f ? 4 : 0) | (m.w != 0.f ? 8 : 0);
+        }
+        const v4f *row = reinterpret_cast<const v4f *>(p.re) + (size_t)(mine ? d : 0) * E4;
+        v4f it[16 * CH];                                    // the candidate's row: fetched once, before the pattern loop
+#pragma unroll
+        for (int q = 0; q < 16 * CH; ++q) it[q] = (mine && q < E4) ? row[q] : v4f{0.f, 0.f, 0.f, 0.f};
+        // The low-level operand w_P = sum of the pattern's U_low rows is the same for every candidate of a pattern: the 32 lanes
+        // of a user work it out a float4 column each (as the repair's wp table: the rows added in category order from zero) and
+        // pass it through LDS, pattern by pattern -- a user's candidates carry one or two patterns, almost always
+        bool todo = mine && pt != 0;
+        v4f *wb = &s_w[(threadIdx.x >> 5)][0];
+        for (;;) {
+            const unsigned long long tm = __ballot(todo);
+            if (tm == 0ull) break;                          // wave-uniform
+            const uint32_t hm = (uint32_t)(tm >> (32 * half));
+            const int cur = __shfl(pt, half * 32 + (hm ? __builtin_ctz(hm) : 0), 64) * (hm ? 1 : 0);      // this half's pattern of the round (0: none)
+            if (i < E4 && cur) {
+                v4f w = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const v4f z = {0.f, 0.f, 0.f, 0.f};
+                    const v4f r = um4[(c + 1) * E4 + i];
+                    w += ((cur >> c) & 1) ? r : z;
+                }
+                wb[i] = w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (todo && pt == cur) {
+                float part[16];
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    float lo = 0.f;
+#pragma unroll
+                    for (int ch = 0; ch < CH; ++ch) {
+                        const int q = jj + 16 * ch;
+                        if (q < E4) {
+                            const v4f w = wb[q];
+                            lo = fmaf(it[q].x, w.x, fmaf(it[q].y, w.y, fmaf(it[q].z, w.z, fmaf(it[q].w, w.w, lo))));
+                        }
+                    }
+                    part[jj] = lo;
+                }
+                float s8[8], s4[4], s2[2];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) s8[jj] = part[jj] + part[jj + 8];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) s4[jj] = s8[jj] + s8[jj + 4];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) s2[jj] = s4[jj] + s4[jj + 2];
+                const float lo = s2[0] + s2[1];
+                const float npat = (float)__builtin_popcount(pt);
+                sc = fmaxf(repair_score_planned(repair_alpha(p.a, hc, pt), p.b, lo / npat), -INFINITY);
+                todo = false;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                // (the next round overwrites wb)
+        }
+        // a candidate's rank = how many candidates of its user are ahead of it in (score desc, id asc)
+        int rank = 0;
+        for (int o = 0; o < 18; ++o) {                      // (k <= 16, two more at most)
+            const float s2v = __shfl(sc, half * 32 + o, 64);
+            const int32_t i2v = __shfl(d, half * 32 + o, 64);
+            rank += (o < nc && (s2v > sc || (s2v == sc && i2v < d))) ? 1 : 0;
+        }
+        if (mine && rank < n) { os[rank] = sc; oi[rank] = d; }
     }
 }
 
@@ -1236,6 +1543,8 @@ struct GroupedArgs {
     const int32_t *order;      // [nU] position in the launch -> index into users / plan (users sorted by pattern mask), or null
     unsigned long long *tiles_scanned;   // diagnostic: 32-dish tiles the blocks stepped through
     const int32_t *items;      // [user blocks x nsplit] launch order of a pruned scan: block * nsplit + split, longest first; or null
+    float *ex_out;             // [nU, nsplit, 8] per (user, dish range): the best two scores left out of the range's list with their dish ids
+                               // (bits), the third best such score -- what m2d_topk_refine needs to finish near-tied lists; null = not kept
     int32_t *shared_thr;       // word 6 of the plan records (stride 8): the user's running threshold over ALL dish ranges, as an
                                // ordered key (thr_key); null = every (block, range) item keeps to its own lists
 };
@@ -1391,7 +1700,8 @@ template <int CH>                                           // float4 columns a 
 __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const float *ce, const int32_t *users, int64_t nU, int64_t U,
                                                           int64_t user_base, int E, const int32_t *grp, int k, float a, float b,
                                                           int no_alpha, float *plan, int32_t *zero_tie, unsigned long long *zero_tiles,
-                                                          int32_t *zero_hist, int nhist, const float *probe_rows, int probe_width, int nprobe)
+                                                          int32_t *zero_hist, int nhist, const float *probe_rows, int probe_width, int nprobe,
+                                                          int chain)
 {
     const int lane = threadIdx.x & 63, j = lane & 15;
     const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
@@ -1500,6 +1810,22 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
         if (p1 && nrow >= k && probed > seed) seed = probed;
     }
     uint32_t mask = grouped_mask_lanes(hi, seed, j);
+    // How far a score of this user as a scan kernel computes it (split bf16: 3 x 2^-18 per product + the f32 accumulation; exact
+    // f32: an MFMA chain from alpha) can lie from the same score in the tie repair's plain-f32 arithmetic -- the ranking the
+    // lists are finished in (m2d_topk_refine): 2e-5 reach + gam (|alpha| + reach), the largest over ALL patterns with dishes,
+    // so that it does not depend on the option form (seed and mask do).
+    // (the repair takes alpha_P from this plan's words, bit for bit as the scan kernels form it: the high-level dot products'
+    // own rounding is common to both and drops out.  Split bf16: 3 x 2^-18 |w||r| for the products and the splits; both: gam
+    // |w||r| for the f32 accumulation orders; 4 u |score| for the final sums; an exact-f32 MFMA chain starts from alpha and
+    // rounds its running sum E / 2 times at the score's magnitude -- `chain`.)
+    const float smag = fabsf(pb.alpha) + pb.reach;
+    // per unit of |w||r|: 1.2e-5 for the split (3 x 2^-18 = 1.144e-5), (E + 8) u for the split-bf16 kernel's f32 accumulation of E
+    // products in whatever order the matrix pipe takes, (E / 16 + 12) u for the repair's own chain + rotation tree
+    float delta = (j >= 1 && grp[40 + j] > 0)
+                      ? (1.2e-5f + (float)(E + E / 16 + 20) * 5.9604645e-8f) * pb.reach + (4.f + (chain ? 0.5f * (float)E + 4.f : 0.f)) * 5.9604645e-8f * smag
+                      : 0.f;
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) delta = fmaxf(delta, __shfl_xor(delta, off, 64));
     if (no_alpha == 1) { seed = -INFINITY; mask = 0xfffeu; }     // ingredient rows: the score has no alpha_P term to bound it with
     if (no_alpha == 2) mask = 0xfffeu;                        // option topk_prune = 2: the bound, but every pattern (A/B)
     if (no_alpha == 4) seed = -INFINITY;                      // option topk_prune = 4: the patterns, but no bound (A/B)
@@ -1507,7 +1833,7 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
         float *o = plan + (size_t)u * 8;
         o[0] = seed; o[1] = hc[0]; o[2] = hc[1]; o[3] = hc[2]; o[4] = hc[3]; o[5] = __uint_as_float(mask);
         o[6] = __int_as_float(thr_key(seed));               // the dish ranges' shared running threshold starts at the bound
-        o[7] = 0.f;
+        o[7] = delta;
     }
 }
 
@@ -1659,9 +1985,14 @@ __global__ __launch_bounds__(1024) void m2d_plan_items_sort(const int32_t *work,
 template <int KR>
 __device__ __forceinline__ void grouped_publish(float *ls, int32_t *li, const float (&rs)[KR], const int32_t (&ri)[KR],
                                                 const GroupedArgs &p, const int lane, const int64_t uidx, const bool uvalid,
-                                                const unsigned long long tie_mask, const int split)
+                                                const unsigned long long tie_mask, const int split,
+                                                const LeftOut lo = M2D_LEFTOUT_NONE)
 {
     const int j = lane & 31, h = lane >> 5, k = p.k;
+    // this lane's left-out scores, and the other lane's of the same user (l + 32), for the lane that merges the two lists
+    const int32_t lo_id1 = (p.ex_out && lo.i1 >= 0) ? p.perm[lo.i1] : -1, lo_id2 = (p.ex_out && lo.i2 >= 0) ? p.perm[lo.i2] : -1;
+    const float lob_s1 = __shfl(lo.s1, j + 32, 64), lob_s2 = __shfl(lo.s2, j + 32, 64), lob_s3 = __shfl(lo.s3, j + 32, 64);
+    const int32_t lob_id1 = __shfl(lo_id1, j + 32, 64), lob_id2 = __shfl(lo_id2, j + 32, 64);
     int cnt = 0;
 #pragma unroll
     for (int i = 0; i < KR; ++i) {
@@ -1702,6 +2033,21 @@ __device__ __forceinline__ void grouped_publish(float *ls, int32_t *li, const fl
         const bool tie = full && ((pa < ca && ls[pa * 64 + lane] == last) || (pb < cb && ls[pb * 64 + lane + 32] == last) ||
                                   (tie_a && ls[(KR - 1) * 64 + lane] == last) || (tie_b && ls[(KR - 1) * 64 + lane + 32] == last));
         p.tie_val[(size_t)uidx * p.nsplit + split] = tie ? last : __builtin_nanf("");
+        if (p.ex_out) {
+            // left out of this range's list: what the two lanes left out, and what the merge left behind in their lists (two
+            // entries of each suffice for the best two)
+            LeftOut o = lo;
+            o.i1 = lo_id1; o.i2 = lo_id2;
+            left_out_merge(o, lob_s1, lob_id1);
+            left_out_merge(o, lob_s2, lob_id2);
+            left_out_merge(o, lob_s3, -1);
+            for (int q = 0; q < 3; ++q) {                    // three entries of each list suffice for the best three
+                if (pa + q < ca) left_out_merge(o, ls[(pa + q) * 64 + lane], li[(pa + q) * 64 + lane]);
+                if (pb + q < cb) left_out_merge(o, ls[(pb + q) * 64 + lane + 32], li[(pb + q) * 64 + lane + 32]);
+            }
+            float *ex = p.ex_out + ((size_t)uidx * p.nsplit + split) * 8;
+            ex[0] = o.s1; ex[1] = __int_as_float(o.i1); ex[2] = o.s2; ex[3] = __int_as_float(o.i2); ex[4] = o.s3;
+        }
     }
 }
 
@@ -1763,6 +2109,9 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
 #pragma unroll
     for (int c = 0; c < C; ++c) hc[c] = rec[1 + c];
     const float seed = uvalid ? rec[0] : INFINITY;         // a lane without a user never has a candidate
+    constexpr bool EXT = !PAD && E8 <= 16;                 // what the lists leave out is kept for m2d_topk_refine (p.ex_out; E = 32 / 64 / 128)
+    const float dlt2 = (EXT && p.ex_out && uvalid) ? 2.f * rec[7] : 0.f;     // scores this close under a threshold still reach the insertion
+    LeftOut lout = M2D_LEFTOUT_NONE;
     uint32_t umask_lane = uvalid ? __float_as_uint(rec[5]) : 0u;
     __shared__ uint32_t s_umask;
     if (threadIdx.x == 0) s_umask = 0u;
@@ -1900,15 +2249,17 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
 #pragma unroll
             for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
             mx = fmaxf(mx, acc[15]);
-            if (!__any(mx >= thr)) continue;
+            if (!__any(mx >= thr - dlt2)) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = acc[r];
-                const bool cand = v >= thr;
+                const bool cand = v >= thr - dlt2;
                 if (__any(cand)) {
                     const float old_last = rs[KR - 1];
+                    const int32_t old_id = ri[KR - 1];
                     sorted_insert<KR>(rs, ri, v, sbase + (r & 3) + 8 * (r >> 2));
                     tie_mask = tie_update(tie_mask, v, old_last, rs[KR - 1]);
+                    if (EXT) left_out_note(lout, fmaxf(v, -INFINITY), sbase + (r & 3) + 8 * (r >> 2), old_last, old_id, rs[KR - 1] - dlt2);
                     thr = fmaxf(rs[KR - 1], seed);
                 }
             }
@@ -1923,7 +2274,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
     // ---- publish (slot -> dish id), merge the two lanes of each user -------------------------------------
     float *ls = smem + (size_t)wave * 2 * KR * 64;       // aliases stage 0: every wave is past the last barrier
     int32_t *li = reinterpret_cast<int32_t *>(ls + (size_t)KR * 64);
-    grouped_publish<KR>(ls, li, rs, ri, p, lane, uidx, uvalid, tie_mask, by);
+    grouped_publish<KR>(ls, li, rs, ri, p, lane, uidx, uvalid, tie_mask, by, lout);
     (void)k;
 }
 
@@ -2175,7 +2526,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
 // WAVES: 8 / G (a block of 256 users, 128 KiB of LDS, one block per CU), or 4 with G = 1: a block of 128 users over stages of
 // half the tiles (64 KiB of LDS), TWO blocks per CU -- a stage barrier then holds up four waves, not eight, and the CU's other
 // block keeps the matrix pipes busy meanwhile (launch_grouped: pruned launches, where the waves of a block are unequal).
-template <int E, int KR, int G, bool HV = false, int WAVES = 8 / G>
+template <int E, int KR, int G, bool HV = false, int WAVES = 8 / G, bool KEEP = false>
 __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(GroupedArgs p)
 {
     constexpr int C = 4;
@@ -2197,6 +2548,10 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
                                                            // pruned call and 6 % of an every-tile one and bought nothing (one instantiation
                                                            // spilled), with the ingredient table (no plan bound to start from) 3 %
     constexpr int AR = KS < 4 ? KS : 4;                    // A-fragment register sets: the LDS reads run AR k-steps ahead
+    constexpr bool EXT = KEEP && !HV && !(E == 128 && KR == 16);   // what the lists leave out is kept for m2d_topk_refine (p.ex_out): an
+                                                           // instantiation of its own (the bookkeeping's registers and code cost the scan
+                                                           // 6 % also when it is not asked for), and five registers the E = 128, k > 10
+                                                           // instantiation does not have
     static_assert(PIECES % WAVES == 0 && (WAVES * 64) % S8 == 0 && ((WAVES * 64 / S8) / RPB) % S8 == 0, "piece layout");
 
     extern __shared__ __align__(16) unsigned char smem8[];
@@ -2219,6 +2574,8 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
     const v4f *pmu[G];
     float hc[G][C];                                        // <U_high, CE_c>   Model_Recommender.py:67-75 (from the plan)
     float seed[G];                                         // scan-start bound of the user's final k-th score (from the plan)
+    float dlt2[G];                                         // 2 delta: scores this close under a threshold still reach the insertion
+    LeftOut lout[G];                                       // what this lane's list leaves out (EXT)
     uint32_t umask_lane = 0u;                              // patterns that can reach the top-k of this lane's user(s)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -2243,6 +2600,8 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
 #pragma unroll
         for (int c = 0; c < C; ++c) hc[g][c] = rec[1 + c];
         seed[g] = uvalid[g] ? rec[0] : INFINITY;            // a lane without a user never has a candidate
+        dlt2[g] = (EXT && p.ex_out && uvalid[g]) ? 2.f * rec[7] : 0.f;
+        lout[g] = M2D_LEFTOUT_NONE;
         if (SHARE && p.shared_thr && uvalid[g])             // what the user's other dish ranges have reached so far (see exchange_thresholds)
             seed[g] = fmaxf(seed[g], thr_unkey(__hip_atomic_load(p.shared_thr + (size_t)uidx[g] * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
         umask_lane |= uvalid[g] ? __float_as_uint(rec[5]) : 0u;
@@ -2456,11 +2815,13 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
                     const float (&thr_rel)[G], unsigned long long (&m)[G][16], float (&mx)[G]) __attribute__((always_inline)) {
         constexpr bool INS = decltype(ins_tag)::value;
         float x[G], old_last[G];
+        int32_t old_id[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             x[g] = fmaxf(px[g], -INFINITY);
             mx[g] = -INFINITY;
             old_last[g] = rs[g][KR - 1];
+            old_id[g] = ri[g][KR - 1];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -2499,6 +2860,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 tie_mask[g] = tie_update(tie_mask[g], x[g], old_last[g], rs[g][KR - 1]);
+                if (EXT) left_out_note(lout[g], x[g], pid[g], old_last[g], old_id[g], rs[g][KR - 1] - dlt2[g]);
                 share_threshold(g);
             }
         }
@@ -2599,7 +2961,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const float d = thr[g] - alpha_prev[g];
-            thr_rel[g] = d - 2.4e-7f * (fabsf(thr[g]) + fabsf(alpha_prev[g]));   // 2^-22 (|thr| + |alpha|); thr = +inf: NaN, no candidate
+            thr_rel[g] = d - 2.4e-7f * (fabsf(thr[g]) + fabsf(alpha_prev[g])) - dlt2[g];   // 2^-22 (|thr| + |alpha|); thr = +inf: NaN, no candidate
         }
         const int img_off = (int)(((q / TPS) & 1) * STAGE_BYTES + sub * TILE_BYTES) + lane_off;   // tile q
         const int img_prev = (int)((((q - 1) / TPS) & 1) * STAGE_BYTES + ((q - 1) & (TPS - 1)) * TILE_BYTES) + lane_off;
@@ -2676,8 +3038,10 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
                             float xv = __int_as_float(lane_select(b3, __float_as_int(t2[1]), __float_as_int(t2[0])));
                             xv = has ? xv + alpha_prev[g] : -INFINITY;    // a lane without a candidate inserts nothing
                             const float ol = rs[g][KR - 1];
+                            const int32_t oi = ri[g][KR - 1];
                             sorted_insert_inplace<KR>(rs[g], ri[g], xv, sbase + (r & 3) + 8 * (r >> 2));
                             tie_mask[g] = tie_update(tie_mask[g], xv, ol, rs[g][KR - 1]);
+                            if (EXT) left_out_note(lout[g], xv, sbase + (r & 3) + 8 * (r >> 2), ol, oi, rs[g][KR - 1] - dlt2[g]);
                             rm &= ~(0x8000u >> r);
                         }
                     } else {
@@ -2685,8 +3049,10 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
                         for (int r = 0; r < 16; ++r) {
                             if (m[g][r] != 0ull) {
                                 const float ol = rs[g][KR - 1], xv = accP[g][r] + alpha_prev[g];
+                                const int32_t oi = ri[g][KR - 1];
                                 sorted_insert_inplace<KR>(rs[g], ri[g], xv, sbase + (r & 3) + 8 * (r >> 2));
                                 tie_mask[g] = tie_update(tie_mask[g], xv, ol, rs[g][KR - 1]);
+                                if (EXT) left_out_note(lout[g], fmaxf(xv, -INFINITY), sbase + (r & 3) + 8 * (r >> 2), ol, oi, rs[g][KR - 1] - dlt2[g]);
                             }
                         }
                     }
@@ -2721,8 +3087,10 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const float ol = rs[g][KR - 1];
+            const int32_t oi = ri[g][KR - 1];
             sorted_insert_inplace<KR>(rs[g], ri[g], px[g], pid[g]);
             tie_mask[g] = tie_update(tie_mask[g], fmaxf(px[g], -INFINITY), ol, rs[g][KR - 1]);
+            if (EXT) left_out_note(lout[g], fmaxf(px[g], -INFINITY), pid[g], ol, oi, rs[g][KR - 1] - dlt2[g]);
         }
     }
     if (SHARE && p.shared_thr && n > 0) {                  // what this range ends with: ranges of the user that start later begin there
@@ -2751,7 +3119,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
     for (int g = 0; g < G; ++g) {
         float *ls = reinterpret_cast<float *>(smem8) + (size_t)(wave * G + g) * 2 * KR * 64;   // aliases stage 0
         int32_t *li = reinterpret_cast<int32_t *>(ls + (size_t)KR * 64);
-        grouped_publish<KR>(ls, li, rs[g], ri[g], p, lane, uidx[g], uvalid[g], tie_mask[g], by);
+        grouped_publish<KR>(ls, li, rs[g], ri[g], p, lane, uidx[g], uvalid[g], tie_mask[g], by, lout[g]);
     }
     (void)k;
 }
@@ -2834,12 +3202,13 @@ int refresh_grouped_nonfinite(m2d_engine *h, hipStream_t st)
 
 void m2d_launch_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k, float *out_s, int32_t *out_i,
                              hipStream_t st, const float *tie_in = nullptr, float *tie_out = nullptr, int32_t *tie_list = nullptr,
-                             int64_t I = 0)
+                             int64_t I = 0, const float *ex_in = nullptr, float *ex_out = nullptr, const float *plan = nullptr,
+                             int32_t *rcount = nullptr)
 {
     int lpu = 1;
     while (lpu < nsplit) lpu <<= 1;
     const unsigned grid = (unsigned)((nU * lpu + 255) / 256);
-#define M2D_MERGE(L) if (lpu == L) hipLaunchKernelGGL(m2d_topk_merge_splits<L>, dim3(grid), dim3(256), 0, st, ps, pi, nU, nsplit, k, out_s, out_i, tie_in, tie_out, tie_list, I);
+#define M2D_MERGE(L) if (lpu == L) hipLaunchKernelGGL(m2d_topk_merge_splits<L>, dim3(grid), dim3(256), 0, st, ps, pi, nU, nsplit, k, out_s, out_i, tie_in, tie_out, tie_list, I, ex_in, ex_out, plan, rcount);
     M2D_MERGE(1) M2D_MERGE(2) M2D_MERGE(4) M2D_MERGE(8) M2D_MERGE(16) M2D_MERGE(32) M2D_MERGE(64)
 #undef M2D_MERGE
 }
@@ -2849,17 +3218,21 @@ void m2d_launch_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int
 // tmp_s / tmp_i hold nU * (nsplit / 64) * k entries.  Consecutive groups are consecutive dish ranges, so the
 // lower-split-wins tie rule carries through both passes.
 // tie: [nU * nsplit] values of the splits, then room for the nU * (nsplit / 64) of the first pass, then the nU final ones
+// ex: [nU * nsplit] x 8 floats of the splits' left-out scores (LeftOut), then room for the first pass's nU * (nsplit / 64), then the
+// nU final ones -- laid out like `tie`; null = not kept
 void m2d_launch_merge_splits2(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k, float *tmp_s, int32_t *tmp_i,
-                              float *out_s, int32_t *out_i, hipStream_t st, float *tie, float *tie_final, int32_t *tie_list, int64_t I)
+                              float *out_s, int32_t *out_i, hipStream_t st, float *tie, float *tie_final, int32_t *tie_list, int64_t I,
+                              float *ex = nullptr, float *ex_final = nullptr, const float *plan = nullptr, int32_t *rcount = nullptr)
 {
     if (nsplit <= 64) {
-        m2d_launch_merge_splits(ps, pi, nU, nsplit, k, out_s, out_i, st, tie, tie_final, tie_list, I);
+        m2d_launch_merge_splits(ps, pi, nU, nsplit, k, out_s, out_i, st, tie, tie_final, tie_list, I, ex, ex_final, plan, rcount);
         return;
     }
     const int G = nsplit / 64;
     float *tie_mid = tie + (size_t)nU * nsplit;
-    m2d_launch_merge_splits(ps, pi, nU * G, 64, k, tmp_s, tmp_i, st, tie, tie_mid);      // a "user" of this pass is (user, group)
-    m2d_launch_merge_splits(tmp_s, tmp_i, nU, G, k, out_s, out_i, st, tie_mid, tie_final, tie_list, I);
+    float *ex_mid = ex ? ex + (size_t)nU * nsplit * 8 : nullptr;
+    m2d_launch_merge_splits(ps, pi, nU * G, 64, k, tmp_s, tmp_i, st, tie, tie_mid, nullptr, 0, ex, ex_mid);      // a "user" of this pass is (user, group)
+    m2d_launch_merge_splits(tmp_s, tmp_i, nU, G, k, out_s, out_i, st, tie_mid, tie_final, tie_list, I, ex_mid, ex_final, plan, rcount);
 }
 
 // shared tail of every MFMA retrieval launch: dish-range splits -> partial lists in scratch.  The grouped kernels run
@@ -2920,7 +3293,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     a.grp = h->grp_work + (size_t)((h->I + 255) / 256) * GRP_KEYS;
     a.users = users; a.nU = nU; a.U = h->U; a.user_base = h->user_base; a.k = k; a.tiles = h->grp_tiles;
     a.a = h->a; a.b = h->b; a.err = h->err_dev; a.dbg = g_m2d_diag_buffer; a.e_real = h->E;
-    a.plan = nullptr; a.order = nullptr; a.tiles_scanned = nullptr; a.items = nullptr; a.shared_thr = nullptr;
+    a.plan = nullptr; a.order = nullptr; a.tiles_scanned = nullptr; a.items = nullptr; a.shared_thr = nullptr; a.ex_out = nullptr;
     const int64_t ublocks = (nU + 32 * WV - 1) / (32 * WV);
     int nsplit = pick_splits(h, ublocks, a.tiles, 2 * TPS, 512);
     if ((!BF16X3 || (!HV && h->opt_topk_form != 1)) && h->opt_topk_prune != 0 && h->opt_variant < 100) {
@@ -2965,6 +3338,25 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     if (!planned) M2D_HIP_TRY(h, hipMemsetAsync(tie_list, 0, sizeof(int32_t), st));
     h->topk_tie_final = tie_final;
     h->topk_flags_used = nU;
+    // what the lists leave out, for m2d_topk_refine (kernels that keep it: see EXT in the scan kernels)
+    const bool ext = planned && h->opt_topk_refine != 0 && !HV && !PAD &&
+                     (BF16X3 ? (pipe && !(E == 128 && KR == 16)) : E8 <= 16);
+    float *ex_final = nullptr;
+    if (ext) {
+        const size_t ex_need = ((size_t)nU * (nsplit > 1 ? nsplit + (nsplit > 64 ? nsplit / 64 : 0) + 1 : 1)) * 8 + (size_t)nU + 8;
+        if (h->topk_ex_cap < ex_need) {
+            if (h->topk_ex) M2D_HIP_TRY(h, hipFree(h->topk_ex));
+            h->topk_ex = nullptr; h->topk_ex_cap = 0;
+            M2D_HIP_TRY(h, hipMalloc((void **)&h->topk_ex, ex_need * sizeof(float)));
+            h->topk_ex_cap = ex_need;
+        }
+        a.ex_out = h->topk_ex;
+        ex_final = h->topk_ex + (nsplit > 1 ? (size_t)nU * (nsplit + (nsplit > 64 ? nsplit / 64 : 0)) * 8 : 0);
+        h->topk_refine_counter = reinterpret_cast<int32_t *>(h->topk_ex + ex_need - (size_t)nU - 8);     // [0] refined [1] sent to the repair [2] listed; [8..] the list
+        M2D_HIP_TRY(h, hipMemsetAsync(h->topk_refine_counter, 0, 4 * sizeof(int32_t), st));
+    } else {
+        h->topk_refine_counter = nullptr;
+    }
     const size_t tmp_entries = nsplit > 64 ? (size_t)nU * (nsplit / 64) * k : 0;
     if (nsplit > 1) {
         const size_t need = ((size_t)nU * nsplit * k + tmp_entries) * 8 + 256;
@@ -3009,7 +3401,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
             const int nprobe = a.tiles < 8192 ? 16 : (a.tiles < 65536 ? 32 : PLAN_PROBES);
             auto pk = h->E <= 64 ? m2d_topk_user_plan<1> : (h->E <= 128 ? m2d_topk_user_plan<2> : m2d_topk_user_plan<4>);
             hipLaunchKernelGGL(pk, pgrid, dim3(256), 0, st, h->pm, h->ce, users, nU, h->U, h->user_base, h->E, a.grp, (int)k, h->a, h->b, pmode,
-                               plan, tie_list, counter, sorted ? hist : nullptr, PLAN_KEYS, probes, h->grp_ew, nprobe);
+                               plan, tie_list, counter, sorted ? hist : nullptr, PLAN_KEYS, probes, h->grp_ew, nprobe, BF16X3 ? 0 : 1);
         }
         a.plan = plan;
         // dish ranges of a user share their thresholds (pipelined kernel; "topk_prune" = 7 keeps them apart: A/B)
@@ -3048,15 +3440,16 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
             hipLaunchKernelGGL(kern, grid, dim3(WAVES * 64), lds, st, a);
         } else {
             static_assert(WAVES == 8, "the pipelined kernel is written for 256 users per block");
+            constexpr bool CAN_KEEP = !(E == 128 && KR == 16);
             if constexpr (E == 64) {
                 if (half) {
-                    auto kern4 = m2d_topk_grouped_bf16_pipe2<E, KR, 1, false, 4>;
+                    auto kern4 = a.ex_out ? m2d_topk_grouped_bf16_pipe2<E, KR, 1, false, 4, true> : m2d_topk_grouped_bf16_pipe2<E, KR, 1, false, 4>;
                     M2D_HIP_TRY(h, m2d_lds_limit((const void *)kern4, (int)lds));
                     hipLaunchKernelGGL(kern4, grid, dim3(256), lds, st, a);
                 }
             }
             if (!half) {
-                auto kern = m2d_topk_grouped_bf16_pipe2<E, KR, 1>;
+                auto kern = (CAN_KEEP && a.ex_out) ? m2d_topk_grouped_bf16_pipe2<E, KR, 1, false, 8, CAN_KEEP> : m2d_topk_grouped_bf16_pipe2<E, KR, 1>;
                 M2D_HIP_TRY(h, m2d_lds_limit((const void *)kern, (int)lds));
                 hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);
             }
@@ -3069,7 +3462,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     M2D_HIP_TRY(h, hipGetLastError());
     if (nsplit > 1) {
         m2d_launch_merge_splits2(a.out_scores, a.out_ids, nU, nsplit, k, tmp_s, tmp_i, final_s, final_i, st, h->topk_flags, tie_final, tie_list,
-                                 h->I);
+                                 h->I, a.ex_out, ex_final, ext ? a.plan : nullptr, ext ? h->topk_refine_counter : nullptr);
         M2D_HIP_TRY(h, hipGetLastError());
     }
     {   // users whose final k-th score is tied with a score left out: re-ranked in dish-id order (none is the common case)
@@ -3078,7 +3471,8 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         r.users = users; r.tie_list = tie_list; r.nU = nU; r.U = h->U; r.I = h->I; r.user_base = h->user_base;
         r.C = h->C; r.E = h->E; r.k = k; r.a = h->a; r.b = h->b; r.out_scores = final_s; r.out_ids = final_i;
         r.rows = h->grp_rs; r.perm = h->grp_perm; r.grp = a.grp; r.ew = h->grp_ew;
-        r.plan = (a.plan && h->opt_topk_prune != 9) ? a.plan : nullptr;      // "topk_prune" = 9: the repair reads every pattern (A/B)
+        r.plan = a.plan;
+        r.all_patterns = h->opt_topk_prune == 9 ? 1 : 0;                     // "topk_prune" = 9: the repair reads every pattern (A/B)
         r.cap = h->opt_variant == 13 ? 2 : REPAIR_CAP;      // test hook: send all but two listed users to the one-block-per-user kernel
         r.part_s = h->topk_flags + tie_vals + 1 + (size_t)nU;
         r.part_i = reinterpret_cast<int32_t *>(r.part_s + (size_t)REPAIR_CAP * REPAIR_SPLITS * k);
@@ -3089,6 +3483,16 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         if (nsplit == 1)                                     // (with dish ranges the last merge pass has listed the tied users)
             hipLaunchKernelGGL(m2d_topk_tie_compact, dim3((unsigned)((nU + 255) / 256)), dim3(256), 0, st, tie_final, nU, tie_list, final_s,
                                final_i, (int)k, h->I);
+        if (ext) {                                           // near-tied lists: finished in the repair's arithmetic (may add to the repair's list)
+            RefineArgs f;
+            f.pm = h->pm; f.re = h->re; f.ce = h->ce; f.cats = h->dish_cats; f.plan = a.plan; f.tie_final = tie_final; f.ex = ex_final;
+            f.users = users; f.tie_list = tie_list; f.counter = h->topk_refine_counter; f.nU = nU; f.U = h->U; f.I = h->I;
+            f.user_base = h->user_base; f.E = h->E; f.k = k; f.a = h->a; f.b = h->b; f.out_scores = final_s; f.out_ids = final_i;
+            if (nsplit == 1)                                 // (with dish ranges the last merge pass has listed the near-tied users)
+                hipLaunchKernelGGL(m2d_topk_refine_flag, dim3((unsigned)((nU + 255) / 256)), dim3(256), 0, st, f);
+            if (h->E <= 64) hipLaunchKernelGGL(m2d_topk_refine<1>, dim3((unsigned)((nU + 63) / 64)), dim3(256), 0, st, f);
+            else hipLaunchKernelGGL(m2d_topk_refine<2>, dim3((unsigned)((nU + 63) / 64)), dim3(256), 0, st, f);
+        }
         if (ub == 4) {
             auto rk = m2d_topk_repair_scan<4, HV>;
             M2D_HIP_TRY(h, m2d_lds_limit((const void *)rk, (int)slds));

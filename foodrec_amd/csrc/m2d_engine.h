@@ -119,6 +119,11 @@ struct m2d_engine {
     int opt_topk_bf16x3 = 1;            // retrieval (build-defined) on split-bf16 MFMA; 0 = exact-f32 MFMA
     int opt_topk_grouped = 1;           // 0/1-mask catalogues: pattern-grouped retrieval (contraction over E); 0 = dense kernel
     int opt_topk_form = 0;              // split-bf16 retrieval kernel: 0 / 2 = pipelined form, 1 = first form
+    int opt_topk_refine = 1;            // near-tied lists are finished in the tie repair's plain-f32 arithmetic (m2d_topk_refine): 0 = off (A/B)
+    int64_t topk_refined = 0;           // diagnostics of the last call (device counters, read on request)
+    float *topk_ex = nullptr;           // what the lists leave out, per (user, dish range) / (user, group) / user: 4 floats each
+    size_t topk_ex_cap = 0;             // floats
+    int32_t *topk_refine_counter = nullptr;   // [2] users refined, users sent on to the repair (inside topk_ex's allocation)
     int opt_topk_block = 0;             // users per block of a pruned split-bf16 launch: 0 = the launcher's choice, 128 / 256 forced (A/B)
     int topk_block_users = 256;         // what the last pattern-grouped launch used (the tile counters count tiles of blocks this size)
     int opt_topk_prune = 1;             // pipelined form: blocks step through the tiles of their users' relevant mask patterns only (0 = every tile)

@@ -258,12 +258,17 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
  * user's dish ranges keep their thresholds apart (by default they meet in one atomic-max word per user, E = 64); 9: the tie
  * repair reads every pattern's dishes (by default only the patterns that can reach its users' top-k).  "topk_block"
  * (default 0): users per block of a pruned pipelined launch -- 0 = the launcher's choice (128 for E = 64, at least 16 384
- * users and catalogues up to 8 192 tiles, else 256), 128 / 256 forced; same lists.
+ * users and catalogues up to 8 192 tiles, else 256), 128 / 256 forced; same lists.  "topk_refine" (default 1): the
+ * pattern-grouped kernels (pipelined split-bf16 and exact f32, E = 32 / 64 / 128, k <= 10 at E = 128 split-bf16) finish
+ * near-tied lists -- neighbouring scores, or the last entry and a score left out, closer than twice the kernel's rounding
+ * margin -- in the tie repair's plain-f32 arithmetic, so that both kernels return the same dish ids (a few per cent of the
+ * users are re-scored, 10 % of a 65 536-user call); 0 = the lists as the scan leaves them.
  * m2d_score_pairs* (the reference path) is always exact float32.  Unknown names: M2D_ERR_INVALID_ARG.
  * m2d_get_option also answers three diagnostics of the last m2d_topk_users call on the pattern-grouped kernels (they
  * synchronise the device): "topk_repaired" (users re-ranked in id order because their k-th score was tied),
  * "topk_tiles_scanned" / "topk_tiles_full" (32-dish tiles the blocks stepped through / would have without pruning; a
- * block holds "topk_block_users" users, 256 or 128, which m2d_get_option answers too). */
+ * block holds "topk_block_users" users, 256 or 128, which m2d_get_option answers too), "topk_refined" /
+ * "topk_refine_repaired" (users whose near-tied list was finished by m2d_topk_refine / sent on to the tie repair). */
 int m2d_set_option(m2d_engine *h, const char *name, int64_t value);
 int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value);
 

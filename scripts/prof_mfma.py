@@ -66,8 +66,9 @@ if which in ("both", "topk"):
         eng.set_option("topk_prune", prune)
         avg, med = timed(lambda: eng.topk_users(users, 10))
         eng.check()
-        kn = eng.last_kernel()
-        first = launches.get(kn, 1 if x3 else 0) + WARM      # (the table-building call ran the default kernel once)
+        bu = eng.get_option("topk_block_users")              # 256, or 128: another instantiation of the scan kernel, its own trace name
+        kn = (eng.last_kernel(), bu)
+        first = launches.get(kn, 1 if (x3 and bu == 256) else 0) + WARM      # (the table-building call ran the default kernel once)
         launches[kn] = first + TIMED
         # flops of the tiles the blocks stepped through (a block's 256 or 128 user lanes x 32 dishes each; 3 MFMA passes in split bf16)
         scanned, full = eng.get_option("topk_tiles_scanned"), eng.get_option("topk_tiles_full")
@@ -77,7 +78,7 @@ if which in ("both", "topk"):
             "event_avg_ms": avg, "event_median_ms": med, "executed_flop_per_launch": flop,
             "frac_of_peak": flop / avg / 1e9 / (2500.0 if x3 else 157.3), "peak_TFLOPs": 2500.0 if x3 else 157.3,
             "tiles_scanned": scanned, "tiles_without_pruning": full, "pairs_per_s": n * I / avg * 1e3,
-            "scan_kernel_dispatches": [first, first + TIMED],
+            "scan_kernel_dispatches": [first, first + TIMED], "block_users": bu,
             "what": ("event time = the whole call (plan, sort, scan kernel, merge, tie repair); the trace's kernel time is the scan "
                      "kernel alone"),
             "repaired_users": repaired(eng)}

@@ -70,6 +70,9 @@ def main():
             base = {"m2d_topk_grouped_bf16x3": "m2d_topk_grouped_bf16_pipe2", "m2d_topk_grouped": "m2d_topk_grouped<",
                     "m2d_mlp_pc_bf16x3": "m2d_mlp_pc<"}.get(v["kernel"], v["kernel"])
             cands = [(n, k) for n, k in summ["kernels"].items() if base in n and "merge" not in n]
+            if v["kernel"] == "m2d_topk_grouped_bf16x3" and "block_users" in v:      # blocks of 128 users: the four-wave instantiation
+                tail = ", 4, " if v["block_users"] == 128 else ", 8, "       # ...<E, KR, 1, false, WAVES, KEEP>
+                cands = [(n, k) for n, k in cands if tail in n] or cands
             if not cands:
                 continue
             n, k = max(cands, key=lambda nk: nk[1]["total_ms"])

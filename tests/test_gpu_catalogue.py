@@ -509,3 +509,40 @@ def test_blocks_of_128_users_return_the_same_lists(k):
         assert np.array_equal(i, i0) and np.array_equal(s.view(np.int32), s0.view(np.int32)), key
     eng.set_option("topk_prune", 1); eng.set_option("topk_block", 0); eng.set_option("variant", 0)
     _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:50], k, dup=60)
+
+
+@pytest.mark.parametrize("E,k,I", [(64, 10, 9000), (128, 10, 7000), (64, 16, 9000), (64, 1, 3000), (128, 5, 20000)])
+def test_split_bf16_lists_are_the_exact_f32_kernels_lists(E, k, I):
+    """Dish ids are index output.  The split-bf16 kernel's products differ from the exact-f32 kernel's by up to ~1e-5 of
+    |w||r|, which used to reorder dishes whose scores sit closer than that (about 0.2 % of the lists).  Both kernels now finish
+    near-tied lists -- neighbouring scores, or the last entry and the best score left out, within 2 delta of each other -- in
+    ONE arithmetic, the tie repair's plain f32 (m2d_topk_refine), so they return the same ids; "topk_refine" = 0 is the old
+    behaviour.  Coarse-ish tables make near-ties common."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    U = 24000
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=E + k + 900, n_nan=5, dup=30)
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    users = torch.as_tensor(np.random.default_rng(k).permutation(U).astype(np.int32), device="cuda")
+    res = {}
+    for x3 in (1, 0):
+        eng.set_option("topk_bf16x3", x3)
+        for prune, forced in ((1, 0), (0, 101), (1, 105)):
+            eng.set_option("topk_prune", prune); eng.set_option("variant", forced)
+            s, i = eng.topk_users(users, k); eng.check()
+            res[x3, prune, forced] = (s.cpu().numpy(), i.cpu().numpy(), eng.get_option("topk_refined"))
+    i_ref = res[0, 0, 101][1]
+    for key, (s, i, refined) in res.items():
+        assert np.array_equal(i, i_ref), (key, int((i != i_ref).any(1).sum()), refined)
+    assert res[1, 1, 0][2] > 0                              # some lists were near-tied and went through the refinement
+    for x3 in (1, 0):                                       # and inside one kernel every option form returns the same bits
+        base = res[x3, 0, 101][0]
+        for key, (s, i, refined) in res.items():
+            if key[0] == x3:
+                assert np.array_equal(s.view(np.int32), base.view(np.int32)), key
+    eng.set_option("topk_bf16x3", 1); eng.set_option("topk_prune", 1); eng.set_option("variant", 0)
+    eng.set_option("topk_refine", 0)                        # without it the two kernels disagree on some near-tie (what was measured)
+    s_off, i_off = eng.topk_users(users, k); eng.check()
+    eng.set_option("topk_refine", 1)
+    _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:60], k, dup=30)
