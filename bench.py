@@ -1220,6 +1220,12 @@ def main():
                                                         "what": "option topk_refine = 0: the split-bf16 lists as the scan leaves them (round 3's "
                                                                 "behaviour); ids then differ from the exact-f32 kernel's wherever two scores sit inside "
                                                                 "the split's rounding"}
+                eng.set_option("topk_prune", 0)         # the every-tile form without it: the scan's own matrix-pipe fraction
+                try:
+                    et = catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U))
+                    line["catalogue_topk"]["refine_off"]["every_tile"] = {"median_ms": et["median_ms"], "roofline_frac": et["roofline"]["frac"]}
+                finally:
+                    eng.set_option("topk_prune", 1)
                 eng.set_option("topk_bf16x3", 0)
                 lists_f32_off = {}
                 catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, min(a.topk_users, U), keep=lists_f32_off)
