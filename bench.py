@@ -21,7 +21,7 @@ child's status.  At N > 1 the line also carries `sharded_topk_allgather` (the us
 top-k + RCCL all-gather, median of 7) and `routed_pairs_alltoall` (pairs routed to the owners of their users).
 
 Every line also carries `scaling_path`: the user-sharded top-k path north_star's ">= 6x at 8 GPUs" speaks of, at
-BASELINE configs[3]'s per-GPU shape (10 M / N users x 1 M dishes, E = 64; every user of the shard in rounds of 262 144,
+BASELINE configs[3]'s per-GPU shape (10 M / N users x 1 M dishes, E = 64; every user of the shard in rounds of 524 288,
 one all-gather of [shard, 10] x (f32, i32)) -- `--config 3|4` makes that path the timed step itself.
 
 Exit status: 3 when the in-run parity check of the timed kernel against the CPU restatement fails; 4 when a leg after
@@ -81,7 +81,7 @@ def parse():
                    help="BASELINE.json configs[3] / configs[4] as the timed step: 10 M / N users per GPU x 1 M replicated dishes, "
                         "E = 64 / 128, top-10 for EVERY user of the shard in rounds of --round-users, then ONE all-gather of "
                         "[shard, 10] x (f32 score, i32 id) (100 MB per rank at N = 8)")
-    p.add_argument("--round-users", type=int, default=262144, help="users per retrieval launch in the sharded top-k path")
+    p.add_argument("--round-users", type=int, default=524288, help="users per retrieval launch in the sharded top-k path")
     p.add_argument("--scaling-users", type=int, default=10_000_000,
                    help="users over ALL GPUs in the scaling_path block (configs[3]: 10 M; 0 = leave the block out)")
     p.add_argument("--topk-with-ingredients", action="store_true",

@@ -178,13 +178,14 @@ class UserShardedScorer:
                     torch.empty((0, k), dtype=torch.int32, device=self.device))
         return self.scorer.topk_users(users, k)
 
-    def topk_local_rounds(self, k: int, round_users: int = 262144):
+    def topk_local_rounds(self, k: int, round_users: int = 524288):
         """Top-k for EVERY user of this shard, computed in rounds of `round_users` users -- a launch and its scratch stay
         the same size whatever the shard holds (1.25 M users per GPU at BASELINE configs[3]) -- into one pair of
         ``[count, k]`` buffers: (scores f32, dish ids i32).  A round is one retrieval call, and a call sorts ITS users by
         the mask patterns that can reach their top-k: larger rounds make blocks of users that share more (fewer tiles
         stepped through) and spread the per-call launches thinner -- 10 M users x 1 M dishes: 0.59 s in rounds of 65 536,
-        0.46 s in rounds of 262 144, 0.44 s at 524 288 (the scratch grows with the round: 640 B per user)."""
+        0.46 s in rounds of 262 144, 0.44 s at 524 288 (round 4, with the left-out records: 0.418 / 0.406 s; the scratch grows
+        with the round: about 1 KB per user, 0.5 GB at the default)."""
         s = torch.empty((self.count, k), dtype=torch.float32, device=self.device)
         ids = torch.empty((self.count, k), dtype=torch.int32, device=self.device)
         into = getattr(self.scorer, "topk_users_into", None)          # ScoringEngine: straight into the slices, no copy
