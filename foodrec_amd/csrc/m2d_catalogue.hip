@@ -1701,7 +1701,7 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
                                                           int64_t user_base, int E, const int32_t *grp, int k, float a, float b,
                                                           int no_alpha, float *plan, int32_t *zero_tie, unsigned long long *zero_tiles,
                                                           int32_t *zero_hist, int nhist, const float *probe_rows, int probe_width, int nprobe,
-                                                          int chain)
+                                                          int chain, int32_t *zero_refine)
 {
     const int lane = threadIdx.x & 63, j = lane & 15;
     const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
@@ -1711,6 +1711,7 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
     {
         const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
         if (gid == 0) { *zero_tie = 0; *zero_tiles = 0ull; }
+        if (gid < 4 && zero_refine) zero_refine[gid] = 0;   // m2d_topk_refine's counters
         if (zero_hist)
             for (int64_t i = gid; i < nhist; i += (int64_t)gridDim.x * 256) zero_hist[i] = 0;
     }
@@ -3352,8 +3353,8 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         }
         a.ex_out = h->topk_ex;
         ex_final = h->topk_ex + (nsplit > 1 ? (size_t)nU * (nsplit + (nsplit > 64 ? nsplit / 64 : 0)) * 8 : 0);
-        h->topk_refine_counter = reinterpret_cast<int32_t *>(h->topk_ex + ex_need - (size_t)nU - 8);     // [0] refined [1] sent to the repair [2] listed; [8..] the list
-        M2D_HIP_TRY(h, hipMemsetAsync(h->topk_refine_counter, 0, 4 * sizeof(int32_t), st));
+        h->topk_refine_counter = reinterpret_cast<int32_t *>(h->topk_ex + ex_need - (size_t)nU - 8);     // [0] refined [1] sent to the repair; [8 + u] user u's word
+                                                                                                       // (zeroed by the plan kernel: no memset launch)
     } else {
         h->topk_refine_counter = nullptr;
     }
@@ -3401,7 +3402,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
             const int nprobe = a.tiles < 8192 ? 16 : (a.tiles < 65536 ? 32 : PLAN_PROBES);
             auto pk = h->E <= 64 ? m2d_topk_user_plan<1> : (h->E <= 128 ? m2d_topk_user_plan<2> : m2d_topk_user_plan<4>);
             hipLaunchKernelGGL(pk, pgrid, dim3(256), 0, st, h->pm, h->ce, users, nU, h->U, h->user_base, h->E, a.grp, (int)k, h->a, h->b, pmode,
-                               plan, tie_list, counter, sorted ? hist : nullptr, PLAN_KEYS, probes, h->grp_ew, nprobe, BF16X3 ? 0 : 1);
+                               plan, tie_list, counter, sorted ? hist : nullptr, PLAN_KEYS, probes, h->grp_ew, nprobe, BF16X3 ? 0 : 1, ext ? h->topk_refine_counter : nullptr);
         }
         a.plan = plan;
         // dish ranges of a user share their thresholds (pipelined kernel; "topk_prune" = 7 keeps them apart: A/B)
