@@ -69,6 +69,14 @@ for it in range(n):
         s1, i1 = s1.cpu().numpy(), i1.cpu().numpy()
         bad = np.flatnonzero((i1 != i0).any(1) | ~((s1 == s0) | (np.isnan(s1) & np.isnan(s0))).all(1))
         assert bad.size == 0, ("case %d seed %d" % (it, seed0 + it), kern, E, U, I, k, nU, prune, var, "style", style, "repaired", rep0, eng.get_option("topk_repaired"), bad.size, bad[:5], i1[bad[:2]], i0[bad[:2]], s1[bad[:2]], s0[bad[:2]])
+    if E in (64, 128) and not (E == 128 and k > 10):                       # index-exact lists: the other dtype's kernel returns the same ids
+        eng.set_option("topk_bf16x3", 1 - x3); eng.set_option("topk_prune", 1); eng.set_option("variant", 0)
+        s2, i2 = eng.topk_users(du, k); eng.check()
+        i2 = i2.cpu().numpy()
+        bad = np.flatnonzero((i2 != i0).any(1))
+        assert bad.size == 0, ("case %d seed %d" % (it, seed0 + it), "split-bf16 and exact-f32 ids differ", E, U, I, k, nU, "style", style, adv, bad.size,
+                               bad[:4], i2[bad[:2]], i0[bad[:2]], s2.cpu().numpy()[bad[:2]], s0[bad[:2]])
+        eng.set_option("topk_bf16x3", x3)
     all_items = np.arange(I); nv = min(k, I)
     PMf, REf, CEf = PM.astype(np.float32), RE.astype(np.float32), CE.astype(np.float32)
     for r in rng.integers(0, nU, 6):
