@@ -766,6 +766,7 @@ int m2d_set_option(m2d_engine *h, const char *name, int64_t value)
     else if (!strcmp(name, "topk_prune")) h->opt_topk_prune = (int)value;
     else if (!strcmp(name, "topk_block")) h->opt_topk_block = (int)value;
     else if (!strcmp(name, "topk_refine")) h->opt_topk_refine = (int)value;
+    else if (!strcmp(name, "topk_probes")) h->opt_topk_probes = (value >= 8 && value <= 64) ? (int)(value & ~7) : 0;
     else if (!strcmp(name, "topk_grouped")) h->opt_topk_grouped = (int)value;
     else if (!strcmp(name, "mlp_bf16x3")) h->opt_mlp_bf16x3 = (int)value;
     else if (!strcmp(name, "mlp_form")) h->opt_mlp_form = (int)value;

@@ -3399,7 +3399,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
             const dim3 pgrid((unsigned)((nU * 16 + 255) / 256));
             // probe rows per user: each costs a row read per user (16: +18 us for 65 536 users) and buys a tighter bound -- 16 rows
             // at 100 k dishes (0.71 ms; 32: 0.73), 32 at 1 M (3.83 ms; 16: 4.02)
-            const int nprobe = a.tiles < 8192 ? 16 : (a.tiles < 65536 ? 32 : PLAN_PROBES);
+            const int nprobe = h->opt_topk_probes ? h->opt_topk_probes : (a.tiles < 8192 ? 16 : (a.tiles < 65536 ? 32 : PLAN_PROBES));
             auto pk = h->E <= 64 ? m2d_topk_user_plan<1> : (h->E <= 128 ? m2d_topk_user_plan<2> : m2d_topk_user_plan<4>);
             hipLaunchKernelGGL(pk, pgrid, dim3(256), 0, st, h->pm, h->ce, users, nU, h->U, h->user_base, h->E, a.grp, (int)k, h->a, h->b, pmode,
                                plan, tie_list, counter, sorted ? hist : nullptr, PLAN_KEYS, probes, h->grp_ew, nprobe, BF16X3 ? 0 : 1, ext ? h->topk_refine_counter : nullptr);

@@ -18,6 +18,8 @@ eng = foodrec_amd.ScoringEngine(PM, RE, CE); eng.set_dish_categories(cats)
 users = torch.randperm(U, generator=g, device="cuda")[:n].to(torch.int32)
 if os.environ.get("PROBE_BLOCK"):
     eng.set_option("topk_block", int(os.environ["PROBE_BLOCK"]))    # users per block of the pruned pipelined launch (128 / 256)
+if os.environ.get("PROBE_NPROBE"):
+    eng.set_option("topk_probes", int(os.environ["PROBE_NPROBE"]))
 if os.environ.get("PROBE_REFINE"):
     eng.set_option("topk_refine", int(os.environ["PROBE_REFINE"]))  # near-tied lists finished in the repair's arithmetic (default 1)
 if os.environ.get("PROBE_F32"):
