@@ -1810,7 +1810,6 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
         const float probed = kth - 2.f * slack1;
         if (p1 && nrow >= k && probed > seed) seed = probed;
     }
-    uint32_t mask = grouped_mask_lanes(hi, seed, j);
     // How far a score of this user as a scan kernel computes it (split bf16: 3 x 2^-18 per product + the f32 accumulation; exact
     // f32: an MFMA chain from alpha) can lie from the same score in the tie repair's plain-f32 arithmetic -- the ranking the
     // lists are finished in (m2d_topk_refine): 2e-5 reach + gam (|alpha| + reach), the largest over ALL patterns with dishes,
@@ -1827,6 +1826,9 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
                       : 0.f;
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) delta = fmaxf(delta, __shfl_xor(delta, off, 64));
+    // a pattern is left out only if its dishes stay 2 delta under the bound: a score that close to the k-th must reach an
+    // insertion in every launch shape (the refinement's candidates may not depend on the option form)
+    uint32_t mask = grouped_mask_lanes(hi, seed - 2.f * delta, j);
     if (no_alpha == 1) { seed = -INFINITY; mask = 0xfffeu; }     // ingredient rows: the score has no alpha_P term to bound it with
     if (no_alpha == 2) mask = 0xfffeu;                        // option topk_prune = 2: the bound, but every pattern (A/B)
     if (no_alpha == 4) seed = -INFINITY;                      // option topk_prune = 4: the patterns, but no bound (A/B)
