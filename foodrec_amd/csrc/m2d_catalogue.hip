@@ -3284,8 +3284,10 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     // the barriers did -- 1 M dishes: 65 536 users 3.19 -> 3.24 ms, 262 144 users 10.7 -> 11.4 ms -- so: catalogues up to 8 192
     // tiles (64 MiB of image).  "topk_block" = 128 / 256 forces either.
     const bool half_ok = BF16X3 && !HV && E == 64 && pipe;
+    // (k > 10 with the left-out bookkeeping: that four-wave instantiation needs 261 registers, one wave per SIMD -- eight waves then)
+    const bool keep_regs_ok = !(KR == 16 && h->opt_topk_refine != 0);
     const bool half = half_ok && (h->opt_topk_block == 128 || (h->opt_topk_block == 0 && M2D_TOPK_HALF_BLOCKS && h->opt_topk_prune != 0 &&
-                                                              h->opt_variant < 100 && nU >= 16384 && h->grp_tiles <= 8192));
+                                                              h->opt_variant < 100 && nU >= 16384 && h->grp_tiles <= 8192 && keep_regs_ok));
     const int WV = half ? 4 : WAVES;                         // waves per block
     const int TPS = grouped_tiles_per_stage(E) * WV / WAVES;
     const size_t lds = (size_t)2 * TPS * 32 * E * sizeof(float);

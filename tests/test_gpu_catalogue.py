@@ -503,7 +503,8 @@ def test_blocks_of_128_users_return_the_same_lists(k):
         eng.set_option("topk_prune", prune); eng.set_option("topk_block", block); eng.set_option("variant", forced)
         s, i = eng.topk_users(users, k); eng.check()
         out[prune, block, forced] = (s.cpu().numpy(), i.cpu().numpy(), eng.get_option("topk_block_users"))
-    assert out[1, 0, 0][2] == 128 and out[1, 256, 0][2] == 256 and out[1, 128, 105][2] == 128 and out[0, 0, 101][2] == 256
+    # (k > 10 with the refinement's bookkeeping: the four-wave instantiation would need 261 registers, so the launcher keeps 256)
+    assert out[1, 0, 0][2] == (128 if k <= 10 else 256) and out[1, 256, 0][2] == 256 and out[1, 128, 105][2] == 128 and out[0, 0, 101][2] == 256
     s0, i0, _ = out[0, 0, 101]
     for key, (s, i, _) in out.items():
         assert np.array_equal(i, i0) and np.array_equal(s.view(np.int32), s0.view(np.int32)), key
