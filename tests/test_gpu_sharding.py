@@ -96,3 +96,64 @@ def test_routing_is_stable_and_owner_only(nccl_world1):
         pos = order[owner_sorted == r]
         assert torch.equal(pos, torch.sort(pos).values)        # stable: original order kept
         assert int(counts[r]) == int((own == r).sum())
+
+
+# ---- two ranks, real engines, ONE GPU, gloo: the N = 2 code path on hardware (correctness only: RCCL wants a GPU per rank) ----
+def _two_rank_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import foodrec_amd
+        from foodrec_amd.sharding import UserShardedScorer, shard_range
+        from oracle import m2d_oracle as oracle
+        from test_gpu_catalogue import _tables
+        U, I, E, k = 5003, 3000, 64, 10                      # 5003 users: the last shard is one user short
+        PM, RE, CE, cats = _tables(U, I, 4, E, seed=77, n_nan=3, dup=20)
+        base, count = shard_range(U, world, rank)
+        dev = torch.device("cuda", 0)
+        eng = foodrec_amd.ScoringEngine(PM[base:base + count], RE, CE, device=dev, user_base=base)
+        eng.set_dish_categories(cats)
+        sh = UserShardedScorer(eng, U, device=dev)
+        # retrieval: rounds with the all-gather pipelined behind the next round == rounds + one gather == one call
+        s1, i1 = sh.topk_all_users(k, round_users=700)
+        s2, i2 = sh.topk_all_users(k, round_users=700, pipelined=False)
+        s3, i3 = sh.topk_all_users(k)
+        assert i1.shape == (U, k) and torch.equal(i1, i2) and torch.equal(i1, i3) and torch.equal(s1.view(torch.int32), s2.view(torch.int32))
+        assert torch.equal(s1.view(torch.int32), s3.view(torch.int32))
+        # ... == one engine that holds every user
+        full = foodrec_amd.ScoringEngine(PM, RE, CE, device=dev)
+        full.set_dish_categories(cats)
+        sf, jf = full.topk_users(torch.arange(U, dtype=torch.int32, device=dev), k)
+        full.check()
+        assert torch.equal(jf, i1) and torch.equal(sf.view(torch.int32), s1.view(torch.int32))
+        # pairs: every rank brings its own batch, the owners score, the scores come back (two all-to-alls)
+        rng = np.random.default_rng(50 + rank)
+        nb = 3000 + 500 * rank
+        u2 = rng.integers(0, U, nb).astype(np.int32); d2 = rng.integers(0, I, nb).astype(np.int32)
+        m2 = cats[d2]
+        got = sh.score_pairs_routed(torch.as_tensor(u2, device=dev), torch.as_tensor(d2, device=dev), torch.as_tensor(m2, device=dev))
+        ref = oracle.inference_f64(PM, RE, CE, u2, d2, m2)
+        assert_scores_close(got.cpu().numpy(), ref, what="routed pairs over two ranks")
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_over_gloo(tmp_path):
+    """N = 2 on hardware, as far as a one-GPU box goes: two processes, each a real ScoringEngine over its user shard on cuda:0,
+    torch.distributed over gloo (device tensors).  The sharded retrieval -- rounds, per-round pieces gathered asynchronously --
+    returns on every rank the lists of ONE engine holding all users, bit for bit; pairs routed to their owners match the
+    restatement.  (RCCL needs a GPU per rank: the N > 1 TIMING stays the driver's.)"""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(os.path.join(tmp_path, "ok%d" % r)) for r in range(2))
