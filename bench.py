@@ -825,10 +825,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = launched
+    # M2D_BENCH_REHEARSE_ONE_GPU=1: every rank on cuda:0, torch.distributed over gloo (device tensors) -- a FUNCTIONAL run of the
+    # N > 1 legs on a one-GPU box (RCCL wants a GPU per rank); the line says so and its timings mean nothing
+    rehearse = use_dist and os.environ.get("M2D_BENCH_REHEARSE_ONE_GPU") == "1"
+    if rehearse:
+        local = 0
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: foodrec_amd has no CPU fallback")
     dev = torch.device("cuda", local)
@@ -1289,6 +1297,9 @@ def main():
                 rc = 3
                 print("bench.py: PARITY FAILURE: timed kernel vs CPU restatement, max |d| / max(1, |ref|) = %.3e > %.0e"
                       % (err, PARITY_TOL), file=sys.stderr)
+        if rehearse:
+            line["rehearsal"] = ("%d ranks share ONE GPU, collectives over gloo: a functional run of the N > 1 path "
+                                 "(M2D_BENCH_REHEARSE_ONE_GPU=1); its timings and rates mean nothing" % world)
         watchdog.cancel()
         print(json.dumps(line))
         sys.stdout.flush()
