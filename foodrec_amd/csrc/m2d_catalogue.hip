@@ -646,7 +646,11 @@ __global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, co
                 float *e = ex_out + (size_t)u * 8;
                 e[0] = o.s1; e[1] = __int_as_float(o.i1); e[2] = o.s2; e[3] = __int_as_float(o.i2); e[4] = o.s3;
             }
-            if (rcount && plan && !any && n_real > 0) {      // m2d_topk_refine_flag's decision, from the values at hand
+            // m2d_topk_refine_flag's decision, from the values at hand.  A tie at the list's end IS a near-tie (gap 0, the tied
+            // dish among the left-out ones): with the refinement on, it is settled there -- the same (score desc, id asc) ranking
+            // in the same arithmetic, over the handful of dishes that can matter instead of the user's patterns -- and the repair
+            // is left with the users that have three or more dishes that close (copies of dishes, all-zero users)
+            if (rcount && plan && n_real > 0) {
                 int nex = 0;
                 if (n_real == k) {
                     const float lim = last - d2;
@@ -661,7 +665,7 @@ __global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, co
             // the final pass of a pattern-grouped call also does m2d_topk_tie_compact's work: a tied user joins the repair's
             // list, everybody else's list is finished here (this lane wrote it: its own stores, in program order)
             if (tie_list) {
-                if (any || to_repair) tie_list[1 + atomicAdd(&tie_list[0], 1)] = (int32_t)u;
+                if (to_repair || (any && !(rcount && plan))) tie_list[1 + atomicAdd(&tie_list[0], 1)] = (int32_t)u;
                 else fill_absent_user(out_scores + u * k, out_ids + u * k, k, I);
                 if (to_repair) atomicAdd(&rcount[1], 1);
             }
@@ -696,11 +700,12 @@ constexpr int REPAIR_SPLITS = 64, REPAIR_CAP = 1024;
 // -- and the lists of everybody else finished on the way (m2d_topk_fill_absent's work; a listed user's list is finished by
 // the kernel that rewrites it)
 __global__ __launch_bounds__(256) void m2d_topk_tie_compact(const float *tie_final, int64_t nU, int32_t *tie_list, float *scores,
-                                                            int32_t *ids, int k, int64_t I)
+                                                            int32_t *ids, int k, int64_t I, int refined)
 {
     const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (u >= nU) return;
-    if (tie_final[u] == tie_final[u]) tie_list[1 + atomicAdd(&tie_list[0], 1)] = (int32_t)u;
+    // refined: m2d_topk_refine_flag decides about the tied users too (they are near-tied lists with a gap of 0)
+    if (!refined && tie_final[u] == tie_final[u]) tie_list[1 + atomicAdd(&tie_list[0], 1)] = (int32_t)u;
     else fill_absent_user(scores + u * k, ids + u * k, k, I);
 }
 
@@ -1169,9 +1174,7 @@ __global__ __launch_bounds__(256) void m2d_topk_refine_flag(RefineArgs p)
 {
     const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (u >= p.nU) return;
-    int32_t ent = -1;
-    if (!(p.tie_final[u] == p.tie_final[u])) ent = refine_flag_user(p, u);                 // (tie-listed: the repair rewrites that list)
-    p.counter[8 + u] = ent;
+    p.counter[8 + u] = refine_flag_user(p, u);
 }
 
 // 32 lanes per listed user, a lane per candidate (k <= 16 list entries + at most two left-out dishes): the candidate's score in
@@ -3487,7 +3490,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
         M2D_HIP_TRY(h, m2d_lds_limit((const void *)m2d_topk_repair_finish<HV>, (int)rlds));
         if (nsplit == 1)                                     // (with dish ranges the last merge pass has listed the tied users)
             hipLaunchKernelGGL(m2d_topk_tie_compact, dim3((unsigned)((nU + 255) / 256)), dim3(256), 0, st, tie_final, nU, tie_list, final_s,
-                               final_i, (int)k, h->I);
+                               final_i, (int)k, h->I, ext ? 1 : 0);
         if (ext) {                                           // near-tied lists: finished in the repair's arithmetic (may add to the repair's list)
             RefineArgs f;
             f.pm = h->pm; f.re = h->re; f.ce = h->ce; f.cats = h->dish_cats; f.plan = a.plan; f.tie_final = tie_final; f.ex = ex_final;

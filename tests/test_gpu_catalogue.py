@@ -471,16 +471,18 @@ def test_re_ranked_scores_do_not_depend_on_where_a_dish_was_scored(E, x3):
     eng.set_dish_categories(cats)
     eng.set_option("topk_bf16x3", x3)
     users = torch.as_tensor(np.random.default_rng(E).permutation(U).astype(np.int32), device="cuda")
-    out = {}
-    for prune, forced in ((0, 101), (1, 0), (9, 0), (1, 103), (9, 107), (1, 0)):
-        eng.set_option("topk_prune", prune); eng.set_option("variant", forced)
-        s, i = eng.topk_users(users, k); eng.check()
-        out.setdefault((prune, forced), []).append((s.cpu().numpy(), i.cpu().numpy(), eng.get_option("topk_repaired")))
-    s0, i0, rep = out[0, 101][0]
-    assert rep >= 100, rep                                 # the tables do send many users through the repair
-    for key, runs in out.items():
-        for s, i, r in runs:
-            assert np.array_equal(i, i0) and np.array_equal(s.view(np.int32), s0.view(np.int32)), (key, r, rep)
+    for refine in (0, 1):                                 # 0: every tied user goes through the repair; 1: only those with three or
+        eng.set_option("topk_refine", refine)             # more dishes that close (the others are settled by m2d_topk_refine)
+        out = {}
+        for prune, forced in ((0, 101), (1, 0), (9, 0), (1, 103), (9, 107), (1, 0)):
+            eng.set_option("topk_prune", prune); eng.set_option("variant", forced)
+            s, i = eng.topk_users(users, k); eng.check()
+            out.setdefault((prune, forced), []).append((s.cpu().numpy(), i.cpu().numpy(), eng.get_option("topk_repaired")))
+        s0, i0, rep = out[0, 101][0]
+        assert rep >= 100, rep                             # the tables do tie many users' k-th score
+        for key, runs in out.items():
+            for s, i, r in runs:
+                assert np.array_equal(i, i0) and np.array_equal(s.view(np.int32), s0.view(np.int32)), (refine, key, r, rep)
     eng.set_option("topk_prune", 1); eng.set_option("variant", 0)
     _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:40], k, dup=300)
 
