@@ -820,19 +820,15 @@ int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value)
     else if (!strcmp(name, "host_zero_copy")) *value = h->opt_host_zero_copy;
     else if (!strcmp(name, "num_cu")) *value = h->num_cu;
     else if (!strcmp(name, "topk_repaired")) {
-        // diagnostic (synchronises the device): users of the last pattern-grouped m2d_topk_users call that met a tie at a
-        // list boundary and were re-ranked in id order
+        // diagnostic (synchronises the device): users of the last pattern-grouped m2d_topk_users call that the tie repair re-ranked
+        // over their patterns (a tie at the list's end; with the refinement on: three or more dishes that close)
         *value = 0;
-        if (h->topk_tie_final && h->topk_flags_used > 0) {
-            float *tmp = new (std::nothrow) float[(size_t)h->topk_flags_used];
-            if (!tmp) return M2D_ERR_HIP;
+        if (h->topk_tie_list) {
+            int32_t c = 0;
             if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
-                hipMemcpy(tmp, h->topk_tie_final, (size_t)h->topk_flags_used * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
-                delete[] tmp;
+                hipMemcpy(&c, h->topk_tie_list, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess)
                 return M2D_ERR_HIP;
-            }
-            for (int64_t i = 0; i < h->topk_flags_used; ++i) *value += tmp[i] == tmp[i];
-            delete[] tmp;
+            *value = c;
         }
     }
     else return M2D_ERR_INVALID_ARG;

@@ -2554,6 +2554,8 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
                                                            // pruned call and 6 % of an every-tile one and bought nothing (one instantiation
                                                            // spilled), with the ingredient table (no plan bound to start from) 3 %
     constexpr int AR = KS < 4 ? KS : 4;                    // A-fragment register sets: the LDS reads run AR k-steps ahead
+    // (with EXT the tie bits are not kept: a tie at a list's end is a left-out score EQUAL to its last one, and the left-out
+    //  scores say so -- the merge's decision reads them)
     constexpr bool EXT = KEEP && !HV && !(E == 128 && KR == 16);   // what the lists leave out is kept for m2d_topk_refine (p.ex_out): an
                                                            // instantiation of its own (the bookkeeping's registers and code cost the scan
                                                            // 6 % also when it is not asked for), and five registers the E = 128, k > 10
@@ -2865,7 +2867,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
         if constexpr (INS) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                tie_mask[g] = tie_update(tie_mask[g], x[g], old_last[g], rs[g][KR - 1]);
+                if (!EXT) tie_mask[g] = tie_update(tie_mask[g], x[g], old_last[g], rs[g][KR - 1]);
                 if (EXT) left_out_note(lout[g], x[g], pid[g], old_last[g], old_id[g], rs[g][KR - 1] - dlt2[g]);
                 share_threshold(g);
             }
@@ -3046,7 +3048,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
                             const float ol = rs[g][KR - 1];
                             const int32_t oi = ri[g][KR - 1];
                             sorted_insert_inplace<KR>(rs[g], ri[g], xv, sbase + (r & 3) + 8 * (r >> 2));
-                            tie_mask[g] = tie_update(tie_mask[g], xv, ol, rs[g][KR - 1]);
+                            if (!EXT) tie_mask[g] = tie_update(tie_mask[g], xv, ol, rs[g][KR - 1]);
                             if (EXT) left_out_note(lout[g], xv, sbase + (r & 3) + 8 * (r >> 2), ol, oi, rs[g][KR - 1] - dlt2[g]);
                             rm &= ~(0x8000u >> r);
                         }
@@ -3057,7 +3059,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
                                 const float ol = rs[g][KR - 1], xv = accP[g][r] + alpha_prev[g];
                                 const int32_t oi = ri[g][KR - 1];
                                 sorted_insert_inplace<KR>(rs[g], ri[g], xv, sbase + (r & 3) + 8 * (r >> 2));
-                                tie_mask[g] = tie_update(tie_mask[g], xv, ol, rs[g][KR - 1]);
+                                if (!EXT) tie_mask[g] = tie_update(tie_mask[g], xv, ol, rs[g][KR - 1]);
                                 if (EXT) left_out_note(lout[g], fmaxf(xv, -INFINITY), sbase + (r & 3) + 8 * (r >> 2), ol, oi, rs[g][KR - 1] - dlt2[g]);
                             }
                         }
@@ -3095,7 +3097,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
             const float ol = rs[g][KR - 1];
             const int32_t oi = ri[g][KR - 1];
             sorted_insert_inplace<KR>(rs[g], ri[g], px[g], pid[g]);
-            tie_mask[g] = tie_update(tie_mask[g], fmaxf(px[g], -INFINITY), ol, rs[g][KR - 1]);
+            if (!EXT) tie_mask[g] = tie_update(tie_mask[g], fmaxf(px[g], -INFINITY), ol, rs[g][KR - 1]);
             if (EXT) left_out_note(lout[g], fmaxf(px[g], -INFINITY), pid[g], ol, oi, rs[g][KR - 1] - dlt2[g]);
         }
     }
@@ -3345,6 +3347,7 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     const bool planned = !BF16X3 || pipe;                    // (the first-form bf16 kernel takes no plan)
     if (!planned) M2D_HIP_TRY(h, hipMemsetAsync(tie_list, 0, sizeof(int32_t), st));
     h->topk_tie_final = tie_final;
+    h->topk_tie_list = tie_list;
     h->topk_flags_used = nU;
     // what the lists leave out, for m2d_topk_refine (kernels that keep it: see EXT in the scan kernels)
     const bool ext = planned && h->opt_topk_refine != 0 && !HV && !PAD &&
@@ -3554,6 +3557,7 @@ int launch_mfma(m2d_engine *h, TopkArgs &a, float *final_s, int32_t *final_i, hi
         a.out_scores = final_s;
         a.out_ids = final_i;
     }
+    h->topk_tie_list = nullptr;                             // (no tie repair on this path: "topk_repaired" answers 0)
     auto kern = m2d_topk_mfma<NB, WAVES, KR>;
     M2D_HIP_TRY(h, m2d_lds_limit((const void *)kern, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)ublocks, (unsigned)nsplit), dim3(WAVES * 64), lds, st, a);

@@ -103,6 +103,7 @@ struct m2d_engine {
     size_t topk_plan_cap = 0;           // floats
     unsigned long long *topk_tiles_counter = nullptr;   // tiles the blocks of the last pipelined launch stepped through (inside topk_plan)
     int64_t topk_tiles_full = 0;        // ... and what they would have stepped through without pattern pruning
+    int32_t *topk_tie_list = nullptr;   // [0] users the tie repair re-ranked in the last pattern-grouped call (get_option "topk_repaired")
     int64_t topk_flags_used = 0;        // users of the last pattern-grouped call (get_option "topk_repaired" counts the non-NaN values)
 
     // benchmarking knobs

@@ -262,11 +262,12 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
  * pattern-grouped kernels (pipelined split-bf16 and exact f32, E = 32 / 64 / 128, k <= 10 at E = 128 split-bf16) finish
  * near-tied lists -- neighbouring scores, or the last entry and a score left out, closer than twice the kernel's rounding
  * margin -- in the tie repair's plain-f32 arithmetic, so that both kernels return the same dish ids (a few per cent of the
- * users are re-scored, 10 % of a 65 536-user call); 0 = the lists as the scan leaves them.  "topk_probes" (default 0 = 16 /
+ * users are re-scored; ties at a list's end are settled there too, the tie repair keeps the users with three or more dishes
+ * that close; no measurable cost); 0 = the lists as the scan leaves them, ties repaired over the user's patterns.  "topk_probes" (default 0 = 16 /
  * 32 / 64 by catalogue size): probe rows per user of the retrieval plan, 8 ... 64 (A/B; more rows bought nothing measurable).
  * m2d_score_pairs* (the reference path) is always exact float32.  Unknown names: M2D_ERR_INVALID_ARG.
  * m2d_get_option also answers three diagnostics of the last m2d_topk_users call on the pattern-grouped kernels (they
- * synchronise the device): "topk_repaired" (users re-ranked in id order because their k-th score was tied),
+ * synchronise the device): "topk_repaired" (users the tie repair re-ranked over their patterns),
  * "topk_tiles_scanned" / "topk_tiles_full" (32-dish tiles the blocks stepped through / would have without pruning; a
  * block holds "topk_block_users" users, 256 or 128, which m2d_get_option answers too), "topk_refined" /
  * "topk_refine_repaired" (users whose near-tied list was finished by m2d_topk_refine / sent on to the tie repair). */

@@ -477,9 +477,10 @@ def test_re_ranked_scores_do_not_depend_on_where_a_dish_was_scored(E, x3):
         for prune, forced in ((0, 101), (1, 0), (9, 0), (1, 103), (9, 107), (1, 0)):
             eng.set_option("topk_prune", prune); eng.set_option("variant", forced)
             s, i = eng.topk_users(users, k); eng.check()
-            out.setdefault((prune, forced), []).append((s.cpu().numpy(), i.cpu().numpy(), eng.get_option("topk_repaired")))
+            out.setdefault((prune, forced), []).append((s.cpu().numpy(), i.cpu().numpy(),
+                                                        eng.get_option("topk_repaired") + (eng.get_option("topk_refined") if refine else 0)))
         s0, i0, rep = out[0, 101][0]
-        assert rep >= 100, rep                             # the tables do tie many users' k-th score
+        assert rep >= 100, rep                             # the tables do tie many users' k-th score (re-ranked by the repair, or refined)
         for key, runs in out.items():
             for s, i, r in runs:
                 assert np.array_equal(i, i0) and np.array_equal(s.view(np.int32), s0.view(np.int32)), (refine, key, r, rep)
