@@ -2916,7 +2916,10 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
             }
             const int left = g_tot - (int)(t - g_beg) * 32;
             nvalid = left < 32 ? left : 32;
-            if (gp != cur_pat) {
+            // a stage that straddles a group boundary brings a few tiles of a neighbouring pattern along: if none of the
+            // block's users can rank a dish of that pattern, its tiles are dummies (no row valid) and the operands stay
+            if (!((umask >> gp) & 1u)) nvalid = 0;
+            else if (gp != cur_pat) {
                 cur_pat = gp;
                 const int pat = gp;
                 const float inv_n = 1.0f / (float)__builtin_popcount(pat);
