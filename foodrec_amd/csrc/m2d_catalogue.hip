@@ -159,6 +159,15 @@ __device__ __forceinline__ void sorted_insert_range(float (&ls)[N], int32_t (&li
     }
 }
 
+// (the scores of slots [lo, hi) are final HERE: keeps the v_med3 of a range in the MFMA gap it was written into -- the
+//  compiler otherwise collects them behind the last MFMA of the step, where nothing hides them)
+template <int N, int LO, int HI>
+__device__ __forceinline__ void pin_range(float (&ls)[N])
+{
+#pragma unroll
+    for (int i = LO; i < HI; ++i) asm volatile("" : "+v"(ls[i]));
+}
+
 template <int N>
 __device__ __forceinline__ void sorted_insert_inplace(float (&ls)[N], int32_t (&li)[N], float x, const int32_t id)
 {
@@ -2822,6 +2831,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
     auto body = [&](auto ins_tag, v16f (&accN)[G], const v16f (&accP)[G], const int img_prev, const int img_off,
                     const float (&thr_rel)[G], unsigned long long (&m)[G][16], float (&mx)[G]) __attribute__((always_inline)) {
         constexpr bool INS = decltype(ins_tag)::value;
+        constexpr bool PIN = WAVES == 4;
         float x[G], old_last[G];
         int32_t old_id[G];
 #pragma unroll
@@ -2863,14 +2873,17 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(Groupe
                     m[g][r] = __ballot(accP[g][r] >= tr[g]);           // one v_cmp into an SGPR pair; folded into a
                     mx[g] = fmaxf(mx[g], accP[g][r]);                  // per-lane row map only if some lane has a candidate
                 }
+                if (PIN && INS) asm volatile("" : "+v"(mx[g]));
                 if constexpr (INS) {
                     // slots [lo, hi) of the list, highest ranges first
                     constexpr int PER = (KR + KS - 1) / KS;
-                    if (ks == 0) sorted_insert_range<KR, (KR - PER > 0 ? KR - PER : 0), KR>(rs[g], ri[g], x[g], pid[g]);
-                    if (ks == 1) sorted_insert_range<KR, (KR - 2 * PER > 0 ? KR - 2 * PER : 0), (KR - PER > 0 ? KR - PER : 0)>(rs[g], ri[g], x[g], pid[g]);
-                    if (ks == 2) sorted_insert_range<KR, (KR - 3 * PER > 0 ? KR - 3 * PER : 0), (KR - 2 * PER > 0 ? KR - 2 * PER : 0)>(rs[g], ri[g], x[g], pid[g]);
-                    if (ks == 3) sorted_insert_range<KR, (KS == 4 ? 0 : (KR - 4 * PER > 0 ? KR - 4 * PER : 0)), (KR - 3 * PER > 0 ? KR - 3 * PER : 0)>(rs[g], ri[g], x[g], pid[g]);
-                    if (KS > 4 && ks == 4) sorted_insert_range<KR, 0, (KR - 4 * PER > 0 ? KR - 4 * PER : 0)>(rs[g], ri[g], x[g], pid[g]);
+                    constexpr int L0 = KR - PER > 0 ? KR - PER : 0, L1 = KR - 2 * PER > 0 ? KR - 2 * PER : 0,
+                                  L2 = KR - 3 * PER > 0 ? KR - 3 * PER : 0, L3 = KS == 4 ? 0 : (KR - 4 * PER > 0 ? KR - 4 * PER : 0);
+                    if (ks == 0) { sorted_insert_range<KR, L0, KR>(rs[g], ri[g], x[g], pid[g]); if (PIN) pin_range<KR, L0, KR>(rs[g]); }
+                    if (ks == 1) { sorted_insert_range<KR, L1, L0>(rs[g], ri[g], x[g], pid[g]); if (PIN) pin_range<KR, L1, L0>(rs[g]); }
+                    if (ks == 2) { sorted_insert_range<KR, L2, L1>(rs[g], ri[g], x[g], pid[g]); if (PIN) pin_range<KR, L2, L1>(rs[g]); }
+                    if (ks == 3) { sorted_insert_range<KR, L3, L2>(rs[g], ri[g], x[g], pid[g]); if (PIN) pin_range<KR, L3, L2>(rs[g]); }
+                    if (KS > 4 && ks == 4) sorted_insert_range<KR, 0, L3>(rs[g], ri[g], x[g], pid[g]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
