@@ -2542,7 +2542,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
 // half the tiles (64 KiB of LDS), TWO blocks per CU -- a stage barrier then holds up four waves, not eight, and the CU's other
 // block keeps the matrix pipes busy meanwhile (launch_grouped: pruned launches, where the waves of a block are unequal).
 template <int E, int KR, int G, bool HV = false, int WAVES = 8 / G, bool KEEP = false>
-__global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16_pipe2(GroupedArgs p)
+__global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(GroupedArgs p)
 {
     constexpr int C = 4;
     constexpr int KS = E / 16;                             // k-steps (16 k-values) per tile
