@@ -3039,7 +3039,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                 cand[g] = rowmap[g] != 0u;
                 multi |= __ballot((rowmap[g] & (rowmap[g] - 1u)) != 0u);                      // two or more bits set
             }
-            if ((M2D_DIAG & 64) ? false : multi != 0ull) { // immediate path: some lane holds two or more candidates of this tile
+            // one candidate per lane at most: it is the lane's maximum, its row is the map's only set bit, and it is parked
+            // for the next step's body (written ahead of the branch, not as its else-arm: as the two arms of a diamond the
+            // compiler gave the lists other registers in the multi-candidate arm and paid for it in THIS arm -- 26 v_mov into
+            // those registers and 26 back at the merge, in every step with a candidate)
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int r = __builtin_clz(rowmap[g] | 1u) - 16;          // bit 15 - r  ->  r  (lanes without a candidate: any)
+                px[g] = cand[g] ? mx[g] + alpha_prev[g] : -INFINITY;
+                pid[g] = sbase + (r & 3) + 8 * (r >> 2);
+            }
+            pend = (M2D_DIAG & 128) ? (__ballot(px[0] == 12345.678f) != 0ull) : true;
+            if ((M2D_DIAG & 64) ? false : __builtin_expect(multi != 0ull, 0)) { // immediate path: some lane holds two or more candidates of this tile
+                pend = false;
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     // Two ways to get them in.  Row by row: every row in which SOME lane has a candidate is inserted by the
@@ -3049,12 +3061,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                     // (about 85 VALU a pass, passes = the most candidates any lane holds).  In the tiles of a pattern the
                     // block's users all want -- the only tiles a pruned scan still visits -- nearly every row has a taker
                     // but a lane has two or three: 16 x 55 against 3 x 85.
+                    // (Which is cheaper was worked out per tile from the number of rows with a taker -- sixteen scalar
+                    //  compares the compiler turned into 32 VALU + 32 SALU, more than the choice ever saved: row by row wins
+                    //  only when at most 3 / 4 / 6 rows have takers while a lane holds 2 / 3 / 4.  Now: lane by lane up to
+                    //  four candidates per lane.)
                     const uint32_t pc = (uint32_t)__builtin_popcount(rowmap[g]);
-                    const bool b5 = __ballot(pc >= 5u) != 0ull, b4 = __ballot(pc >= 4u) != 0ull, b3 = __ballot(pc >= 3u) != 0ull;
-                    int rows_any = 0;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) rows_any += m[g][r] != 0ull ? 1 : 0;
-                    if (!b5 && (2 + (b3 ? 1 : 0) + (b4 ? 1 : 0)) * 85 < rows_any * 55) {
+                    const bool b5 = __ballot(pc >= 5u) != 0ull;
+                    if (!b5) {
                         uint32_t rm = rowmap[g];
                         while (__ballot(rm != 0u) != 0ull) {        // wave-uniform; a lane's rows in ascending order
                             const bool has = rm != 0u;
@@ -3096,15 +3109,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
 #if M2D_DIAG & 16
                 ++n_ins;
 #endif
-            } else {
-                // one candidate per lane at most: it is the lane's maximum, and its row is the map's only set bit
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const int r = __builtin_clz(rowmap[g] | 1u) - 16;          // bit 15 - r  ->  r  (lanes without a candidate: any)
-                    px[g] = cand[g] ? mx[g] + alpha_prev[g] : -INFINITY;
-                    pid[g] = sbase + (r & 3) + 8 * (r >> 2);
-                }
-                pend = (M2D_DIAG & 128) ? (__ballot(px[0] == 12345.678f) != 0ull) : true;
             }
 #if M2D_DIAG & 16
             asm volatile("" ::"v"(thr[0]), "v"(px[0]));
