@@ -3067,32 +3067,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                     //  four candidates per lane.)
                     const uint32_t pc = (uint32_t)__builtin_popcount(rowmap[g]);
                     const bool b5 = __ballot(pc >= 5u) != 0ull;
-                    if (!b5) {
-                        uint32_t rm = rowmap[g];
-                        while (__ballot(rm != 0u) != 0ull) {        // wave-uniform; a lane's rows in ascending order
-                            const bool has = rm != 0u;
-                            const int r = __builtin_clz(rm | 1u) - 16;
-                            // the lane's row r out of its sixteen accumulators: a binary tree of selects on the bits of r (four
-                            // lane masks + fifteen v_cndmask; sixteen compares + sixteen selects before)
-                            const unsigned long long b0 = __ballot((r & 1) != 0), b1 = __ballot((r & 2) != 0), b2 = __ballot((r & 4) != 0),
-                                                     b3 = __ballot((r & 8) != 0);
-                            float t8[8], t4[4], t2[2];
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) t8[q] = __int_as_float(lane_select(b0, __float_as_int(accP[g][2 * q + 1]), __float_as_int(accP[g][2 * q])));
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) t4[q] = __int_as_float(lane_select(b1, __float_as_int(t8[2 * q + 1]), __float_as_int(t8[2 * q])));
-#pragma unroll
-                            for (int q = 0; q < 2; ++q) t2[q] = __int_as_float(lane_select(b2, __float_as_int(t4[2 * q + 1]), __float_as_int(t4[2 * q])));
-                            float xv = __int_as_float(lane_select(b3, __float_as_int(t2[1]), __float_as_int(t2[0])));
-                            xv = has ? xv + alpha_prev[g] : -INFINITY;    // a lane without a candidate inserts nothing
-                            const float ol = rs[g][KR - 1];
-                            const int32_t oi = ri[g][KR - 1];
-                            sorted_insert_inplace<KR>(rs[g], ri[g], xv, sbase + (r & 3) + 8 * (r >> 2));
-                            if (!EXT) tie_mask[g] = tie_update(tie_mask[g], xv, ol, rs[g][KR - 1]);
-                            if (EXT) left_out_note(lout[g], xv, sbase + (r & 3) + 8 * (r >> 2), ol, oi, rs[g][KR - 1] - dlt2[g]);
-                            rm &= ~(0x8000u >> r);
-                        }
-                    } else {
+                    // (No loop and no else-arm below: plain ifs.  As a `while` beside an else-arm the compiler moved the lists
+                    //  into other registers on the way in and back on the way out, 50 v_mov per multi-candidate tile.)
+                    uint32_t rm = rowmap[g];
+                    if (b5) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             if (m[g][r] != 0ull) {
@@ -3102,6 +3080,38 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                                 if (!EXT) tie_mask[g] = tie_update(tie_mask[g], xv, ol, rs[g][KR - 1]);
                                 if (EXT) left_out_note(lout[g], fmaxf(xv, -INFINITY), sbase + (r & 3) + 8 * (r >> 2), ol, oi, rs[g][KR - 1] - dlt2[g]);
                             }
+                        }
+                        rm = 0u;
+                    }
+                    auto pass = [&]() __attribute__((always_inline)) {     // a lane's rows in ascending order, one per pass
+                        const bool has = rm != 0u;
+                        const int r = __builtin_clz(rm | 1u) - 16;
+                        // the lane's row r out of its sixteen accumulators: a binary tree of selects on the bits of r (four
+                        // lane masks + fifteen v_cndmask; sixteen compares + sixteen selects before)
+                        const unsigned long long b0 = __ballot((r & 1) != 0), b1 = __ballot((r & 2) != 0), b2 = __ballot((r & 4) != 0),
+                                                 b3 = __ballot((r & 8) != 0);
+                        float t8[8], t4[4], t2[2];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) t8[q] = __int_as_float(lane_select(b0, __float_as_int(accP[g][2 * q + 1]), __float_as_int(accP[g][2 * q])));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) t4[q] = __int_as_float(lane_select(b1, __float_as_int(t8[2 * q + 1]), __float_as_int(t8[2 * q])));
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) t2[q] = __int_as_float(lane_select(b2, __float_as_int(t4[2 * q + 1]), __float_as_int(t4[2 * q])));
+                        float xv = __int_as_float(lane_select(b3, __float_as_int(t2[1]), __float_as_int(t2[0])));
+                        xv = has ? xv + alpha_prev[g] : -INFINITY;    // a lane without a candidate inserts nothing
+                        const float ol = rs[g][KR - 1];
+                        const int32_t oi = ri[g][KR - 1];
+                        sorted_insert_inplace<KR>(rs[g], ri[g], xv, sbase + (r & 3) + 8 * (r >> 2));
+                        if (!EXT) tie_mask[g] = tie_update(tie_mask[g], xv, ol, rs[g][KR - 1]);
+                        if (EXT) left_out_note(lout[g], xv, sbase + (r & 3) + 8 * (r >> 2), ol, oi, rs[g][KR - 1] - dlt2[g]);
+                        rm &= ~(0x8000u >> r);
+                    };
+                    if (__ballot(rm != 0u) != 0ull) {               // (not b5: some lane holds two to four)
+                        pass();
+                        pass();
+                        if (__ballot(rm != 0u) != 0ull) {
+                            pass();
+                            if (__ballot(rm != 0u) != 0ull) pass();
                         }
                     }
                     share_threshold(g);
