@@ -2272,7 +2272,7 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
                 if (__any(cand)) {
                     const float old_last = rs[KR - 1];
                     const int32_t old_id = ri[KR - 1];
-                    sorted_insert<KR>(rs, ri, v, sbase + (r & 3) + 8 * (r >> 2));
+                    sorted_insert_inplace<KR>(rs, ri, v, sbase + (r & 3) + 8 * (r >> 2));     // (the out-of-place form under this `if`: 18 v_mov per insertion to copy the new list over the old)
                     tie_mask = tie_update(tie_mask, v, old_last, rs[KR - 1]);
                     if (EXT) left_out_note(lout, fmaxf(v, -INFINITY), sbase + (r & 3) + 8 * (r >> 2), old_last, old_id, rs[KR - 1] - dlt2);
                     thr = fmaxf(rs[KR - 1], seed);
