@@ -3330,10 +3330,10 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
     // the barriers did -- 1 M dishes: 65 536 users 3.19 -> 3.24 ms, 262 144 users 10.7 -> 11.4 ms -- so: catalogues up to 8 192
     // tiles (64 MiB of image).  "topk_block" = 128 / 256 forces either.
     const bool half_ok = BF16X3 && !HV && E == 64 && pipe;
-    // (k > 10 with the left-out bookkeeping: that four-wave instantiation needs 261 registers, one wave per SIMD -- eight waves then)
-    const bool keep_regs_ok = !(KR == 16 && h->opt_topk_refine != 0);
+    // (k > 10 with the left-out bookkeeping: 232 registers since the launch bounds say two waves per SIMD -- it took 261 and one
+    //  wave per SIMD before, and the launcher kept eight-wave blocks for it: 65 536 users x 100 k dishes, k = 16: 0.764 -> 0.666 ms)
     const bool half = half_ok && (h->opt_topk_block == 128 || (h->opt_topk_block == 0 && M2D_TOPK_HALF_BLOCKS && h->opt_topk_prune != 0 &&
-                                                              h->opt_variant < 100 && nU >= 16384 && h->grp_tiles <= 8192 && keep_regs_ok));
+                                                              h->opt_variant < 100 && nU >= 16384 && h->grp_tiles <= 8192));
     const int WV = half ? 4 : WAVES;                         // waves per block
     const int TPS = grouped_tiles_per_stage(E) * WV / WAVES;
     const size_t lds = (size_t)2 * TPS * 32 * E * sizeof(float);
@@ -3362,6 +3362,12 @@ int launch_grouped(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, f
             // long catalogues: since a user's ranges share their thresholds, twice the ranges cost little and balance better
             // (65 536 users x 1 M dishes: 8 ranges 3.41 ms, 16 ranges 3.19 ms, 24: 3.32; 262 144 users: 8 ranges 10.7, 16: 11.2)
             if (BF16X3 && E == 64 && a.tiles >= 16384 && ublocks >= 192 && ublocks < 768) nsplit = 16;
+            // blocks of 128 users, many of them: about 4 096 items is what balances (8 rounds of the 512 block slots); more only
+            // adds item prologues, partial stages and merge work -- 131 072 users x 100 k dishes: 4 ranges 0.87 ms (3: 0.95, 6:
+            // 0.90, 8: 0.95); 262 144 users: 2 ranges 1.59 (1: 2.11, 3: 1.65, 4: 1.66, 8: 1.85); 524 288 users: 1 range 2.86
+            // (2: 2.99, 4: 3.24, 8: 3.67).  (Blocks of 256 users over 1 M dishes: 8 stays -- 262 144 users 10.2 ms against 10.6
+            // with 3 ... 6; 524 288 users 19.3 ... 20.2 for 2 ... 8, within the noise.)
+            if (half && ublocks >= 768) nsplit = ublocks >= 3072 ? 1 : (ublocks >= 1536 ? 2 : 4);
             const int64_t most = a.tiles / (4 * TPS);        // at least four stages per range
             if (most < nsplit) nsplit = most > 1 ? (int)most : 1;
         } else {

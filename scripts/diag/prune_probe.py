@@ -6,6 +6,7 @@ import torch, foodrec_amd
 I = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
+K = int(os.environ.get("PROBE_K", "10"))
 U, C = max(1_000_000, n), 4
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 s = E ** -0.5
@@ -31,11 +32,11 @@ VARS = [int(v) for v in os.environ.get("PROBE_VARIANTS", "101 116").split()]
 for prune, var in [(0, 0), (6, 0), (1, 0)] + [(pr, v) for v in VARS for pr in PRUNES]:      # 6: Cauchy-Schwarz bounds only; 1: + probe rows      # 5: pruned, grid launch order; 1: longest item first
     eng.set_option("topk_prune", prune); eng.set_option("variant", var)
     for _ in range(5):
-        s1, i1 = eng.topk_users(users, 10)
+        s1, i1 = eng.topk_users(users, K)
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(11)]
     for i in range(10):
-        ev[i].record(); s1, i1 = eng.topk_users(users, 10)
+        ev[i].record(); s1, i1 = eng.topk_users(users, K)
     ev[10].record(); torch.cuda.synchronize(); eng.check()
     ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(10))[5]
     res[prune] = (s1, i1)

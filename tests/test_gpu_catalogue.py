@@ -506,13 +506,33 @@ def test_blocks_of_128_users_return_the_same_lists(k):
         eng.set_option("topk_prune", prune); eng.set_option("topk_block", block); eng.set_option("variant", forced)
         s, i = eng.topk_users(users, k); eng.check()
         out[prune, block, forced] = (s.cpu().numpy(), i.cpu().numpy(), eng.get_option("topk_block_users"))
-    # (k > 10 with the refinement's bookkeeping: the four-wave instantiation would need 261 registers, so the launcher keeps 256)
-    assert out[1, 0, 0][2] == (128 if k <= 10 else 256) and out[1, 256, 0][2] == 256 and out[1, 128, 105][2] == 128 and out[0, 0, 101][2] == 256
+    assert out[1, 0, 0][2] == 128 and out[1, 256, 0][2] == 256 and out[1, 128, 105][2] == 128 and out[0, 0, 101][2] == 256
     s0, i0, _ = out[0, 0, 101]
     for key, (s, i, _) in out.items():
         assert np.array_equal(i, i0) and np.array_equal(s.view(np.int32), s0.view(np.int32)), key
     eng.set_option("topk_prune", 1); eng.set_option("topk_block", 0); eng.set_option("variant", 0)
     _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:50], k, dup=60)
+
+
+@pytest.mark.parametrize("nblocks", [800, 1600, 3100])
+def test_many_user_blocks_take_fewer_dish_ranges(nblocks):
+    """A pruned launch of blocks of 128 users is cut into 8 dish ranges up to 767 blocks, then 4 / 2 / 1 (about 4 096 items
+    balance the launch; more only add prologues and merge work): the same lists as the plain scan, bit for bit, at each count --
+    one range means no merge pass and no shared thresholds."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    U, I, E, k = 128 * nblocks + 40, 9000, 64, 10
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=nblocks, n_nan=3, dup=40)
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    users = torch.as_tensor(np.random.default_rng(nblocks).permutation(U).astype(np.int32), device="cuda")
+    eng.set_option("topk_prune", 0)
+    s0, i0 = eng.topk_users(users, k); eng.check()
+    eng.set_option("topk_prune", 1)
+    s1, i1 = eng.topk_users(users, k); eng.check()
+    assert eng.get_option("topk_block_users") == 128
+    assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+    _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:30], k, dup=40)
 
 
 @pytest.mark.parametrize("E,k,I", [(64, 10, 9000), (128, 10, 7000), (64, 16, 9000), (64, 1, 3000), (128, 5, 20000)])
