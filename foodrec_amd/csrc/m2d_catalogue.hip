@@ -1737,9 +1737,9 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
     float hc[4] = {0.f, 0.f, 0.f, 0.f}, ha[4] = {0.f, 0.f, 0.f, 0.f}, G[10];     // ha: the same sums over |terms| (the bounds' rounding margin)
 #pragma unroll
     for (int i = 0; i < 10; ++i) G[i] = 0.f;
+    v4f r[4] = {v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}, v4f{0.f, 0.f, 0.f, 0.f}};     // (CH = 1: kept for the probes' operand)
     for (int q = j; q < E4; q += 16) {
         const v4f uh = pmu[q];
-        v4f r[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const v4f w = ce4[c * E4 + q];
@@ -1753,16 +1753,15 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
 #pragma unroll
             for (int d = c; d < 4; ++d, ++i) G[i] += fmaf(r[c].x, r[d].x, r[c].y * r[d].y) + fmaf(r[c].z, r[d].z, r[c].w * r[d].w);
     }
+    // sums over the user's 16 lanes: row rotations by 8, 4, 2, 1 (DPP: one VALU each) -- the same bits in every lane as the xor
+    // butterfly gave (each step adds the same two partial sums, and a + b = b + a), without its 72 ds_bpermute
 #pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            hc[c] += __shfl_xor(hc[c], off, 64);
-            ha[c] += __shfl_xor(ha[c], off, 64);
-        }
-#pragma unroll
-        for (int i = 0; i < 10; ++i) G[i] += __shfl_xor(G[i], off, 64);
+    for (int c = 0; c < 4; ++c) {
+        hc[c] = row16_sum(hc[c]);
+        ha[c] = row16_sum(ha[c]);
     }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) G[i] = row16_sum(G[i]);
     float seed, lo, hi;
     const PatternBound pb = grouped_pattern_bounds_lanes(hc, ha, G, grp, k, a, b, E, j, seed, lo, hi);
     // A better bound from a few dishes: the pattern whose lower bound IS the bound (the user's best) holds its largest-norm
@@ -1783,7 +1782,13 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
         for (int i = 0; i < CH; ++i) {
             wv[i] = v4f{0.f, 0.f, 0.f, 0.f};
             const int q = j + 16 * i;
-            if (q < E4) {
+            if (CH == 1) {
+                // the lane's float4 of the four rows is still in registers (the sums above read it): as conditional loads
+                // they were four exec-masked blocks, each waiting for its own round trip
+#pragma unroll
+                for (int c = 0; c < 4; ++c) wv[0] += ((p1 >> c) & 1) ? r[c] : v4f{0.f, 0.f, 0.f, 0.f};
+                wv[0] *= beta;
+            } else if (q < E4) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
                     if ((p1 >> c) & 1) wv[i] += pmu[(c + 1) * E4 + q];
@@ -1836,8 +1841,11 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
     float delta = (j >= 1 && grp[40 + j] > 0)
                       ? (1.2e-5f + (float)(E + E / 16 + 20) * 5.9604645e-8f) * pb.reach + (4.f + (chain ? 0.5f * (float)E + 4.f : 0.f)) * 5.9604645e-8f * smag
                       : 0.f;
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) delta = fmaxf(delta, __shfl_xor(delta, off, 64));
+    // max over the user's 16 lanes (row rotations, as above)
+    delta = fmaxf(delta, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, delta), 0x128, 0xf, 0xf, false)));
+    delta = fmaxf(delta, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, delta), 0x124, 0xf, 0xf, false)));
+    delta = fmaxf(delta, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, delta), 0x122, 0xf, 0xf, false)));
+    delta = fmaxf(delta, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, delta), 0x121, 0xf, 0xf, false)));
     // a pattern is left out only if its dishes stay 2 delta under the bound: a score that close to the k-th must reach an
     // insertion in every launch shape (the refinement's candidates may not depend on the option form)
     uint32_t mask = grouped_mask_lanes(hi, seed - 2.f * delta, j);
