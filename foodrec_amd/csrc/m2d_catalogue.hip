@@ -596,15 +596,41 @@ __global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, co
         float bs = hs;
         int32_t bi = hi;
         int bw = w;
+        // The group's best head: the other candidate wins if this one is exhausted, or it ranks strictly ahead (`ahead`: NaN
+        // after every number), or ties from a lower split.  That is a total order, so it is one unsigned 64-bit key -- high
+        // word: the score's ordered image (+-0 alike, NaN = 1, an exhausted list = 0), low word: LPU - 1 - split -- and the
+        // reduction is a max of keys with the head (score, id) as payload.  Partners inside a row of 16 lanes come by DPP (one
+        // VALU each; 8 and 4 by mirror images, which reach the same maximum): the xor butterfly of three ds_bpermute and
+        // twenty VALU per step was what this kernel spent its time on (all 64 lanes work for 64 / LPU users).
+        uint32_t kh;
+        {
+            const float z = hs + 0.f;                        // -0 -> +0
+            const int32_t b = __float_as_int(z);
+            const uint32_t ord = (uint32_t)(b ^ ((b >> 31) & 0x7fffffff)) ^ 0x80000000u;      // order-preserving, > 1 for every number (-inf: 0x007fffff)
+            kh = hi < 0 ? 0u : (z != z ? 1u : ord);
+        }
+        uint32_t kl = (uint32_t)(LPU - 1 - w);
 #pragma unroll
         for (int off = LPU / 2; off >= 1; off >>= 1) {
-            const float os = __shfl_xor(bs, off, 64);
-            const int32_t oi = __shfl_xor(bi, off, 64);
-            const int ow = __shfl_xor(bw, off, 64);
-            // the other candidate wins if this one is exhausted, or it ranks strictly ahead, or ties from a lower split
-            const bool take = oi >= 0 && (bi < 0 || ahead(os, bs) || (!ahead(bs, os) && ow < bw));
-            if (take) { bs = os; bi = oi; bw = ow; }
+            float os;
+            int32_t oi;
+            uint32_t oh, ol;
+            if (off >= 16) {
+                os = __shfl_xor(bs, off, 64); oi = __shfl_xor(bi, off, 64);
+                oh = (uint32_t)__shfl_xor((int)kh, off, 64); ol = (uint32_t)__shfl_xor((int)kl, off, 64);
+            } else {
+                constexpr int Q1 = 0xB1, Q2 = 0x4E, HM = 0x141, RM = 0x140;      // quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+#define M2D_DPP_PARTNER(x) (off == 1 ? __builtin_amdgcn_update_dpp(0, (x), Q1, 0xf, 0xf, false) : off == 2 ? __builtin_amdgcn_update_dpp(0, (x), Q2, 0xf, 0xf, false) : off == 4 ? __builtin_amdgcn_update_dpp(0, (x), HM, 0xf, 0xf, false) : __builtin_amdgcn_update_dpp(0, (x), RM, 0xf, 0xf, false))
+                os = __int_as_float(M2D_DPP_PARTNER(__float_as_int(bs)));
+                oi = M2D_DPP_PARTNER(bi);
+                oh = (uint32_t)M2D_DPP_PARTNER((int)kh);
+                ol = (uint32_t)M2D_DPP_PARTNER((int)kl);
+#undef M2D_DPP_PARTNER
+            }
+            const bool take = (((unsigned long long)oh << 32) | ol) > (((unsigned long long)kh << 32) | kl);
+            if (take) { bs = os; bi = oi; kh = oh; kl = ol; }
         }
+        bw = LPU - 1 - (int)kl;
         if (u < nU && w == 0) {
             out_scores[u * k + o] = bi >= 0 ? bs : __builtin_nanf("");
             out_ids[u * k + o] = bi;
