@@ -2633,9 +2633,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
         const int64_t pos = (((int64_t)bx * WAVES + wave) * G + g) * 32 + j;
         uvalid[g] = pos < p.nU;
         uidx[g] = uvalid[g] ? (p.order ? p.order[pos] : (int32_t)pos) : 0;
+        // everything that hangs on the user's index is fetched in ONE round trip: the id, the plan record, the shared word
+        // (read one after the other -- id, its range check, record, word -- they were four in a row at the head of every item)
+        const float *rec = p.plan + (size_t)uidx[g] * 8;
+        const int32_t uid = uvalid[g] ? p.users[uidx[g]] : 0;
+        const float rec0 = rec[0], rec1 = rec[1], rec2 = rec[2], rec3 = rec[3], rec4 = rec[4], rec5 = rec[5], rec7 = rec[7];
+        int32_t shared_key = thr_key(-INFINITY);
+        if (SHARE && p.shared_thr && uvalid[g])             // what the user's other dish ranges have reached so far (see exchange_thresholds)
+            shared_key = __hip_atomic_load(p.shared_thr + (size_t)uidx[g] * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int64_t ul = 0;
         if (uvalid[g]) {
-            const int32_t uid = p.users[uidx[g]];
             ul = (int64_t)uid - p.user_base;
             if (ul < 0 || ul >= p.U) {
                 if (atomicCAS(&p.err[0], 0, M2D_ERR_BAD_USER_ID) == 0) {
@@ -2647,15 +2654,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
             }
         }
         pmu[g] = reinterpret_cast<const v4f *>(p.pm) + (size_t)ul * ((C + 1) * S4);
-        const float *rec = p.plan + (size_t)uidx[g] * 8;
-#pragma unroll
-        for (int c = 0; c < C; ++c) hc[g][c] = rec[1 + c];
-        seed[g] = uvalid[g] ? rec[0] : INFINITY;            // a lane without a user never has a candidate
-        dlt2[g] = (EXT && p.ex_out && uvalid[g]) ? 2.f * rec[7] : 0.f;
+        hc[g][0] = rec1; hc[g][1] = rec2; hc[g][2] = rec3; hc[g][3] = rec4;
+        seed[g] = uvalid[g] ? rec0 : INFINITY;              // a lane without a user never has a candidate
+        dlt2[g] = (EXT && p.ex_out && uvalid[g]) ? 2.f * rec7 : 0.f;
         lout[g] = M2D_LEFTOUT_NONE;
-        if (SHARE && p.shared_thr && uvalid[g])             // what the user's other dish ranges have reached so far (see exchange_thresholds)
-            seed[g] = fmaxf(seed[g], thr_unkey(__hip_atomic_load(p.shared_thr + (size_t)uidx[g] * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-        umask_lane |= uvalid[g] ? __float_as_uint(rec[5]) : 0u;
+        if (SHARE && p.shared_thr && uvalid[g]) seed[g] = fmaxf(seed[g], thr_unkey(shared_key));
+        umask_lane |= uvalid[g] ? __float_as_uint(rec5) : 0u;
     }
     // the block's patterns: the union over its users.  Tiles of every other pattern are not even fetched.
     __shared__ uint32_t s_umask;
@@ -2988,9 +2992,40 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
 #pragma unroll
                     for (int c = 0; c < C; ++c) hs += ((pat >> c) & 1) ? hc[g][c] : 0.f;
                     alpha[g] = HV ? 0.f : p.a * (hs * inv_n);
+                    // E = 64: the pattern's rows category by category -- a category's eight float4 in flight together, one wait,
+                    // then the adds (the same sums in the same order).  Written k-step by k-step with the category test inside,
+                    // the loads came out as sixteen exec-masked pairs, each waited for before the next was issued: sixteen
+                    // round trips in a row at every pattern switch, with the block's matrix pipe idle
+                    constexpr bool BYCAT = !HV && KS == 4;
+                    v4f wacc[BYCAT ? KS : 1][2];
+                    if constexpr (BYCAT) {
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) wacc[ks][0] = wacc[ks][1] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            if ((pat >> c) & 1) {
+                                v4f ld[KS][2];
+#pragma unroll
+                                for (int ks = 0; ks < KS; ++ks) {
+                                    const v4f *row = pmu[g] + (c + 1) * S4 + 4 * ks + 2 * h;
+                                    ld[ks][0] = row[0];
+                                    ld[ks][1] = row[1];
+                                }
+#pragma unroll
+                                for (int ks = 0; ks < KS; ++ks) {
+                                    wacc[ks][0] += ld[ks][0];
+                                    wacc[ks][1] += ld[ks][1];
+                                }
+                            }
+                        }
+                    }
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {                   // unrolled: every register index is static
                         v4f w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+                        if constexpr (BYCAT) {
+                            w0 = wacc[ks][0] * beta;
+                            w1 = wacc[ks][1] * beta;
+                        } else
                         if (HV && ks < KS / 2) {                        // k < EU: a U_high against H[d]
                             const v4f *row = pmu[g] + 4 * ks + 2 * h;
                             w0 = row[0] * p.a;
