@@ -45,14 +45,14 @@ class _ModelSess:
     Model.inference (oracle/m2d_oracle.py) on tables whose values are small dyadic rationals, so every
     product and partial sum is exact in float32 and the scores do not depend on summation order."""
 
-    def __init__(self, PM, RE, CE):
-        self.PM, self.RE, self.CE = PM, RE, CE
+    def __init__(self, PM, RE, CE, coef=0.99):
+        self.PM, self.RE, self.CE, self.coef = PM, RE, CE, coef
 
     def run(self, fetches, feed_dict):
         assert fetches == [_Model.logits]
         from oracle import m2d_oracle
         return [m2d_oracle.inference_f32(self.PM, self.RE, self.CE, feed_dict[_Model.user_input],
-                                         feed_dict[_Model.item_input], feed_dict[_Model.categories])]
+                                         feed_dict[_Model.item_input], feed_dict[_Model.categories], self.coef)]
 
 
 class _Sess:
@@ -125,8 +125,11 @@ def main():
     # ---- evaluator driven by model scores (device-path parity: tests/test_gpu_evaluator.py) ------
     sys.path.insert(0, os.path.join(OUT, "..", ".."))
     mcases = []
-    for seed, nu, ni, E, K, n_nan in [(11, 9, 40, 8, 10, 0), (12, 6, 25, 32, 10, 1), (13, 12, 400, 64, 5, 3),
-                                     (14, 8, 60, 200, 10, 0)]:
+    # the last four (round 5): other values of --high_level_score_coefficient (Train_recommender.py:61-62) than its default
+    # 0.99 -- with 1.0 every dish of a mask pattern scores the same, so nlargest's tie order decides most of the lists
+    for seed, nu, ni, E, K, n_nan, coef in [(11, 9, 40, 8, 10, 0, 0.99), (12, 6, 25, 32, 10, 1, 0.99), (13, 12, 400, 64, 5, 3, 0.99),
+                                           (14, 8, 60, 200, 10, 0, 0.99), (15, 10, 50, 64, 10, 1, 0.5), (16, 8, 40, 32, 10, 0, 1.0),
+                                           (17, 7, 60, 64, 5, 2, 0.0), (18, 9, 45, 128, 10, 0, 1.25)]:
         rng = np.random.default_rng(seed)
         q = lambda shape: (rng.integers(-4, 5, shape) / 4.0).astype(np.float32)     # dyadic values
         PM, RE, CE = q((nu, 5, E)), q((ni, E)), q((4, E))
@@ -142,8 +145,8 @@ def main():
             ratings[str(u)] = [int(rng.integers(0, ni))]
             nneg = 100 if u % 4 else 60 + int(rng.integers(0, 30))
             negatives[str(u)] = [int(x) for x in rng.integers(0, ni, nneg)]
-        hits, ndcgs = ev.evaluate_model(_ModelSess(PM, RE, CE), _Model, ratings, negatives, K, cats)
-        mcases.append({"seed": seed, "K": K, "E": E, "PM": PM.tolist(), "RE": RE.tolist(), "CE": CE.tolist(),
+        hits, ndcgs = ev.evaluate_model(_ModelSess(PM, RE, CE, coef), _Model, ratings, negatives, K, cats)
+        mcases.append({"seed": seed, "K": K, "E": E, "coef": coef, "PM": PM.tolist(), "RE": RE.tolist(), "CE": CE.tolist(),
                        "testRatings": ratings, "testNegatives": negatives, "dish_to_category": cats,
                        "hits": [int(h) for h in hits], "ndcgs": [float(x) for x in ndcgs]})
     with open(os.path.join(OUT, "ref_eval_model_cases.json"), "w") as f:

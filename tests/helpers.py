@@ -11,6 +11,11 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # |score| grows with E and table magnitude ("Reduction order").
 TOL = 1e-4
 
+# high_level_score_coefficient values the parity tests run beside the reference's default 0.99 (Train_recommender.py:61-62;
+# `1 - coef` is taken in float32, Model_Recommender.py:17, :96): low level only, an even blend, a heavier low level than the
+# default, high level only (every dish of a mask pattern then scores the same), and a NEGATIVE low-level weight.
+COEFS = [0.0, 0.5, 0.9, 1.0, 1.25]
+
 
 def assert_scores_close(got, ref, tol=TOL, what=""):
     got = np.asarray(got, dtype=np.float64)

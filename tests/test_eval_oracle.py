@@ -31,10 +31,10 @@ def test_oracle_evaluator_matches_reference(case):
         assert [int(x) for x in got] == want
 
 
-@pytest.mark.parametrize("case", MODEL, ids=lambda c: "E%d-K%d" % (c["E"], c["K"]))
+@pytest.mark.parametrize("case", MODEL, ids=lambda c: "E%d-K%d-coef%s" % (c["E"], c["K"], c.get("coef", 0.99)))
 def test_oracle_model_evaluator_matches_reference(case):
     PM, RE, CE = (np.asarray(case[k], dtype=np.float32) for k in ("PM", "RE", "CE"))
-    fn = lambda u, i, c: oracle.inference_f32(PM, RE, CE, u, i, c)
+    fn = lambda u, i, c: oracle.inference_f32(PM, RE, CE, u, i, c, case.get("coef", 0.99))
     hits, ndcgs = oracle.evaluate_model(fn, case["testRatings"], case["testNegatives"], case["K"],
                                         case["dish_to_category"])
     assert hits == case["hits"] and ndcgs == case["ndcgs"]

@@ -4,7 +4,7 @@ order with NaN last, optimality of the returned set, and lower-id-first on exact
 import numpy as np
 import pytest
 
-from helpers import TOL, assert_scores_close
+from helpers import COEFS, TOL, assert_scores_close
 
 pytestmark = pytest.mark.gpu
 
@@ -25,7 +25,7 @@ def _tables(U, I, C, E, seed, n_nan=0, dup=0):
     return PM, RE, CE, cats
 
 
-def _explain_mismatches(PM, RE, CE, cats, users, sa, ia, sb, ib, bound=3e-5):
+def _explain_mismatches(PM, RE, CE, cats, users, sa, ia, sb, ib, bound=3e-5, coef=0.99):
     """Two kernels' lists for the same users: wherever they hold different dishes at a position, the two dishes' exact
     (float64) scores are closer than the kernels' rounding -- `bound` x max(1, |s|): 3e-5 is the split-bf16 product's
     measured error -- so either order is a correct ranking at that precision.  Returns the number of such positions."""
@@ -33,7 +33,7 @@ def _explain_mismatches(PM, RE, CE, cats, users, sa, ia, sb, ib, bound=3e-5):
     I = RE.shape[0]
     n = 0
     for r in np.flatnonzero(np.any(ia != ib, axis=1)):
-        ref = oracle.inference_f64(PM, RE, CE, np.full(I, users[r]), np.arange(I), cats)
+        ref = oracle.inference_f64(PM, RE, CE, np.full(I, users[r]), np.arange(I), cats, coef)
         for p in np.flatnonzero(ia[r] != ib[r]):
             ea, eb = ref[ia[r, p]], ref[ib[r, p]]
             assert abs(ea - eb) <= bound * max(1.0, abs(ea)), (int(users[r]), int(p), int(ia[r, p]), int(ib[r, p]), ea, eb)
@@ -41,16 +41,17 @@ def _explain_mismatches(PM, RE, CE, cats, users, sa, ia, sb, ib, bound=3e-5):
     return n
 
 
-def _check(eng, PM, RE, CE, cats, users, k, user_base=0, dup=0):
+def _check(eng, PM, RE, CE, cats, users, k, user_base=0, dup=0, coef=None):
     import torch
     from oracle import m2d_oracle as oracle
+    coef = eng.coef if coef is None else coef            # the engine's high_level_score_coefficient (Model_Recommender.py:17)
     s, ids = eng.topk_users(torch.as_tensor(users + user_base, dtype=torch.int32, device="cuda"), k)
     eng.check()
     s, ids = s.cpu().numpy(), ids.cpu().numpy()
     I = RE.shape[0]
     all_items = np.arange(I)
     for r, u in enumerate(users):
-        ref = oracle.inference_f64(PM, RE, CE, np.full(I, u), all_items, cats)
+        ref = oracle.inference_f64(PM, RE, CE, np.full(I, u), all_items, cats, coef)
         got_ids = ids[r]
         n_valid = min(k, I)
         assert np.all(got_ids[:n_valid] >= 0) and np.all(got_ids[:n_valid] < I), (r, got_ids)
@@ -76,13 +77,35 @@ def _check(eng, PM, RE, CE, cats, users, k, user_base=0, dup=0):
                     assert int(d) - (I - dup) in held, (u, int(d))
 
 
+def _assert_ids_are_the_oracles_where_clear(ids, PM, RE, CE, cats, users, k, coef, gap=1e-6, what=""):
+    """Index parity with `heapq.nlargest` over the float64 restatement (oracle.topk_catalogue: score desc, ties to the lower
+    dish id, evaluate.py:63): the id at every position whose float64 score is either bit-equal to a neighbour's (a structural
+    tie: id order decides) or more than `gap` away from both neighbours' -- the (k + 1)-th best included -- is the oracle's.
+    Returns the fraction of positions checked."""
+    from oracle import m2d_oracle as oracle
+    ref_s, ref_i = oracle.topk_catalogue(PM, RE, CE, cats, users, k + 1, coef)
+    checked = 0
+    for r in range(len(users)):
+        rs = np.where(np.isnan(ref_s[r]), -np.inf, ref_s[r])
+        with np.errstate(invalid="ignore"):
+            before = np.concatenate([[np.inf], rs[:k - 1] - rs[1:k]])
+            after = rs[:k] - rs[1:k + 1]
+        before = np.where(np.isnan(before), 0.0, before)   # -inf - -inf: NaN dishes, in id order
+        after = np.where(np.isnan(after), 0.0, after)
+        ok = ((before > gap) | (before == 0)) & ((after > gap) | (after == 0))
+        assert np.array_equal(ids[r][ok], ref_i[r, :k][ok]), (what, int(users[r]), ids[r], ref_i[r, :k], ref_s[r])
+        checked += int(ok.sum())
+    return checked / float(len(users) * k)
+
+
 @pytest.mark.parametrize("E,C", [(32, 4), (64, 4), (128, 4), (200, 4), (16, 3), (20, 4), (100, 4), (48, 4), (256, 4), (260, 4), (22, 4)])
 @pytest.mark.parametrize("k", [1, 10, 16, 17, 64])
 def test_topk_users_shapes(E, C, k):
     from foodrec_amd import ScoringEngine
     U, I = 150, 333
     PM, RE, CE, cats = _tables(U, I, C, E, seed=E + k, n_nan=3, dup=20)
-    eng = ScoringEngine(PM, RE, CE)
+    coef = ([0.99] + COEFS)[(E // 4 + k) % 6]            # every kernel family meets every blend coefficient over the grid
+    eng = ScoringEngine(PM, RE, CE, coef=coef)
     eng.set_dish_categories(cats)
     users = np.random.default_rng(1).integers(0, U, 45)
     _check(eng, PM, RE, CE, cats, users, k, dup=20)
@@ -374,8 +397,9 @@ def test_both_forms_of_the_split_bf16_kernel_agree(E, k):
     _check(eng, PM, RE, CE, cats, np.arange(0, U, 7), k)                # the first form on its own against the oracle
 
 
-@pytest.mark.parametrize("E,low_scale", [(64, 1.0), (128, 1.0), (64, 6.0), (128, 0.05)])
-def test_pattern_pruning_changes_nothing_but_the_work(E, low_scale):
+@pytest.mark.parametrize("E,low_scale,coef", [(64, 1.0, 0.99), (128, 1.0, 0.99), (64, 6.0, 0.99), (128, 0.05, 0.99)] +
+                         [(64, 1.0, c) for c in COEFS] + [(128, 1.0, 0.5), (128, 1.0, 1.0), (128, 6.0, 1.25), (64, 0.05, 0.0)])
+def test_pattern_pruning_changes_nothing_but_the_work(E, low_scale, coef):
     """The pipelined kernel takes its users sorted by the mask of patterns that can reach their top-k, and a block steps
     through those patterns' tiles only (bounds from Cauchy-Schwarz: include/m2d.h, option "topk_prune").  Same lists, bit
     for bit, as the scan of everything ("topk_prune" = 0) -- whatever the low-level rows' scale makes of the bounds -- and,
@@ -386,7 +410,10 @@ def test_pattern_pruning_changes_nothing_but_the_work(E, low_scale):
     PM, RE, CE, cats = _tables(U, I, 4, E, seed=E + 41, n_nan=6, dup=50)
     PM[:, 1:] *= low_scale
     PM[7] = 0.0                                           # every pattern ties: nothing can be pruned for this user
-    eng = ScoringEngine(PM, RE, CE)
+    # the bounds scale with the coefficient (alpha_P with coef, the reach with |1 - coef|): 0 leaves no alpha_P to prune by, 0.5
+    # and 0.9 widen the reach against it, 1.0 makes every dish of a pattern score alpha_P (a tie per group, for every user),
+    # 1.25 turns the low-level operand's sign
+    eng = ScoringEngine(PM, RE, CE, coef=coef)
     eng.set_dish_categories(cats)
     users = torch.as_tensor(np.random.default_rng(5).permutation(U).astype(np.int32), device="cuda")
     out = {}
@@ -400,12 +427,61 @@ def test_pattern_pruning_changes_nothing_but_the_work(E, low_scale):
     base = out[0, 101]
     for key, (s, i, scanned, full) in out.items():
         assert np.array_equal(i, base[1]) and np.array_equal(s, base[0], equal_nan=True), key
-    assert out[0, 101][2] >= out[0, 101][3]               # everything is stepped through without pruning
-    if low_scale <= 1.0:
+    if coef != 1.0:                                       # (coef = 1: no scan at all, see test_high_level_only_blend)
+        assert out[0, 101][2] >= out[0, 101][3]           # everything is stepped through without pruning
+    if low_scale <= 1.0 and 0.9 <= coef < 1.0:
         assert out[1, 101][2] < 0.5 * out[0, 101][2], (out[1, 101][2], out[0, 101][2])
     eng.set_option("variant", 0); eng.set_option("topk_prune", 1)
     _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:60], k, dup=50)
     _check(eng, PM, RE, CE, cats, np.array([7, 3, 7]), k)       # a single block of users: no sort, the union of three masks
+    frac = _assert_ids_are_the_oracles_where_clear(base[1][:80], PM, RE, CE, cats, users.cpu().numpy()[:80], k, coef, gap=3e-5,
+                                                   what="coef %s" % coef)
+    assert frac > 0.3, frac
+
+
+@pytest.mark.parametrize("E,x3", [(64, 1), (64, 0), (128, 1), (200, 0), (32, 0)])
+@pytest.mark.parametrize("nU", [37, 3000])
+def test_high_level_only_blend(E, x3, nU):
+    """--high_level_score_coefficient 1.0 (Train_recommender.py:61-62): `1 - coef` is an exact float32 zero
+    (Model_Recommender.py:96), every dish of a mask pattern scores alpha_P[u], and `heapq.nlargest` (evaluate.py:63) returns
+    the best pattern's LOWEST ids, then the next pattern's -- for every user.  Every kernel form returns exactly that list
+    (the pattern-grouped path takes it from the patterns' first ids, no scan; the dense kernel scans in id order), with the
+    NaN dishes of empty masks last when a user's patterns run out."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    from oracle import m2d_oracle as oracle
+    U, I, k = 3000, 2600, 10
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=E + 23, n_nan=9)
+    pat = (cats * (1 << np.arange(4))[None, :]).sum(1).astype(int)
+    cats[np.flatnonzero(pat == 5)[3:]] = [1, 0, 0, 0]          # pattern {0, 2} keeps three dishes: lists that span patterns
+    eng = ScoringEngine(PM, RE, CE, coef=1.0)
+    eng.set_dish_categories(cats)
+    eng.set_option("topk_bf16x3", x3)
+    users_np = np.random.default_rng(E).permutation(U)[:nU].astype(np.int32)
+    users = torch.as_tensor(users_np, device="cuda")
+    ref_s, ref_i = oracle.topk_catalogue(PM, RE, CE, cats, users_np[:200], k, 1.0)
+    outs = []
+    for grouped, prune, forced in ((1, 1, 0), (1, 0, 101), (1, 1, 105), (0, 1, 0)):
+        if grouped == 0 and E == 200:
+            continue                                          # (no dense MFMA kernel for K = 1000: the one-block-per-user kernel, covered elsewhere)
+        eng.set_option("topk_grouped", grouped); eng.set_option("topk_prune", prune); eng.set_option("variant", forced)
+        s, i = eng.topk_users(users, k); eng.check()
+        s, i = s.cpu().numpy(), i.cpu().numpy()
+        frac = _assert_ids_are_the_oracles_where_clear(i[:200], PM, RE, CE, cats, users_np[:200], k, 1.0, gap=3e-6, what=(grouped, prune, forced))
+        assert frac > 0.95, frac                              # ties everywhere; only two patterns' alpha within 3e-6 are left out
+        assert_scores_close(s[:200], ref_s)
+        outs.append((s, i))
+    for s, i in outs[1:3]:                                    # the pattern-grouped forms: the same bits
+        assert np.array_equal(i, outs[0][1]) and np.array_equal(s.view(np.int32), outs[0][0].view(np.int32))
+    eng.set_option("topk_grouped", 1); eng.set_option("topk_prune", 1); eng.set_option("variant", 0)
+    _check(eng, PM, RE, CE, cats, users_np[:40], k)
+    s16, i16 = eng.topk_users(users[:64], 16); eng.check()    # k = 16, and a catalogue with fewer rankable dishes than k
+    _assert_ids_are_the_oracles_where_clear(i16.cpu().numpy(), PM, RE, CE, cats, users_np[:64], 16, 1.0, gap=3e-6)
+    few = np.zeros_like(cats); few[[5, 17, 900], 1] = 1; few[[3, 40], 2] = 1
+    eng.set_dish_categories(few)
+    _check(eng, PM, RE, CE, few, users_np[:20], k)
+    s5, i5 = eng.topk_users(users[:20], k); eng.check()
+    _assert_ids_are_the_oracles_where_clear(i5.cpu().numpy(), PM, RE, CE, few, users_np[:20], k, 1.0, gap=3e-6)
 
 
 @pytest.mark.parametrize("E,x3", [(64, 1), (64, 0), (128, 1), (200, 0), (32, 0)])
@@ -535,8 +611,9 @@ def test_many_user_blocks_take_fewer_dish_ranges(nblocks):
     _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:30], k, dup=40)
 
 
-@pytest.mark.parametrize("E,k,I", [(64, 10, 9000), (128, 10, 7000), (64, 16, 9000), (64, 1, 3000), (128, 5, 20000)])
-def test_split_bf16_lists_are_the_exact_f32_kernels_lists(E, k, I):
+@pytest.mark.parametrize("E,k,I,coef", [(64, 10, 9000, 0.99), (128, 10, 7000, 0.99), (64, 16, 9000, 0.99), (64, 1, 3000, 0.99), (128, 5, 20000, 0.99)] +
+                         [(64, 10, 9000, c) for c in COEFS] + [(128, 10, 7000, 0.5), (128, 10, 7000, 1.25), (64, 16, 3000, 0.0)])
+def test_split_bf16_lists_are_the_exact_f32_kernels_lists(E, k, I, coef):
     """Dish ids are index output.  The split-bf16 kernel's products differ from the exact-f32 kernel's by up to ~1e-5 of
     |w||r|, which used to reorder dishes whose scores sit closer than that (about 0.2 % of the lists).  Both kernels now finish
     near-tied lists -- neighbouring scores, or the last entry and the best score left out, within 2 delta of each other -- in
@@ -546,7 +623,7 @@ def test_split_bf16_lists_are_the_exact_f32_kernels_lists(E, k, I):
     from foodrec_amd import ScoringEngine
     U = 24000
     PM, RE, CE, cats = _tables(U, I, 4, E, seed=E + k + 900, n_nan=5, dup=30)
-    eng = ScoringEngine(PM, RE, CE)
+    eng = ScoringEngine(PM, RE, CE, coef=coef)            # delta_u (the near-tie margin) scales with |1 - coef| reach and |alpha|
     eng.set_dish_categories(cats)
     users = torch.as_tensor(np.random.default_rng(k).permutation(U).astype(np.int32), device="cuda")
     res = {}
@@ -559,7 +636,8 @@ def test_split_bf16_lists_are_the_exact_f32_kernels_lists(E, k, I):
     i_ref = res[0, 0, 101][1]
     for key, (s, i, refined) in res.items():
         assert np.array_equal(i, i_ref), (key, int((i != i_ref).any(1).sum()), refined)
-    assert res[1, 1, 0][2] > 0                              # some lists were near-tied and went through the refinement
+    if coef != 1.0:
+        assert res[1, 1, 0][2] > 0                          # some lists were near-tied and went through the refinement
     for x3 in (1, 0):                                       # and inside one kernel every option form returns the same bits
         base = res[x3, 0, 101][0]
         for key, (s, i, refined) in res.items():

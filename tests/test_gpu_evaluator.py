@@ -16,11 +16,11 @@ def _model(case):
     from foodrec_amd import Model
     PM, RE, CE = (np.asarray(case[k], dtype=np.float32) for k in ("PM", "RE", "CE"))
     args = types.SimpleNamespace(num_categories=4, num_users=PM.shape[0], embed_size=PM.shape[2],
-                                 high_level_score_coefficient=0.99)
+                                 high_level_score_coefficient=case.get("coef", 0.99))      # Train_recommender.py:61-62
     return Model(args, PM, RE, CE, None), PM, RE, CE
 
 
-@pytest.mark.parametrize("case", MODEL, ids=lambda c: "E%d-K%d" % (c["E"], c["K"]))
+@pytest.mark.parametrize("case", MODEL, ids=lambda c: "E%d-K%d-coef%s" % (c["E"], c["K"], c.get("coef", 0.99)))
 def test_evaluate_model_matches_reference(case):
     from foodrec_amd import Session, evaluate_model, eval_one_rating
     model, PM, RE, CE = _model(case)

@@ -4,7 +4,7 @@ the documented extension and its reduction to the reference score when the head 
 import numpy as np
 import pytest
 
-from helpers import assert_scores_close, random_case
+from helpers import COEFS, assert_scores_close, random_case
 
 pytestmark = pytest.mark.gpu
 
@@ -44,7 +44,8 @@ def test_mlp_scores_match_restatement(E, C, H1, H2, kernel, B, x3, form):
     dish_cats[3] = 0                                      # NaN dish
     K = (C + 1) * E
     head = _head(K, H1, H2, rng, scale=4.0)              # large enough that the head matters
-    eng = ScoringEngine(PM, RE, CE)
+    coef = ([0.99] + COEFS)[(E // 2 + B) % 6]            # the blend coefficient enters the head through z = PM[u] * Dt[d]
+    eng = ScoringEngine(PM, RE, CE, coef=coef)
     ut, it = torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda")
     with pytest.raises(ValueError):
         eng.score_pairs_mlp(ut, it)
@@ -58,15 +59,16 @@ def test_mlp_scores_match_restatement(E, C, H1, H2, kernel, B, x3, form):
     else:
         want = kernel if kernel == "m2d_mlp_generic" or not x3 else ("m2d_mlp_mfma_bf16x3" if form else "m2d_mlp_pc_bf16x3")
     assert eng.last_kernel() == want
-    ref = oracle.inference_mlp(PM, RE, CE, dish_cats, *head, users, items)
-    base = oracle.inference_f64(PM, RE, CE, users, items, dish_cats[items])
+    ref = oracle.inference_mlp(PM, RE, CE, dish_cats, *head, users, items, coef=coef)
+    base = oracle.inference_f64(PM, RE, CE, users, items, dish_cats[items], coef)
     ok = ~np.isnan(ref)
     if ok.sum() > 10:
         assert np.abs(ref[ok] - base[ok]).mean() > 1e-2, "head too small to be tested"
     assert_scores_close(got.cpu().numpy(), ref, what="E%d B%d" % (E, B))
 
 
-def test_mlp_reduces_to_reference_and_reports_bad_ids():
+@pytest.mark.parametrize("coef", [0.99] + COEFS)
+def test_mlp_reduces_to_reference_and_reports_bad_ids(coef):
     import torch
     from foodrec_amd import ScoringEngine
     from oracle import m2d_oracle as oracle
@@ -76,11 +78,11 @@ def test_mlp_reduces_to_reference_and_reports_bad_ids():
     dish_cats[dish_cats.sum(1) == 0, 2] = 1
     rng = np.random.default_rng(2)
     W1, b1, W2, b2, w3, b3 = _head((C + 1) * E, 256, 64, rng)
-    eng = ScoringEngine(PM, RE, CE); eng.set_dish_categories(dish_cats)
+    eng = ScoringEngine(PM, RE, CE, coef=coef); eng.set_dish_categories(dish_cats)
     eng.set_mlp_head(W1, b1, W2, b2, np.zeros_like(w3), 0.0)          # head contributes exactly 0
     ut, it = torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda")
     got = eng.score_pairs_mlp(ut, it).cpu().numpy(); eng.check()
-    assert_scores_close(got, oracle.inference_f64(PM, RE, CE, users, items, dish_cats[items]), 1e-5, "zero head")
+    assert_scores_close(got, oracle.inference_f64(PM, RE, CE, users, items, dish_cats[items], coef), 1e-5, "zero head")
     assert_scores_close(got, eng.score_pairs_bydish(ut, it).cpu().numpy(), 1e-5, "vs reference kernel")
     bad = users.copy(); bad[77] = U
     with pytest.raises(IndexError, match="user id %d at position 77" % U):
@@ -127,7 +129,8 @@ def test_mlp_many_tiles_per_block(E, B):
     dish_cats[::5] *= rng.uniform(0.25, 3.0, (len(dish_cats[::5]), C)).astype(np.float32)     # weighted masks: the pattern is "weight != 0"
     dish_cats[11] = 0                                                                          # a dish without categories: NaN, its own bucket
     head = _head((C + 1) * E, 256, 64, rng, scale=4.0)
-    eng = ScoringEngine(PM, RE, CE); eng.set_dish_categories(dish_cats); eng.set_mlp_head(*head)
+    coef = {128: 0.99, 64: 0.5, 32: 1.25}[E]
+    eng = ScoringEngine(PM, RE, CE, coef=coef); eng.set_dish_categories(dish_cats); eng.set_mlp_head(*head)
     ut, it = torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda")
     got = eng.score_pairs_mlp(ut, it); eng.check()
     assert eng.last_kernel() == "m2d_mlp_pc_bf16x3"
@@ -147,7 +150,7 @@ def test_mlp_many_tiles_per_block(E, B):
     assert np.isfinite(g[ok]).all() and np.isnan(o[~ok]).all()
     assert np.max(np.abs(g[ok] - o[ok]) / np.maximum(1.0, np.abs(o[ok]))) < 5e-5      # two split-bf16 kernels, different summation orders
     pick = np.concatenate([np.arange(0, 300), rng.integers(0, B, 3000), np.arange(B - 300, B)])
-    ref = oracle.inference_mlp(PM, RE, CE, dish_cats, *head, users[pick], items[pick])
+    ref = oracle.inference_mlp(PM, RE, CE, dish_cats, *head, users[pick], items[pick], coef=coef)
     assert_scores_close(g[pick], ref, what="E%d sample" % E)                # NaN rows (dish 11) must agree too
     bad = items.copy(); pos = B - 12_345; bad[pos] = I + 3
     with pytest.raises(IndexError, match="item id %d at position %d" % (I + 3, pos)):

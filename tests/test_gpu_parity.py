@@ -8,7 +8,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from helpers import assert_scores_close, assert_scores_match_nonfinite, random_case, score_cases
+from helpers import COEFS, assert_scores_close, assert_scores_match_nonfinite, random_case, score_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -45,10 +45,11 @@ def test_native_library_is_what_runs(torch_cuda):
 def test_golden_vectors(torch_cuda, path):
     from oracle import m2d_oracle as oracle
     z = np.load(path)
-    eng = _engine(z["PM"], z["RE"], z["CE"], coef=float(z["coef"]))
+    coef = float(z["coef"])                                # high_level_score_coefficient of the case (Train_recommender.py:61-62)
+    eng = _engine(z["PM"], z["RE"], z["CE"], coef=coef)
     got = _run(eng, torch_cuda, z["users"], z["items"], z["cats"])
     assert_scores_close(got, z["score_f64"], what="HIP vs frozen f64")
-    assert_scores_close(got, oracle.inference_f64(z["PM"], z["RE"], z["CE"], z["users"], z["items"], z["cats"]),
+    assert_scores_close(got, oracle.inference_f64(z["PM"], z["RE"], z["CE"], z["users"], z["items"], z["cats"], coef),
                         what="HIP vs live oracle")
     if "hand" in z.files:
         assert abs(float(got[0]) - 3.4625) < 1e-6
@@ -58,7 +59,11 @@ def test_golden_vectors(torch_cuda, path):
                                    (300, 100, 4, 200), (64, 64, 4, 256), (50, 40, 4, 260), (30, 20, 4, 7),
                                    (40, 30, 3, 16), (40, 30, 9, 64), (25, 12, 1, 4)])
 @pytest.mark.parametrize("B", [1, 63, 64, 65, 4097])
-def test_seeded_shapes(torch_cuda, shape, B):
+@pytest.mark.parametrize("coef", [0.99] + COEFS)
+def test_seeded_shapes(torch_cuda, shape, B, coef):
+    """Every pair kernel (C = 4 throughput / latency forms, C != 4, odd embedding sizes) at every blend coefficient:
+    `coef * high + (1 - coef) * low` with `1 - coef` taken in float32 (Model_Recommender.py:17, :95-96) -- the reference's
+    flag default is 0.99 (Train_recommender.py:61-62); 0 and 1 switch a level off, 1.25 makes the low level's weight negative."""
     from oracle import m2d_oracle as oracle
     U, I, C, E = shape
     PM, RE, CE, users, items, cats = random_case(U, I, C, E, B, seed=U + E + B)
@@ -66,17 +71,18 @@ def test_seeded_shapes(torch_cuda, shape, B):
         cats[1] = 1.0
         cats[2] = 0.0
         cats[3] = np.linspace(0.25, 1.75, C)
-    eng = _engine(PM, RE, CE)
+    eng = _engine(PM, RE, CE, coef=coef)
     got = _run(eng, torch_cuda, users, items, cats)
-    assert_scores_close(got, oracle.inference_f64(PM, RE, CE, users, items, cats), what=str(shape))
+    assert_scores_close(got, oracle.inference_f64(PM, RE, CE, users, items, cats, coef), what=str(shape))
 
 
-def test_kernel_variants_agree(torch_cuda):
+@pytest.mark.parametrize("coef", [0.99, 0.0, 1.0, 1.25])
+def test_kernel_variants_agree(torch_cuda, coef):
     from oracle import m2d_oracle as oracle
     for E in (32, 64, 128, 200):
         PM, RE, CE, users, items, cats = random_case(500, 300, 4, E, 20000, seed=E)     # > 8192: the throughput form
-        ref = oracle.inference_f64(PM, RE, CE, users, items, cats)
-        eng = _engine(PM, RE, CE)
+        ref = oracle.inference_f64(PM, RE, CE, users, items, cats, coef)
+        eng = _engine(PM, RE, CE, coef=coef)
         outs = []
         eng.set_option("variant", 12)                      # the latency form (default up to 8192 pairs), forced
         outs.append(_run(eng, torch_cuda, users, items, cats))
@@ -282,7 +288,8 @@ def test_rows_of_weight_zero_categories_are_not_needed(E, B):
         assert_scores_match_nonfinite(eng2.score_pairs(ut, it, ct).cpu().numpy(), oracle.inference_f64(PM2, RE, CE, users, items, cats))
 
 
-def test_user_high_table_option(torch_cuda):
+@pytest.mark.parametrize("coef", [0.99, 0.5, 1.25])
+def test_user_high_table_option(torch_cuda, coef):
     """Serving option "user_high_table": batches of >= 2^18 pairs take the high-level sum from the derived table
     <U_high[u], CE_c>.  Same scores within rounding; the table follows the engine's tables (its own writers reset it,
     in-place edits from outside are announced with tables_updated() as for the retrieval tables)."""
@@ -292,7 +299,7 @@ def test_user_high_table_option(torch_cuda):
     U, I, C, E, B = 700, 300, 4, 64, (1 << 18) + 77
     PM, RE, CE, users, items, cats = random_case(U, I, C, E, B, seed=21)
     pmt = torch.as_tensor(PM, device="cuda")
-    eng = ScoringEngine(pmt, RE, CE)
+    eng = ScoringEngine(pmt, RE, CE, coef=coef)
     ut, it, ct = (torch.as_tensor(x, device="cuda") for x in (users, items, cats))
     lit = eng.score_pairs(ut, it, ct).cpu().numpy(); eng.check()
     assert eng.last_kernel() == "m2d_score_pairs_c4"
@@ -303,7 +310,7 @@ def test_user_high_table_option(torch_cuda):
     assert np.array_equal(np.isnan(tab), np.isnan(lit))
     assert np.max(np.abs(tab[ok] - lit[ok]) / np.maximum(1.0, np.abs(lit[ok]))) < 2e-6
     pick = np.arange(0, B, 97)
-    assert_scores_close(tab[pick], oracle.inference_f64(PM, RE, CE, users[pick], items[pick], cats[pick]))
+    assert_scores_close(tab[pick], oracle.inference_f64(PM, RE, CE, users[pick], items[pick], cats[pick], coef))
     eng.set_option("prefetch", 4)                                               # the table kernel's other instantiation
     tab4 = eng.score_pairs(ut, it, ct).cpu().numpy(); eng.check()
     assert eng.last_kernel() == "m2d_score_pairs_c4_uh" and np.array_equal(tab4, tab, equal_nan=True)
@@ -315,7 +322,7 @@ def test_user_high_table_option(torch_cuda):
     eng.tables_updated()
     PM2 = PM.copy(); PM2[:, 0, :] *= 2.0
     tab2 = eng.score_pairs(ut, it, ct).cpu().numpy(); eng.check()
-    assert_scores_close(tab2[pick], oracle.inference_f64(PM2, RE, CE, users[pick], items[pick], cats[pick]))
+    assert_scores_close(tab2[pick], oracle.inference_f64(PM2, RE, CE, users[pick], items[pick], cats[pick], coef))
 
 
 def test_unusual_mask_weights_with_and_without_row_skipping(torch_cuda):
@@ -398,11 +405,12 @@ def test_vectorised_kernel_for_other_category_counts(torch_cuda, C, E):
     torch = torch_cuda
     from oracle import m2d_oracle as oracle
     B = 20011
+    coef = ([0.99] + COEFS)[(C + E // 4) % 6]             # each shape at one of the blend coefficients
     PM, RE, CE, users, items, cats = random_case(700, 300, C, E, B, seed=C * 100 + E)
     cats[7] = np.linspace(0.25, 1.75, C)
     cats[9] = 0.0                                         # 0/0 -> NaN
-    ref = oracle.inference_f64(PM, RE, CE, users, items, cats)
-    eng = _engine(PM, RE, CE)
+    ref = oracle.inference_f64(PM, RE, CE, users, items, cats, coef)
+    eng = _engine(PM, RE, CE, coef=coef)
     outs = []
     for skip in (1, 0):
         for nt in (1, 0):
@@ -425,7 +433,7 @@ def test_vectorised_kernel_for_other_category_counts(torch_cuda, C, E):
     u, d = torch.as_tensor(users, device=eng.device), torch.as_tensor(items, device=eng.device)
     byd = eng.score_pairs_bydish(u, d); eng.check()
     assert eng.last_kernel() == "m2d_score_pairs_cn"
-    assert_scores_close(byd.cpu().numpy(), oracle.inference_f64(PM, RE, CE, users, items, dish_cats[items]), what="by dish")
+    assert_scores_close(byd.cpu().numpy(), oracle.inference_f64(PM, RE, CE, users, items, dish_cats[items], coef), what="by dish")
     bad = items.copy(); bad[12345] = 300
     eng.score_pairs(u, torch.as_tensor(bad, device=eng.device), torch.as_tensor(cats, device=eng.device))
     with pytest.raises(IndexError, match="item id 300 at position 12345"):

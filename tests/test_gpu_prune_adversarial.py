@@ -14,6 +14,7 @@ plus the float64 restatement's ranking on a sample (`_check`)."""
 import numpy as np
 import pytest
 
+from helpers import COEFS
 from test_gpu_catalogue import _check
 
 pytestmark = pytest.mark.gpu
@@ -102,14 +103,21 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("style,E,x3,eps,low_scale,I", CASES)
-def test_pruned_lists_equal_the_plain_scan_under_cancellation(style, E, x3, eps, low_scale, I):
+# three of the styles again at the other blend coefficients (Train_recommender.py:61-62): the bounds' alpha_P scales with coef,
+# their reach and rounding margins with |1 - coef| -- 0 leaves the cancelling low level alone to rank, 1 leaves none of it,
+# 1.25 flips its sign
+COEF_CASES = [c + (coef,) for coef in COEFS for c in (("anti", 64, 1, 1e-4, 6.0, 7000), ("anti_equal_alpha", 64, 0, 1e-3, 6.0, 3000),
+                                                       ("hc_cancel", 64, 1, 1e-4, 1.0, 7000))]
+
+
+@pytest.mark.parametrize("style,E,x3,eps,low_scale,I,coef", [c + (0.99,) for c in CASES] + COEF_CASES)
+def test_pruned_lists_equal_the_plain_scan_under_cancellation(style, E, x3, eps, low_scale, I, coef):
     import torch
     from foodrec_amd import ScoringEngine
     U, k = 100_352, 10                                     # 392 blocks of 256 users
     seed = 9000 + sum(map(ord, style)) + E + 7 * x3 + I + int(-np.log10(eps)) if eps else 9000 + sum(map(ord, style)) + E + I
     PM, RE, CE, cats = adversarial_tables(style, E, U, I, seed, eps=eps, low_scale=low_scale)
-    eng = ScoringEngine(PM, RE, CE)
+    eng = ScoringEngine(PM, RE, CE, coef=coef)
     eng.set_dish_categories(cats)
     eng.set_option("topk_bf16x3", x3)
     users = torch.arange(U, dtype=torch.int32, device="cuda")

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 from hypothesis import given, settings, strategies as st
 
-from helpers import assert_scores_close, random_case, score_cases
+from helpers import COEFS, assert_scores_close, random_case, score_cases
 from oracle import c_oracle, m2d_oracle as oracle
 
 
@@ -26,13 +26,14 @@ def test_hand_known_answer():
 def test_golden_vectors_frozen(path):
     z = np.load(path)
     args = (z["PM"], z["RE"], z["CE"], z["users"], z["items"], z["cats"])
-    f64 = oracle.inference_f64(*args)
-    f32 = oracle.inference_f32(*args)
+    coef = float(z["coef"])                                # 0.99 (the flag's default) or the *_coef* cases' own
+    f64 = oracle.inference_f64(*args, coef)
+    f32 = oracle.inference_f32(*args, coef)
     assert_scores_close(f64, z["score_f64"], 1e-12, "f64 vs frozen")
     assert_scores_close(f32, z["score_f32"], 2e-6, "f32 vs frozen")        # numpy's pairwise sum may regroup
     assert_scores_close(f32, f64, 1e-5, "f32 vs f64")
-    assert_scores_close(c_oracle.score_pairs(*args), f64, 1e-5, "C vs f64")
-    assert_scores_close(c_oracle.score_pairs(*args, materialised=True), f64, 1e-5, "C-materialised vs f64")
+    assert_scores_close(c_oracle.score_pairs(*args, coef=coef), f64, 1e-5, "C vs f64")
+    assert_scores_close(c_oracle.score_pairs(*args, coef=coef, materialised=True), f64, 1e-5, "C-materialised vs f64")
     if "hand" in z.files:
         assert abs(float(f64[0]) - float(z["hand"][0])) < 1e-6
 
@@ -47,6 +48,28 @@ def test_factored_form_agrees(shape):
     direct = oracle.inference_f64(PM, RE, CE, users, items, dish_cats[items])
     fact = oracle.inference_factored(PM, RE, CE, users, items, dish_cats)
     assert_scores_close(fact, direct, 1e-5, "factored vs direct")
+
+
+@pytest.mark.parametrize("coef", COEFS)
+def test_blend_coefficient_in_every_restatement(coef):
+    """`coef * high + (1 - coef) * low` with a float32 `1 - coef` (Model_Recommender.py:17, :95-96): the float64, float32,
+    factored, C and torch restatements agree at every coefficient, and the two levels can be read off the extremes."""
+    import torch
+    from oracle import torch_graph
+    PM, RE, CE, users, items, _ = random_case(60, 40, 4, 32, 300, seed=int(coef * 100) + 3)
+    dish_cats = np.random.default_rng(2).integers(0, 2, (40, 4)).astype(np.float32)
+    cats = dish_cats[items]
+    a, b = oracle.blend_coefficients(coef)
+    assert float(b) == float(np.float32(1.0) - np.float32(coef))
+    f64 = oracle.inference_f64(PM, RE, CE, users, items, cats, coef)
+    assert_scores_close(oracle.inference_f32(PM, RE, CE, users, items, cats, coef), f64, 1e-5, "f32")
+    assert_scores_close(oracle.inference_factored(PM, RE, CE, users, items, dish_cats, coef), f64, 1e-5, "factored")
+    assert_scores_close(c_oracle.score_pairs(PM, RE, CE, users, items, cats, coef=coef), f64, 1e-5, "C")
+    got = torch_graph.inference(*(torch.from_numpy(x) for x in (PM, RE, CE, users, items, cats)), coef=coef).numpy()
+    assert_scores_close(got, f64, 1e-5, "torch graph")
+    high = oracle.inference_f64(PM, RE, CE, users, items, cats, 1.0)       # 1 - 1 = 0: the high level alone
+    low = oracle.inference_f64(PM, RE, CE, users, items, cats, 0.0)
+    assert_scores_close(f64, float(a) * high + float(b) * low, 1e-12, "levels")
 
 
 def test_zero_mask_is_nan_and_weights_are_linear():
