@@ -247,6 +247,9 @@ class UserShardedScorer:
         and, one round later, copy the gathered round into the result.  Two staging buffers alternate; the copy of round
         r - 1 is queued (behind its all-gather, in front of round r + 1's kernels) before round r + 1 may overwrite a piece."""
         world, per, dev = self.world, self.per, self.device
+        if per == 0:                                            # no user anywhere: nothing to rank, nothing to exchange
+            self.last_allgather_events = None
+            return (torch.empty((0, k), dtype=torch.float32, device=dev), torch.empty((0, k), dtype=torch.int32, device=dev))
         out_s = torch.empty((world, per, k), dtype=torch.float32, device=dev)
         out_i = torch.empty((world, per, k), dtype=torch.int32, device=dev)
         rows_max = min(round_users, per)

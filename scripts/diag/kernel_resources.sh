@@ -1,6 +1,6 @@
 #!/bin/bash
 # Register / spill / occupancy table of every kernel in one HIP source (hipcc -Rpass-analysis=kernel-resource-usage).
-#   scripts/diag/kernel_resources.sh foodrec_amd/csrc/m2d_catalogue.hip [name filter]
+#   scripts/diag/kernel_resources.sh foodrec_amd/csrc/m2d_catalogue_scan_bf16.hip [name filter]
 src=$1; filt=${2:-.}
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -Wno-inline-asm -Wno-unused-function \
     -Rpass-analysis=kernel-resource-usage -c "$src" -o /dev/null 2>&1 |

@@ -1,6 +1,7 @@
 // Phase timing of m2d_mlp_mfma (dev tool; not part of the product).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DM2D_MLP_DIAG=1 scripts/diag/mlp_diag.cpp -o mlp_diag
-#include "../../foodrec_amd/csrc/m2d_catalogue.hip"
+#include "../../foodrec_amd/csrc/m2d_catalogue_dense.hip"      // m2d_ensure_dish_vectors
+#include "../../foodrec_amd/csrc/m2d_catalogue_merge.hip"
 #include "../../foodrec_amd/csrc/m2d_mlp.hip"
 
 #include <algorithm>

@@ -1,6 +1,12 @@
 // Ablation timing of m2d_topk_mfma (dev tool; not part of the product).  Build one binary per mask:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DM2D_DIAG=<mask> scripts/diag/topk_diag.cpp -o topk_diag_<mask>
-#include "../../foodrec_amd/csrc/m2d_catalogue.hip"
+// (a unity build of the retrieval units: -DM2D_DIAG reaches every kernel)
+#include "../../foodrec_amd/csrc/m2d_catalogue_dense.hip"
+#include "../../foodrec_amd/csrc/m2d_catalogue_plan.hip"
+#include "../../foodrec_amd/csrc/m2d_catalogue_scan_f32.hip"
+#include "../../foodrec_amd/csrc/m2d_catalogue_scan_bf16.hip"
+#include "../../foodrec_amd/csrc/m2d_catalogue_merge.hip"
+#include "../../foodrec_amd/csrc/m2d_catalogue_repair.hip"
 
 int m2d_ensure_finite_scan(m2d_engine *, hipStream_t) { return M2D_OK; }   // (m2d_abi.hip is not part of this binary)
 

@@ -13,7 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # git: build it before anything is collected (hipcc cross-compiles gfx950 without a GPU, ~15 s).
 if not os.path.exists(os.path.join(ROOT, "foodrec_amd", "libm2d.so")):
     import subprocess
-    subprocess.run(["make", "-C", os.path.join(ROOT, "foodrec_amd", "csrc"), "-j", "4"], check=True,
+    subprocess.run(["make", "-C", os.path.join(ROOT, "foodrec_amd", "csrc"), "-j", "8"], check=True,
                    stdout=subprocess.DEVNULL)
 
 

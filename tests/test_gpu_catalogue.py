@@ -422,21 +422,21 @@ def test_pattern_pruning_changes_nothing_but_the_work(E, low_scale, coef):
         for forced in (0, 101, 105):                      # automatic splits, one split, five splits
             eng.set_option("variant", forced)
             s, i = eng.topk_users(users, k); eng.check()
-            assert eng.last_kernel() == "m2d_topk_grouped_bf16x3"
+            assert eng.last_kernel() == ("m2d_topk_grouped_bf16x3" if coef != 1.0 else "m2d_topk_high_level_only")
             out[prune, forced] = (s.cpu().numpy(), i.cpu().numpy(), eng.get_option("topk_tiles_scanned"), eng.get_option("topk_tiles_full"))
     base = out[0, 101]
     for key, (s, i, scanned, full) in out.items():
         assert np.array_equal(i, base[1]) and np.array_equal(s, base[0], equal_nan=True), key
     if coef != 1.0:                                       # (coef = 1: no scan at all, see test_high_level_only_blend)
         assert out[0, 101][2] >= out[0, 101][3]           # everything is stepped through without pruning
-    if low_scale <= 1.0 and 0.9 <= coef < 1.0:
+    if low_scale <= 1.0 and coef == 0.99:                 # (at 0.9 the low level reaches ten times further: 0.8 of the tiles)
         assert out[1, 101][2] < 0.5 * out[0, 101][2], (out[1, 101][2], out[0, 101][2])
     eng.set_option("variant", 0); eng.set_option("topk_prune", 1)
     _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:60], k, dup=50)
     _check(eng, PM, RE, CE, cats, np.array([7, 3, 7]), k)       # a single block of users: no sort, the union of three masks
     frac = _assert_ids_are_the_oracles_where_clear(base[1][:80], PM, RE, CE, cats, users.cpu().numpy()[:80], k, coef, gap=3e-5,
                                                    what="coef %s" % coef)
-    assert frac > 0.3, frac
+    assert frac > 0.3 or low_scale < 1.0, frac             # (a low level scaled down: most gaps are under 3e-5)
 
 
 @pytest.mark.parametrize("E,x3", [(64, 1), (64, 0), (128, 1), (200, 0), (32, 0)])
@@ -466,6 +466,8 @@ def test_high_level_only_blend(E, x3, nU):
             continue                                          # (no dense MFMA kernel for K = 1000: the one-block-per-user kernel, covered elsewhere)
         eng.set_option("topk_grouped", grouped); eng.set_option("topk_prune", prune); eng.set_option("variant", forced)
         s, i = eng.topk_users(users, k); eng.check()
+        assert eng.last_kernel() == ("m2d_topk_high_level_only" if grouped else "m2d_topk_mfma")
+        assert eng.get_option("topk_repaired") == 0 and eng.get_option("topk_tiles_scanned") == 0      # nothing is scanned, nobody repaired
         s, i = s.cpu().numpy(), i.cpu().numpy()
         frac = _assert_ids_are_the_oracles_where_clear(i[:200], PM, RE, CE, cats, users_np[:200], k, 1.0, gap=3e-6, what=(grouped, prune, forced))
         assert frac > 0.95, frac                              # ties everywhere; only two patterns' alpha within 3e-6 are left out

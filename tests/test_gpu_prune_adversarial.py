@@ -122,7 +122,7 @@ def test_pruned_lists_equal_the_plain_scan_under_cancellation(style, E, x3, eps,
     eng.set_option("topk_bf16x3", x3)
     users = torch.arange(U, dtype=torch.int32, device="cuda")
     out = lists_of_every_form(eng, users, k)
-    assert eng.last_kernel() == ("m2d_topk_grouped_bf16x3" if x3 else "m2d_topk_grouped")
+    assert eng.last_kernel() == (("m2d_topk_grouped_bf16x3" if x3 else "m2d_topk_grouped") if coef != 1.0 else "m2d_topk_high_level_only")
     assert_forms_agree(out, (style, E, x3, eps, low_scale, I))
     sample = np.random.default_rng(seed).choice(U, 24, replace=False)
     _check(eng, PM, RE, CE, cats, sample, k)
