@@ -255,6 +255,24 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped_bf16(GroupedArgs 
 // WAVES: 8 / G (a block of 256 users, 128 KiB of LDS, one block per CU), or 4 with G = 1: a block of 128 users over stages of
 // half the tiles (64 KiB of LDS), TWO blocks per CU -- a stage barrier then holds up four waves, not eight, and the CU's other
 // block keeps the matrix pipes busy meanwhile (launch_grouped: pruned launches, where the waves of a block are unequal).
+#if M2D_DIAG & 256
+// (timing only) quarter 2 (ks & 1) + Q of a 32 x 32 accumulator as the C / D of one v_mfma_f32_16x16x32_bf16
+template <int Q>
+__device__ __forceinline__ void diag_mfma16(v16f &acc, const int ks, const bf16x8 a, const bf16x8 b, const bool from_zero)
+{
+    const v4f z = {0.f, 0.f, 0.f, 0.f};
+    if (ks & 1) {
+        v4f t = {acc[8 + 4 * Q], acc[9 + 4 * Q], acc[10 + 4 * Q], acc[11 + 4 * Q]};
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, from_zero ? z : t, 0, 0, 0);
+        acc[8 + 4 * Q] = t.x; acc[9 + 4 * Q] = t.y; acc[10 + 4 * Q] = t.z; acc[11 + 4 * Q] = t.w;
+    } else {
+        v4f t = {acc[4 * Q], acc[1 + 4 * Q], acc[2 + 4 * Q], acc[3 + 4 * Q]};
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, from_zero ? z : t, 0, 0, 0);
+        acc[4 * Q] = t.x; acc[1 + 4 * Q] = t.y; acc[2 + 4 * Q] = t.z; acc[3 + 4 * Q] = t.w;
+    }
+}
+#endif
+
 template <int E, int KR, int G, bool HV = false, int WAVES = 8 / G, bool KEEP = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(GroupedArgs p)
 {
@@ -576,9 +594,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
             const int st = ks % AR;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
+#if M2D_DIAG & 256
+                // TIMING ONLY (wrong scores; scripts/diag/topk_diag.cpp): the k-step's flops as six v_mfma_f32_16x16x32_bf16 on the
+                // quarters of the same accumulator registers -- what the 2 x 2 arrangement of 16 x 16 tiles over the wave's 32 users
+                // x 32 dishes would issue (each A and each B fragment feeding two MFMAs: the same LDS reads, the same registers) --
+                // to read the clock the chip holds on that shape before anything is built for it (MI355X_MICROARCH "DVFS give-back" 7)
+                diag_mfma16<0>(accN[g], ks, al[st], wh[g][ks], ks < 2);
+                diag_mfma16<0>(accN[g], ks, ah[st], wl[g][ks], false);
+                diag_mfma16<0>(accN[g], ks, ah[st], wh[g][ks], false);
+                diag_mfma16<1>(accN[g], ks, ah[st], wl[g][ks], ks < 2);      // (another order: identical chains would be merged)
+                diag_mfma16<1>(accN[g], ks, ah[st], wh[g][ks], false);
+                diag_mfma16<1>(accN[g], ks, al[st], wh[g][ks], false);
+#else
                 accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[st], wh[g][ks], ks == 0 ? zero16 : accN[g], 0, 0, 0);
                 accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], wl[g][ks], accN[g], 0, 0, 0);
                 accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], wh[g][ks], accN[g], 0, 0, 0);
+#endif
             }
             // k-step ks + AR of this tile (q-1), or k-step ks + AR - KS of the next (q)
             const unsigned char *a = smem8 + (ks + AR < KS ? (img_prev ^ ((ks + AR) << 5)) : (img_off ^ ((ks + AR - KS) << 5)));

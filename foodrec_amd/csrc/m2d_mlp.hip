@@ -597,6 +597,26 @@ __device__ __forceinline__ void pc_wait_vmem()
 typedef float v2f_pc __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_pc __attribute__((ext_vector_type(2)));
 
+#ifndef M2D_MLP_SHAPE16
+#define M2D_MLP_SHAPE16 0
+#endif
+#if M2D_MLP_SHAPE16
+// (timing only) quarter 2 half + Q of a 32 x 32 accumulator as the C / D of one v_mfma_f32_16x16x32_bf16
+template <int Q>
+__device__ __forceinline__ void mlp_diag_mfma16(v16f &acc, const int half, const bf16x8 a, const bf16x8 b)
+{
+    if (half) {
+        v4f t = {acc[8 + 4 * Q], acc[9 + 4 * Q], acc[10 + 4 * Q], acc[11 + 4 * Q]};
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, t, 0, 0, 0);
+        acc[8 + 4 * Q] = t.x; acc[9 + 4 * Q] = t.y; acc[10 + 4 * Q] = t.z; acc[11 + 4 * Q] = t.w;
+    } else {
+        v4f t = {acc[4 * Q], acc[1 + 4 * Q], acc[2 + 4 * Q], acc[3 + 4 * Q]};
+        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, t, 0, 0, 0);
+        acc[4 * Q] = t.x; acc[1 + 4 * Q] = t.y; acc[2 + 4 * Q] = t.z; acc[3 + 4 * Q] = t.w;
+    }
+}
+#endif
+
 template <int KCH>
 __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
 {
@@ -691,9 +711,21 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
                     __builtin_amdgcn_sched_barrier(0);
                     continue;
                 }
+#if M2D_MLP_SHAPE16
+                // TIMING ONLY (wrong scores; scripts/diag/mlp_diag.cpp): the step's flops as six v_mfma_f32_16x16x32_bf16 on quarters of
+                // the same accumulator -- the 2 x 2 arrangement of 16 x 16 tiles over this step's 32 hidden units x 32 pairs, every
+                // fragment feeding two MFMAs as it would (same LDS reads, same registers) -- to read the clock the chip holds on that shape
+                mlp_diag_mfma16<0>(acc1[nt], ksl, al[it & 3], b[ksl][0]);
+                mlp_diag_mfma16<0>(acc1[nt], ksl, ah[it & 3], b[ksl][1]);
+                mlp_diag_mfma16<0>(acc1[nt], ksl, ah[it & 3], b[ksl][0]);
+                mlp_diag_mfma16<1>(acc1[nt], ksl, ah[it & 3], b[ksl][1]);      // (another order: identical chains would be merged)
+                mlp_diag_mfma16<1>(acc1[nt], ksl, ah[it & 3], b[ksl][0]);
+                mlp_diag_mfma16<1>(acc1[nt], ksl, al[it & 3], b[ksl][0]);
+#else
                 acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[it & 3], b[ksl][0], acc1[nt], 0, 0, 0);
                 acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[it & 3], b[ksl][1], acc1[nt], 0, 0, 0);
                 acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[it & 3], b[ksl][0], acc1[nt], 0, 0, 0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
             hb = hb_add(hb, 2);
@@ -747,9 +779,18 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
                 for (int mt = 0; mt < 2; ++mt) {
                     const bf16x8 wh = *reinterpret_cast<const bf16x8 *>(img + mt * 4096);
                     const bf16x8 wl = *reinterpret_cast<const bf16x8 *>(img + (2 + mt) * 4096);
+#if M2D_MLP_SHAPE16
+                    mlp_diag_mfma16<0>(acc2[mt], ks & 1, wl, bh);
+                    mlp_diag_mfma16<0>(acc2[mt], ks & 1, wh, bl);
+                    mlp_diag_mfma16<0>(acc2[mt], ks & 1, wh, bh);
+                    mlp_diag_mfma16<1>(acc2[mt], ks & 1, wh, bl);
+                    mlp_diag_mfma16<1>(acc2[mt], ks & 1, wh, bh);
+                    mlp_diag_mfma16<1>(acc2[mt], ks & 1, wl, bh);
+#else
                     acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bh, acc2[mt], 0, 0, 0);
                     acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bl, acc2[mt], 0, 0, 0);
                     acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc2[mt], 0, 0, 0);
+#endif
                 }
                 if ((ks & 7) == 7) { hb = hb_add(hb, 2); zb ^= 1; }
             }

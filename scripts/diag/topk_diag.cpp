@@ -12,6 +12,7 @@ int m2d_ensure_finite_scan(m2d_engine *, hipStream_t) { return M2D_OK; }   // (m
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 int main(int argc, char **argv)
@@ -65,6 +66,19 @@ int main(int argc, char **argv)
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (rc) printf("rc=%d %s\n", rc, h.last_error.c_str());
         if (ms < best) best = ms;
+    }
+    // M2D_DIAG_REPS calls queued back to back (no host wait between them), a few times over: the rate, and with M2D_DIAG & 16 the
+    // in-kernel clock of the LAST launch, that the chip HOLDS under this load (a handful of launches read high)
+    if (getenv("M2D_DIAG_REPS")) {
+        const int reps = atoi(getenv("M2D_DIAG_REPS"));
+        for (int round = 0; round < 4; ++round) {
+            hipEventRecord(e0);
+            for (int it = 0; it < reps; ++it) m2d_launch_topk_users(&h, users, U, k, outs, outi, nullptr);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            printf("round %d: %d calls back to back, %.4f ms per call\n", round, reps, ms / reps);
+        }
     }
 #if M2D_DIAG & 16
     {
