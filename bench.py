@@ -81,9 +81,15 @@ def parse():
                    help="BASELINE.json configs[3] / configs[4] as the timed step: 10 M / N users per GPU x 1 M replicated dishes, "
                         "E = 64 / 128, top-10 for EVERY user of the shard in rounds of --round-users, then ONE all-gather of "
                         "[shard, 10] x (f32 score, i32 id) (100 MB per rank at N = 8)")
-    p.add_argument("--round-users", type=int, default=524288, help="users per retrieval launch in the sharded top-k path")
+    p.add_argument("--round-users", type=int, default=0, help="users per retrieval launch in the sharded top-k path "
+                   "(0 = the shard in the fewest even rounds of at most 524288)")
+    p.add_argument("--no-projection", action="store_true", help="skip scaling_path.projected_world8 (the N = 8 per-GPU shape timed on one GPU)")
     p.add_argument("--scaling-users", type=int, default=10_000_000,
                    help="users over ALL GPUs in the scaling_path block (configs[3]: 10 M; 0 = leave the block out)")
+    p.add_argument("--topk-weighted-masks", action="store_true",
+                   help="--workload topk with category weights other than 0 / 1 (the placeholder is float, Model_Recommender.py:32): "
+                        "the masks cannot be grouped by pattern, the dense exact-f32 kernel m2d_topk_mfma serves the call")
+    p.add_argument("--topk-k", type=int, default=10, help="--workload topk: list length (k > 10 takes the 16-slot instantiations)")
     p.add_argument("--topk-with-ingredients", action="store_true",
                    help="workload topk: set the ingredient table first (retrieval over [H[d] | RE[d]] rows, E = 32 / 64)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -569,6 +575,92 @@ def scaling_path_block(torch, dist, foodrec_amd, dev, world, rank, users_total, 
     return out
 
 
+XGMI_LINK_GBS = 153.0      # one xGMI link, per direction (7 links per GPU, point to point)
+
+
+def projected_world8_block(torch, foodrec_amd, dev, users_total, I, E, k, topk_path_ms_n1, rounds=(262144, 0, 524288), repeats=3):
+    """A ONE-GPU PROJECTION of the sharded top-k path at 8 GPUs -- not a measurement of 8 GPUs: this box has one.  What one
+    GPU can say: how long the N = 8 per-GPU shape takes (BASELINE configs[3]: users_total / 8 users held as the LAST shard of
+    eight, the same replicated catalogue, ranked in rounds), at several round sizes -- the fixed launches of a retrieval call and
+    a short last round weigh more on a shard an eighth the size.  What it cannot say is what the seven peers and the
+    collective do; the exchange is priced from SURVEY.md section 5's link rate instead.  `rounds`: users per round; 0 = the shard
+    cut into the fewest EVEN rounds of at most 524 288."""
+    from foodrec_amd.sharding import UserShardedScorer, shard_range
+    C, world, rank = 4, 8, 7
+    base, count = shard_range(users_total, world, rank)
+    per = -(-users_total // world)
+    g = torch.Generator(device=dev); g.manual_seed(20260101 + 4)             # the replicated tables of scaling_path_block
+    sc = E ** -0.5
+    RE = torch.randn((I, E), generator=g, device=dev) * sc
+    CE = torch.randn((C, E), generator=g, device=dev) * sc
+    pat = torch.randint(1, 2 ** C, (I,), generator=g, device=dev, dtype=torch.int32)
+    dish_cats = ((pat[:, None] >> torch.arange(C, device=dev, dtype=torch.int32)[None, :]) & 1).float()
+    g.manual_seed(20260101 + 40 + rank)
+    PM = torch.randn((count, C + 1, E), generator=g, device=dev) * sc
+    eng = foodrec_amd.ScoringEngine(PM, RE, CE, coef=0.99, device=dev, user_base=base)
+    eng.set_dish_categories(dish_cats)
+    sh = UserShardedScorer(eng, users_total, device=dev)
+    sh.base, sh.count, sh.per, sh.rank, sh.world = base, count, per, rank, world      # this process plays rank 7 of 8 (no collective is issued)
+    clk = _Clock(torch, dev)
+    out_rounds = []
+    for R in rounds:
+        R = int(R) if R else -(-count // -(-count // 524288))
+        first = torch.arange(base, base + min(R, count), dtype=torch.int32, device=dev)
+        sh.topk_local(k, first); sh.topk_local(k, first)                      # tables, scratch at this round's size
+        walls = []
+        for _ in range(repeats):
+            clk.sync()
+            t0 = time.perf_counter()
+            sh.topk_local_rounds(k, R)
+            clk.sync()
+            walls.append((time.perf_counter() - t0) * 1e3)
+        eng.check()
+        nround = -(-count // R)
+        last_rows = count - (nround - 1) * R
+        piece, last_piece = R * k * 8, last_rows * k * 8
+        shard_ms = median(walls)
+        # all-gather of one round's pieces over xGMI: every rank sends its piece to 7 peers over 7 links at once (direct, what a
+        # fully connected topology allows) or around a ring (7 steps of one piece per link)
+        direct_ms, ring_ms = piece / (XGMI_LINK_GBS * 1e6), 7 * piece / (XGMI_LINK_GBS * 1e6)
+        exposed_direct, exposed_ring = last_piece / (XGMI_LINK_GBS * 1e6), 7 * last_piece / (XGMI_LINK_GBS * 1e6)
+        out_rounds.append({
+            "round_users": R, "rounds": nround, "last_round_users": last_rows, "shard_ms": shard_ms, "shard_ms_all": walls,
+            "ms_per_round_avg": shard_ms / nround, "allgather_bytes_per_rank_per_round": piece,
+            "allgather_ms_per_round_at_153GBps_direct": direct_ms, "allgather_ms_per_round_at_153GBps_ring": ring_ms,
+            "hidden_behind_next_round": bool(ring_ms < shard_ms / nround),
+            "exposed_last_round_ms_direct": exposed_direct, "exposed_last_round_ms_ring": exposed_ring,
+            "implied_speedup_upper_bound": (topk_path_ms_n1 / (shard_ms + exposed_direct)) if topk_path_ms_n1 else None,
+            "implied_speedup_with_ring_exchange": (topk_path_ms_n1 / (shard_ms + exposed_ring)) if topk_path_ms_n1 else None})
+    best = min(out_rounds, key=lambda r: r["shard_ms"])
+    eng.close()
+    del PM, RE, CE, dish_cats, eng, sh
+    if torch.device(dev).type == "cuda":
+        torch.cuda.empty_cache()
+    return {"status": "PROJECTION from one GPU: UNMEASURED ON HARDWARE at N = 8",
+            "what": ("the N = 8 per-GPU shape of the sharded top-k path timed on ONE GPU: %d of %d users held as shard [%d, %d), "
+                     "%d replicated dishes, E = %d, top-%d for every user of the shard in rounds; the exchange priced at %.0f GB/s "
+                     "per xGMI link (SURVEY.md section 5), not run" % (count, users_total, base, base + count, I, E, k, XGMI_LINK_GBS)),
+            "topk_path_ms_n1": topk_path_ms_n1, "users_per_gpu": count, "rounds": out_rounds,
+            "best_round_users": best["round_users"], "shard_ms": best["shard_ms"],
+            "implied_speedup_upper_bound": best["implied_speedup_upper_bound"],
+            "implied_speedup_with_ring_exchange": best["implied_speedup_with_ring_exchange"],
+            "upper_bound_because": ("every rank is assumed as fast as this one, the per-round collectives fully hidden behind the next "
+                                    "round's ranking (they take a few per cent of a round at the link rate), launch and host overheads "
+                                    "as on this box; north_star asks for >= 6x"),
+            "north_star_target": 6.0}
+
+
+def default_round_users(per_gpu_users, requested):
+    """--round-users 0 (the default): the shard cut into the fewest EVEN rounds of at most 524 288 users -- one round of 524 288
+    at N = 1's 10 M users (20 of them), three of 416 667 at N = 8's 1.25 M (a short last round pays a retrieval call's fixed
+    launches for a fraction of the work: scaling_path.projected_world8 measures the difference)."""
+    if requested:
+        return int(requested)
+    if per_gpu_users <= 0:
+        return 524288
+    return -(-per_gpu_users // -(-per_gpu_users // 524288))
+
+
 def routed_pairs_leg(torch, dist, eng, U, I, C, dev, world, B, repeats=5):
     """Every rank brings B pairs whose users are spread over ALL shards; UserShardedScorer.score_pairs_routed buckets
     them by owner, all-to-alls the records, the owners score, the scores come back ('pairs routed to the
@@ -893,7 +985,10 @@ def main():
     K = (C + 1) * E
     if wl in ("mlp", "topk"):
         pat = torch.randint(1, 2 ** C, (I,), generator=g, device=dev, dtype=torch.int32)
-        eng.set_dish_categories(((pat[:, None] >> torch.arange(C, device=dev, dtype=torch.int32)[None, :]) & 1).float())
+        dcat = ((pat[:, None] >> torch.arange(C, device=dev, dtype=torch.int32)[None, :]) & 1).float()
+        if wl == "topk" and a.topk_weighted_masks:              # any float weight is legal input
+            dcat = dcat * (0.5 + 1.5 * torch.rand((I, C), generator=g, device=dev))
+        eng.set_dish_categories(dcat)
     mlp_head = mlp_cats = None
     if wl == "mlp":
         rn = lambda *shape: torch.randn(shape, generator=g, device=dev)
@@ -909,6 +1004,7 @@ def main():
         eng.set_ingredients(torch.randn((R, E), generator=g, device=dev) * E ** -0.5, off,
                             torch.randint(0, R, (nnz,), generator=g, device=dev, dtype=torch.int32))
     tk_users = sharded = None
+    round_cfg = default_round_users(U, a.round_users)                    # users per retrieval launch of the sharded top-k path
     if wl == "topk":
         from foodrec_amd.sharding import UserShardedScorer
         n_tk = U if a.config is not None else min(a.topk_users if a.topk_users > 0 else 65536, U)
@@ -924,9 +1020,9 @@ def main():
         elif wl == "mlp":
             eng.score_pairs_mlp(users, items, out=out)
         elif a.config is not None:                                       # every user of the shard, rounds, ONE all-gather
-            sharded.topk_all_users(10, round_users=a.round_users)
+            sharded.topk_all_users(10, round_users=round_cfg)
         else:                                                            # retrieval: per-shard top-k, then the exchange
-            sharded.topk_users_gathered(tk_users, 10)
+            sharded.topk_users_gathered(tk_users, a.topk_k)
 
     def barrier():
         torch.cuda.synchronize()
@@ -1080,9 +1176,16 @@ def main():
             in_flight["leg"] = "scaling_path"
             try:
                 scaling = scaling_path_block(torch, dist if use_dist else None, foodrec_amd, dev, world, rank, a.scaling_users,
-                                             1_000_000, 64, 10, a.round_users)
+                                             1_000_000, 64, 10, default_round_users(-(-a.scaling_users // world), a.round_users))
             except Exception as e:                                     # noqa: BLE001
                 scaling = {"error": "%s: %s" % (type(e).__name__, e)}
+            if world == 1 and rank == 0 and not a.no_projection and "error" not in scaling and a.scaling_users >= 8:
+                in_flight["leg"] = "scaling_path.projected_world8"
+                try:
+                    scaling["projected_world8"] = projected_world8_block(torch, foodrec_amd, dev, a.scaling_users, 1_000_000, 64, 10,
+                                                                         scaling.get("wall_ms"))
+                except Exception as e:                                 # noqa: BLE001
+                    scaling["projected_world8"] = {"error": "%s: %s" % (type(e).__name__, e)}
     in_flight["leg"] = "rank-0 side measurements"
 
     if a.sweep and rank == 0:
@@ -1169,12 +1272,14 @@ def main():
             line["config"]["workload"] = (("BASELINE configs[%d]: %d users over %d GPU(s) (%d per GPU) x %d replicated dishes, E=%d: "
                                            "full-catalogue top-10 for EVERY user of the shard in rounds of %d, then ONE all-gather of "
                                            "[shard,10] x (f32 score, i32 id) (%d bytes per rank); build-defined generalisation of "
-                                           "evaluate.py:39-63" % (a.config, world * U, world, U, I, E, a.round_users, U * 80))
+                                           "evaluate.py:39-63" % (a.config, world * U, world, U, I, E, round_cfg, U * 80))
                                           if a.config is not None else
-                                          "BASELINE configs[3]/[4] retrieval: full-catalogue top-10 for %d users per GPU over %d "
+                                          "BASELINE configs[3]/[4] retrieval: full-catalogue top-%d for %d users per GPU over %d "
                                           "replicated dishes (users from this GPU's %d-user shard), E=%d, then all-gather of "
-                                          "[users,10] x (f32 score, i32 id); build-defined generalisation of evaluate.py:39-63"
-                                          % (tk_users.numel(), I, U, E)) + (
+                                          "[users,%d] x (f32 score, i32 id); build-defined generalisation of evaluate.py:39-63"
+                                          % (a.topk_k, tk_users.numel(), I, U, E, a.topk_k)) + (
+                " -- WEIGHTED category masks (any float is legal placeholder input, Model_Recommender.py:32): no pattern grouping, "
+                "the dense exact-f32 kernel contracts over (C + 1) E" if a.topk_weighted_masks else "") + (
                 " -- WITH the build-defined ingredient table (%d rows, 1-20 per dish)" % a.ingredients if a.topk_with_ingredients else "")
             line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                                 "traffic": None, "step_avg_ms": avg_ms, "flop_per_pair_executed": fl / units,
@@ -1199,7 +1304,7 @@ def main():
                                 "a bound on their mask pattern's scores (DESIGN.md 4.4)")
             if sharded is not None and getattr(sharded, "last_allgather_events", None):
                 line["allgather_exposed_ms"] = sharded.last_allgather_events[0].elapsed_time(sharded.last_allgather_events[1])
-            line["roofline"]["allgather_bytes_per_rank"] = tk_users.numel() * 80 if use_dist else 0
+            line["roofline"]["allgather_bytes_per_rank"] = tk_users.numel() * 8 * a.topk_k if use_dist else 0
             line["roofline"]["repaired_users_last_launch"] = eng.get_option("topk_repaired")
         if not a.no_side and wl == "pairs":
             in_flight["leg"] = "no-reuse / stream probe"
@@ -1284,6 +1389,14 @@ def main():
             except Exception as e:                                     # noqa: BLE001
                 line["with_ingredient_table"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if scaling is not None:
+            if world > 1 and wl == "pairs" and "error" not in scaling:
+                # a SCALE record headlines `value`, which is the collective-free pair path in weak scaling (about N x by
+                # construction): say first where the path north_star scales is
+                line["config"]["workload"] = ("[topk_path_ms = %.1f: the STRONGLY scaled user-sharded top-k path (%d users over %d "
+                                              "GPUs x %d dishes, per-round all-gathers) is in topk_path_* / scaling_path -- `value` below "
+                                              "is the weakly scaled pair path] " % (scaling.get("wall_ms") or float("nan"),
+                                                                                   scaling.get("users_total") or 0, world,
+                                                                                   scaling.get("dishes") or 0)) + line["config"]["workload"]
             line["scaling_path"] = scaling                              # ("scaling" itself is the contract's "weak" / "strong" string)
             # the same as scalars of the line itself (a record that keeps only top-level scalar keys keeps these): the path
             # north_star's ">= 6x at 8 GPUs" speaks of
@@ -1293,6 +1406,11 @@ def main():
                          "topk_path_allgather_exposed_ms": scaling.get("allgather_exposed_ms"),
                          "topk_path_dtype": "bf16x3" if str(scaling.get("kernel", "")).endswith("bf16x3") else "f32",
                          "topk_path_users_total": scaling.get("users_total"), "topk_path_dishes": scaling.get("dishes")})
+            pj = scaling.get("projected_world8") or {}
+            if "shard_ms" in pj:                                        # (one-GPU projection of N = 8: labelled as such)
+                line.update({"topk_path_projected_world8_shard_ms": pj["shard_ms"],
+                             "topk_path_projected_world8_speedup_upper_bound": pj["implied_speedup_upper_bound"],
+                             "topk_path_projected_world8_status": pj["status"]})
         if topk_ag is not None:
             line["sharded_topk_allgather"] = topk_ag
         if routed is not None:

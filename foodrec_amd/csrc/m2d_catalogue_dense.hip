@@ -146,6 +146,9 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
     int cnt = 0;
     float thr = -INFINITY;
     v16f acc;
+    int slot_lo[G / 2];                          // float offset of the lane's low slot bits, by T mod G / 2 (see the MFMA loop)
+#pragma unroll
+    for (int t = 0; t < G / 2; ++t) slot_lo[t] = (((2 * t + h) ^ (j & (G - 1))) & (G - 1)) * 4;
 
     if (nstages > 0) issue_stage(0, 0);
     wait_all_vmem();
@@ -176,10 +179,13 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
 #pragma unroll
         for (int cc = 0; cc < NKC; ++cc) {
             if (cc == c) {                                   // static register indices per stage kind
+                // Fragment T of the lane's row sits in slot (2 T + h) ^ key of the swizzled image: the XOR touches the slot's low bits
+                // only, so the lane-dependent part takes G / 2 values (by T mod G / 2) and the rest of the offset is a constant that
+                // rides in the read's immediate.  Written as one expression per T, all 40 lane offsets were hoisted out of the stage
+                // loop as loop invariants -- 40 VGPRs beside the 160 of the user operand: 33 spilled at k = 16, 7 at k = 10.
 #pragma unroll
                 for (int T = 0; T < KC8; ++T) {
-                    const int q = (2 * T + h) ^ (j & (G - 1));
-                    const v4f av = *reinterpret_cast<const v4f *>(img + q * 4);
+                    const v4f av = *reinterpret_cast<const v4f *>(img + slot_lo[T % (G / 2)] + ((2 * T) & ~(G - 1)) * 4);
                     const v4f bv = breg[cc * KC8 + T];
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
@@ -214,7 +220,9 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_mfma(TopkArgs p)
 #if M2D_DIAG & 16
                         was_slow = true;
 #endif
-                        sorted_insert<KR>(rs, ri, v, (int32_t)base + (r & 3) + 8 * (r >> 2));
+                        // (in place, from the last slot up: the out-of-place form's second copy of the list -- 2 KR registers beside
+                        //  the 160 of the user operand -- was what spilled at NB = 40: 33 VGPRs at k = 16, 7 at k = 10)
+                        sorted_insert_inplace<KR>(rs, ri, v, (int32_t)base + (r & 3) + 8 * (r >> 2));
                         thr = rs[KR - 1];
                     }
                 }

@@ -139,6 +139,9 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
     __syncthreads();
 
     v16f acc;
+    int slot_lo[SW / 2];                                   // float offset of the lane's low slot bits, by T mod SW / 2 (see the MFMA loop)
+#pragma unroll
+    for (int t = 0; t < SW / 2; ++t) slot_lo[t] = (((2 * t + h) ^ (j & (SW - 1))) & (SW - 1)) * 4;
     unsigned long long tie_mask = 0ull;                    // lanes with a tie event at their list's present last value (tie_update)
     int tiles_done = 0;
     for (int v = 0; v < vstages; ++v) {
@@ -185,8 +188,10 @@ __global__ __launch_bounds__(WAVES * 64) void m2d_topk_grouped(GroupedArgs p)
 #pragma unroll
             for (int T = 0; T < E8; ++T) {
                 if (PAD && 8 * T >= p.e_real) continue;    // wave-uniform: the rest of the row is padding
-                const int q = (2 * T + h) ^ (j & (SW - 1));
-                const v4f av = *reinterpret_cast<const v4f *>(img + q * 4);
+                // slot (2 T + h) ^ key: the XOR moves the low bits only -- SW / 2 lane-dependent values by T mod SW / 2, the rest in
+                // the read's immediate (as one expression per T the E8 lane offsets were all hoisted out of the tile loop: 32 VGPRs
+                // at E = 256, where the k = 16 instantiation spilled)
+                const v4f av = *reinterpret_cast<const v4f *>(img + slot_lo[T % (SW / 2)] + ((2 * T) & ~(SW - 1)) * 4);
                 const v4f bv = wP[T];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);

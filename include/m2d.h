@@ -118,7 +118,10 @@ int m2d_rank_candidates(m2d_engine *h, const int32_t *users, const int32_t *item
  * or is refused), and such users -- an all-zero Personal_Memory block, a user vector that scores whole groups
  * identically -- are re-ranked over the catalogue in id order with the formula in plain f32 (their scores are then
  * exact-f32 even under "topk_bf16x3" = 1).  Option "topk_grouped" = 0 selects the dense kernel (about 5x the matrix
- * work), which scans in id order. */
+ * work), which scans in id order.
+ * coef = 1 (Train_recommender.py:61-62; `1 - coef` is then an exact float32 zero, Model_Recommender.py:96): every dish of a
+ * mask pattern scores alpha_P[u], so the pattern-grouped path reads each list off the patterns' lowest dish ids, best
+ * alpha_P first (m2d_topk_high_level_only: no scan, no repair; what heapq.nlargest returns for whole groups of equal scores). */
 int m2d_topk_users(m2d_engine *h, const int32_t *users, int64_t nU, int32_t k, float *out_scores,
                    int32_t *out_ids, void *stream);
 
@@ -224,53 +227,62 @@ int m2d_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_t *item
  * bad_value / bad_index (host pointers, may be NULL) receive the offending id and its position. */
 int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_index);
 
-/* "skip_masked" (default 1): the pair kernels do not fetch the Personal_Memory row of a category whose mask weight is
- * exactly 0 -- the reference graph multiplies that row by 0 (Model_Recommender.py:82), so for finite tables the score
- * is the same to the bit and a pair moves (2 + active categories) x E x 4 bytes of rows instead of (C + 2) x E x 4.
- * A non-finite value inside such a row makes the graph's score NaN (0 x inf), so rows are left out only while every value
- * of the three tables is finite: the engine keeps a device word for that -- set by a scan of the tables that m2d_create
- * and m2d_tables_updated queue for the next scoring call, and by m2d_train_step / m2d_write_memory on the values they
- * write -- and with it set every kernel fetches and multiplies everything, whatever this option says (results then equal
- * the literal graph's, NaN positions included).  0 forces the literal fetch-and-multiply.  m2d_score_pairs_mlp uses the
- * same fact per tile: it groups a launch's pairs by
- * the dish's pattern of non-zero weights and does not multiply the k-blocks a pattern lacks (0 = pairs as they come).
- * "user_high_table" (default 0, a serving option): calls of >= 2^18 pairs take the high-level sum from a derived table
- * uh[u][c] = <U_high[u], CE_c> (16 B per user, built by a pass over Personal_Memory and rebuilt after the engine's own
- * writers or m2d_tables_updated) as sum_c m_c uh[u][c] / n -- the same products in another order, scores within 1e-6 --
- * so that a pair reads 16 bytes of it instead of the U_high row.  Off, every call multiplies the gathered row.
- * "host_zero_copy" (default 2): see m2d_score_pairs_host.
- * Kernel-selection knobs for benchmarking ("prefetch", "nt_loads", "blocks_per_cu", "variant"): results
- * never depend on them.  Two numerical switches, both for build-defined paths: "topk_bf16x3" (default 1) lets
- * m2d_topk_users contract on split-bf16 MFMA (x = hi + lo, three bf16 products, fp32 accumulation; score error
- * ~1e-5 relative, inside the 1e-4 bar) where the mask table is 0/1 and E is 64 or 128; "mlp_bf16x3" (default 1)
- * does the same for layers 1-2 of m2d_score_pairs_mlp; 0 forces the exact-f32 MFMA kernels.  "mlp_form" (default 0)
- * picks between the two split-bf16 head kernels, same results within the split's rounding: 0 = matrix waves fed by
- * gather / DMA waves, 1 = every wave gathers its own rows.  "topk_grouped"
- * (default 1; see m2d_topk_users) and "topk_form" (0 / 2 = the pipelined split-bf16 retrieval kernel, 1 = its first
- * form; same results) select among retrieval kernels.  "topk_prune" (default 1): the pattern-grouped retrieval kernels
- * (pipelined split-bf16 and exact f32) start each user's scan from a lower bound of its k-th score and step through the
- * tiles of the mask patterns that can reach its top-k only (with 0/1 masks every dish of pattern P scores within
- * alpha_P[u] +- |w_P[u]| max|RE[d]|, widened by what f32 / split-bf16 arithmetic can move a computed score by, measured
- * against the sums of absolute terms so that cancelling rows keep their margin; users are sorted by their pattern mask so that a block's users share patterns, and a
- * launch's (user block, dish range) items are handed out longest first); the lists are the same bit for bit with 0 (every
- * tile).  2 / 3 / 4 / 5 / 6 are A/B forms of the same: the bound only, no sort, the patterns only, the grid's launch order,
- * the bound without its probe rows (the k-th largest exact score among the first rows of the user's best pattern); 7: a
- * user's dish ranges keep their thresholds apart (by default they meet in one atomic-max word per user, E = 64); 9: the tie
- * repair reads every pattern's dishes (by default only the patterns that can reach its users' top-k).  "topk_block"
- * (default 0): users per block of a pruned pipelined launch -- 0 = the launcher's choice (128 for E = 64, at least 16 384
- * users and catalogues up to 8 192 tiles, else 256), 128 / 256 forced; same lists.  "topk_refine" (default 1): the
- * pattern-grouped kernels (pipelined split-bf16 and exact f32, E = 32 / 64 / 128, k <= 10 at E = 128 split-bf16) finish
- * near-tied lists -- neighbouring scores, or the last entry and a score left out, closer than twice the kernel's rounding
- * margin -- in the tie repair's plain-f32 arithmetic, so that both kernels return the same dish ids (a few per cent of the
- * users are re-scored; ties at a list's end are settled there too, the tie repair keeps the users with three or more dishes
- * that close; no measurable cost); 0 = the lists as the scan leaves them, ties repaired over the user's patterns.  "topk_probes" (default 0 = 16 /
- * 32 / 64 by catalogue size): probe rows per user of the retrieval plan, 8 ... 64 (A/B; more rows bought nothing measurable).
- * m2d_score_pairs* (the reference path) is always exact float32.  Unknown names: M2D_ERR_INVALID_ARG.
- * m2d_get_option also answers three diagnostics of the last m2d_topk_users call on the pattern-grouped kernels (they
- * synchronise the device): "topk_repaired" (users the tie repair re-ranked over their patterns),
- * "topk_tiles_scanned" / "topk_tiles_full" (32-dish tiles the blocks stepped through / would have without pruning; a
- * block holds "topk_block_users" users, 256 or 128, which m2d_get_option answers too), "topk_refined" /
- * "topk_refine_repaired" (users whose near-tied list was finished by m2d_topk_refine / sent on to the tie repair). */
+/* Options.  m2d_score_pairs* -- the reference path (Model_Recommender.py:56-97) -- is exact float32 whatever is set here.
+ * Unknown names: M2D_ERR_INVALID_ARG.  "Results" = the scores / ids a call returns.
+ *
+ * ---- product switches -------------------------------------------------------------------------------------------------------------
+ * name             default  values  changes results?                          what it does
+ * skip_masked      1        0 / 1   no while every table value is finite      Pair kernels do not fetch the Personal_Memory row of a category whose
+ *                                   (same bits); with inf / NaN in a table    mask weight is exactly 0 -- the graph multiplies it by 0 (:82) -- so a pair
+ *                                   the engine ignores it and multiplies      moves (2 + active categories) E 4 B of rows, not (C + 2) E 4 B; a device word
+ *                                   everything (the graph's NaNs)             "a table value is not finite" (table scan queued by m2d_create /
+ *                                                                             m2d_tables_updated, the engine's writers on what they write) switches it
+ *                                                                             off.  m2d_score_pairs_mlp: pairs grouped by the dish's pattern of non-zero
+ *                                                                             weights, k-blocks a pattern lacks not multiplied.  0 = literal fetch-and-multiply.
+ * user_high_table  0        0 / 1   scores within 1e-6 (another summation     Calls of >= 2^18 pairs read sum_c m_c <U_high[u], CE_c> / n from a derived
+ *                                   order)                                    [U, 4] table (16 B per user; rebuilt after the engine's writers or
+ *                                                                             m2d_tables_updated) instead of the U_high row.  A serving option.
+ * host_zero_copy   2        0 1 2   no                                        m2d_score_pairs_host up to 65 536 pairs: 2 = the kernel works on the pinned
+ *                                                                             block and the call spins on a completion word, 1 = without the spin, 0 = staged copies.
+ * topk_bf16x3      1        0 / 1   scores within ~1e-5 relative; dish ids    m2d_topk_users, 0/1 masks, E = 64 / 128: contraction on split-bf16 MFMA
+ *                                   identical while topk_refine = 1           (x = hi + lo, three bf16 products, f32 accumulation).  0 = exact-f32 MFMA.
+ * topk_refine      1        0 / 1   ids of near-tied lists (E = 32 / 64 /     Pattern-grouped kernels finish lists whose neighbouring scores -- or last
+ *                                   128; k <= 10 at E = 128 split bf16)       entry and best score left out -- lie within twice the kernel's rounding
+ *                                                                             margin in ONE plain-f32 arithmetic, so split-bf16 and exact-f32 return the
+ *                                                                             same ids (a few per cent of the users re-scored; no measurable cost).
+ *                                                                             0 = lists as the scan leaves them, ties at a list's end repaired.
+ * topk_grouped     1        0 / 1   scores within the 1e-4 bar; both forms    0/1 masks, C = 4, k <= 16: dishes sorted by mask pattern, contraction over E
+ *                                   resolve ties to the lower dish id         (m2d_topk_users above).  0 = the dense kernel over (C + 1) E (about 5x the work).
+ * mlp_bf16x3       1        0 / 1   scores within ~1e-5 relative              Layers 1-2 of m2d_score_pairs_mlp on split-bf16 MFMA.  0 = exact-f32 MFMA.
+ *
+ * ---- diagnostic / A-B values: kernel selection for benchmarking and tests; results never depend on them (same bits) unless noted ------
+ * name             default  values
+ * prefetch         2        1 / 2 / 4    row-load steps issued ahead in the pair kernels
+ * nt_loads         1        0 / 1        non-temporal loads of Personal_Memory rows
+ * blocks_per_cu    8        1 ... 16     grid size of the pair kernels
+ * mlp_form         0        0 / 1        split-bf16 head kernel: 0 = matrix waves fed by gather / DMA waves, 1 = every wave gathers its own rows
+ *                                        (same results within the split's rounding)
+ * topk_form        0        0 / 1 / 2    split-bf16 retrieval kernel: 0 / 2 = pipelined form, 1 = first form (same lists)
+ * topk_prune       1        0 ... 9      pattern-grouped retrieval: 1 = scan starts from a lower bound of the user's k-th score and steps through the
+ *                                        tiles of the mask patterns that can reach its top-k only (bounds: alpha_P[u] +- |w_P[u]| max|RE[d]|, widened by
+ *                                        what the arithmetic can move a computed score by; users sorted by pattern mask; (user block, dish range) items
+ *                                        longest first); 0 = every tile.  A/B forms: 2 the bound only, 3 no sort, 4 the patterns only, 5 the grid's launch
+ *                                        order, 6 the bound without its probe rows, 7 a user's dish ranges keep their thresholds apart (by default they
+ *                                        meet in one atomic-max word per user, E = 64), 9 the tie repair reads every pattern's dishes.  Same lists, bit for bit.
+ * topk_block       0        0 128 256    users per block of a pruned pipelined launch (0 = the launcher's choice)
+ * topk_probes      0        0, 8 ... 64  probe rows per user of the retrieval plan (0 = 16 / 32 / 64 by catalogue size)
+ * variant          0        7 8 9 11 12 13 14, 100 + n
+ *                                        7 / 8 / 9: retrieval on the dense MFMA kernel / with LDS lists / on the one-block-per-user kernel; 9 also
+ *                                        forces the generic pair and head kernels; 11 / 12: the pair kernel's throughput / latency form whatever the
+ *                                        batch size; 13: tie repair's one-block-per-user tier from the third listed user on; 14: the nine-launch
+ *                                        training step; 100 + n: n dish-range splits in retrieval
+ *
+ * ---- read-only diagnostics of the last m2d_topk_users call (m2d_get_option; they synchronise the device) ---------------------------------
+ * topk_repaired          users the tie repair re-ranked over their patterns
+ * topk_refined           users whose near-tied list m2d_topk_refine finished;  topk_refine_repaired: of those, sent on to the tie repair
+ * topk_tiles_scanned     32-dish tiles the blocks stepped through;  topk_tiles_full: what they would have without pruning
+ * topk_block_users       users per block of that launch (128 or 256);  num_cu: compute units of the device
+ */
 int m2d_set_option(m2d_engine *h, const char *name, int64_t value);
 int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value);
 

@@ -4,6 +4,8 @@
 #include "../../foodrec_amd/csrc/m2d_catalogue_merge.hip"
 #include "../../foodrec_amd/csrc/m2d_mlp.hip"
 
+int m2d_ensure_finite_scan(m2d_engine *, hipStream_t) { return M2D_OK; }   // (m2d_abi.hip is not part of this binary)
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>

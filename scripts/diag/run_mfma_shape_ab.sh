@@ -6,16 +6,18 @@
 set -o pipefail
 OUT=gpurun_out/r05; mkdir -p $OUT/diag
 CC="/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-fast-math -Wno-inline-asm -Wno-unused-value"
-for M in 0 256 16 272; do $CC -DM2D_DIAG=$M scripts/diag/topk_diag.cpp -o $OUT/diag/topk_$M 2> $OUT/diag/build_topk_$M.log & done
+ONLY=${ONLY:-both}        # retrieval | mlp | both
+if [ $ONLY != mlp ]; then for M in 0 256 16 272; do $CC -DM2D_DIAG=$M scripts/diag/topk_diag.cpp -o $OUT/diag/topk_$M 2> $OUT/diag/build_topk_$M.log & done; fi
 $CC -DM2D_MLP_SHAPE16=0 scripts/diag/mlp_diag.cpp -o $OUT/diag/mlp_s0 2> $OUT/diag/build_mlp_s0.log &
 $CC -DM2D_MLP_SHAPE16=1 scripts/diag/mlp_diag.cpp -o $OUT/diag/mlp_s1 2> $OUT/diag/build_mlp_s1.log &
 $CC -DM2D_MLP_SHAPE16=0 -DM2D_MLP_DIAG=2048 scripts/diag/mlp_diag.cpp -o $OUT/diag/mlp_s0_clk 2> $OUT/diag/build_mlp_s0c.log &
 $CC -DM2D_MLP_SHAPE16=1 -DM2D_MLP_DIAG=2048 scripts/diag/mlp_diag.cpp -o $OUT/diag/mlp_s1_clk 2> $OUT/diag/build_mlp_s1c.log &
 wait
 ls -la $OUT/diag | grep -v log
-R=$OUT/shape_ab.txt; : > $R
+R=$OUT/shape_ab_$ONLY.txt; : > $R
 export M2D_DIAG_PATTERNS=1
 for rep in 1 2 3; do
+  [ $ONLY = mlp ] && break
   for M in 0 256; do
     echo "== retrieval, every tile (prune 0), shape build $M, pass $rep" >> $R
     M2D_DIAG_PRUNE=0 M2D_DIAG_REPS=150 timeout -k 5 120 $OUT/diag/topk_$M >> $R 2>&1 || echo FAILED >> $R
@@ -25,12 +27,14 @@ for rep in 1 2 3; do
   echo progress retrieval pass $rep
 done
 for M in 16 272; do
+  [ $ONLY = mlp ] && break
   echo "== retrieval STAMPED (clock), every tile, build $M" >> $R
   M2D_DIAG_PRUNE=0 M2D_DIAG_REPS=100 timeout -k 5 120 $OUT/diag/topk_$M >> $R 2>&1 || echo FAILED >> $R
   echo "== retrieval STAMPED (clock), pruned, build $M" >> $R
   M2D_DIAG_PRUNE=1 M2D_DIAG_REPS=300 timeout -k 5 120 $OUT/diag/topk_$M >> $R 2>&1 || echo FAILED >> $R
 done
 echo progress retrieval stamped
+[ $ONLY = retrieval ] && exit 0
 for rep in 1 2 3; do
   for S in s0 s1; do
     echo "== MLP head (1 M pairs, 200 k users, E = 128, masks grouped), build $S, pass $rep" >> $R

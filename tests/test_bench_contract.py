@@ -36,6 +36,20 @@ def test_flags_and_defaults(monkeypatch):
     assert (a.gpus, a.steps, a.warmup) == (8, 7, 3)
 
 
+def test_round_size_of_the_sharded_topk_path():
+    """--round-users 0 (the default): a shard is ranked in the fewest EVEN rounds of at most 524 288 users -- BASELINE configs[3]'s
+    10 M users: 20 rounds of 500 000 at N = 1, 3 of 416 667 at N = 8 (1.25 M per GPU) -- and an explicit value is taken as is."""
+    b = _bench()
+    assert b.default_round_users(10_000_000, 0) == 500_000
+    assert b.default_round_users(1_250_000, 0) == 416_667
+    assert b.default_round_users(2_500_000, 0) == 500_000 and b.default_round_users(5_000_000, 0) == 500_000
+    assert b.default_round_users(300, 0) == 300 and b.default_round_users(0, 0) == 524288
+    assert b.default_round_users(1_250_000, 262144) == 262144
+    for n in (1, 7, 524288, 524289, 1_250_000, 9_999_999):
+        r = b.default_round_users(n, 0)
+        assert r <= 524288 and -(-n // r) == -(-n // 524288)          # as few rounds as 524 288 would take, none longer
+
+
 def test_usable_cores_is_bounded_by_the_affinity_mask():
     b = _bench()
     n = b.usable_cores()
