@@ -30,7 +30,8 @@ int main(int argc, char **argv)
       float *d; hipMalloc(&d, c.size() * 4); hipMemcpy(d, c.data(), c.size() * 4, hipMemcpyHostToDevice); h.dish_cats = d; }
     h.mlp_w1 = dev(K * 256, 0.1f); h.mlp_b1 = dev(256, 0.1f); h.mlp_w2 = dev(256 * 64, 0.1f); h.mlp_b2 = dev(64, 0.1f);
     h.mlp_w3 = dev(64, 0.1f); h.mlp_b3 = 0.f; h.mlp_h1 = 256; h.mlp_h2 = 64;
-    hipMalloc(&h.err_dev, 16); hipMemset(h.err_dev, 0, 16);
+    hipMalloc(&h.err_dev, 32); hipMemset(h.err_dev, 0, 32);
+    h.nonfinite_dev = h.err_dev + 4; h.finite_scan_pending = false;        // (the pair grouping reads the "a table value is not finite" word)
     if (argc > 3) h.opt_mlp_form = atoi(argv[3]);
     std::vector<int32_t> hu(B), hi(B);
     for (int64_t i = 0; i < B; ++i) { s = s * 1664525u + 1013904223u; hu[i] = (s >> 4) % U; s = s * 1664525u + 1013904223u; hi[i] = (s >> 4) % I; }
