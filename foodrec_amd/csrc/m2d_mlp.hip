@@ -600,6 +600,9 @@ typedef __bf16 bf16x2_pc __attribute__((ext_vector_type(2)));
 #ifndef M2D_MLP_SHAPE16
 #define M2D_MLP_SHAPE16 0
 #endif
+#ifndef M2D_MLP_NT_DISH
+#define M2D_MLP_NT_DISH 0
+#endif
 #if M2D_MLP_SHAPE16
 // (timing only) quarter 2 half + Q of a 32 x 32 accumulator as the C / D of one v_mfma_f32_16x16x32_bf16
 template <int Q>
@@ -941,7 +944,11 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
                 // user rows are read about once per batch: non-temporal, so they do not push the dish vectors (each
                 // read ~10 times) out of L2 / the Infinity Cache
                 ra[set][i] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(bu + (uint64_t)ou * 16));
+#if M2D_MLP_NT_DISH
+                rb_[set][i] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(bd + (uint64_t)od * 16));      // (A/B, scripts/diag)
+#else
                 rb_[set][i] = *reinterpret_cast<const v4f *>(bd + (uint64_t)od * 16);
+#endif
                 __builtin_amdgcn_sched_barrier(0);                        // one pair of addresses live at a time
             }
         };
