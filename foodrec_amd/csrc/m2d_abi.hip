@@ -130,7 +130,6 @@ void release(m2d_engine *h)
         if (h->ing_w) (void)hipFree((void *)h->ing_w);
     }
     if (h->scratch) (void)hipFree(h->scratch);
-    if (h->dish_scale) (void)hipFree(h->dish_scale);
     if (h->topk_flags) (void)hipFree(h->topk_flags);
     if (h->topk_plan) (void)hipFree(h->topk_plan);
     if (h->topk_ex) (void)hipFree(h->topk_ex);

@@ -28,7 +28,7 @@ namespace {
 __global__ __launch_bounds__(256) void m2d_build_dish_vectors(const float *re, const float *ce,
                                                               const float *dish_cats, const float *hv, int64_t I,
                                                               int C, int E, float a, float b, float *dt,
-                                                              int64_t rows, float *scale)
+                                                              int64_t rows)
 {
     const int lane = threadIdx.x & 63;
     const int64_t d = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -41,7 +41,6 @@ __global__ __launch_bounds__(256) void m2d_build_dish_vectors(const float *re, c
     }
     float n = 0.f;
     for (int c = 0; c < C; ++c) n += dish_cats[d * C + c];                 // :77
-    if (lane < C) scale[d * C + lane] = dish_cats[d * C + lane] / n;       // the factor of the low-level blocks below, kept as a table
     for (int e = lane; e < E; e += 64) {
         float s = 0.f;
         for (int c = 0; c < C; ++c) s = fmaf(dish_cats[d * C + c], ce[(size_t)c * E + e], s);   // :67 summed over c
@@ -449,13 +448,10 @@ int m2d_ensure_dish_vectors(m2d_engine *h, hipStream_t st)
         if (h->dish_vec) M2D_HIP_TRY(h, hipFree(h->dish_vec));
         h->dish_vec = nullptr;
         M2D_HIP_TRY(h, hipMalloc((void **)&h->dish_vec, (size_t)rows * K * sizeof(float)));
-        if (h->dish_scale) M2D_HIP_TRY(h, hipFree(h->dish_scale));
-        h->dish_scale = nullptr;
-        M2D_HIP_TRY(h, hipMalloc((void **)&h->dish_scale, (size_t)rows * h->C * sizeof(float)));
         h->dish_vec_rows = rows;
     }
     hipLaunchKernelGGL(m2d_build_dish_vectors, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, h->re, h->ce,
-                       h->dish_cats, h->dish_high, h->I, h->C, h->E, h->a, h->b, h->dish_vec, rows, h->dish_scale);
+                       h->dish_cats, h->dish_high, h->I, h->C, h->E, h->a, h->b, h->dish_vec, rows);
     M2D_HIP_TRY(h, hipGetLastError());
     h->dish_vec_valid = true;
     return M2D_OK;

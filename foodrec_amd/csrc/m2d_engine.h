@@ -71,8 +71,6 @@ struct m2d_engine {
     float *dish_vec = nullptr;  // [I_pad, (C+1)*E]
     int64_t dish_vec_rows = 0;
     bool dish_vec_valid = false;
-    float *dish_scale = nullptr;  // [I, C] m_c / n per dish (Model_Recommender.py:77, :82), built with the dish vectors: the head's
-                                  // producer / consumer kernel forms Dt's low-level blocks from Recipe_Embedding rows with it
 
     // pattern-grouped retrieval tables (0/1 masks only; built lazily by m2d_topk_users)
     float *grp_rs = nullptr;            // [grp_cap_rows, E] Recipe_Embedding rows sorted by (mask pattern, dish id)

@@ -63,10 +63,6 @@ struct MlpArgs {
     const uint32_t *tile_blocks; // [ntiles] the E-wide k-blocks a tile's pattern keeps: nibble j = j-th block, bits 28-31 = count
     const int32_t *ntiles_dev;   // [1]
     int32_t pshift;              // log2(periods of 32 k-values per block)
-    const float *re;             // [I, E] Recipe_Embedding and [I, C] m_c / n (m2d_engine::dish_scale): Dt's low-level block c is
-    const float *dscale;         //   b * ((m_c / n) * RE[d]) (Model_Recommender.py:82-96) -- the gatherers form it from the dish's ONE
-    float b;                     //   E-float row instead of fetching C more rows of the dish-vector table
-    int32_t C;
 };
 
 __device__ __forceinline__ void latch(int32_t *err, int code, int64_t value, int64_t index)
@@ -903,14 +899,7 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
         const unsigned char *dt = reinterpret_cast<const unsigned char *>(p.dt);
         // rows as 32-bit offsets in units of 16 B, this lane's slot included: (row * K / 4 + s) -- the launcher takes
         // this kernel only for tables under 64 GiB.  One 64-bit shift-add per load turns one into an address.
-        // The dish vector's blocks c >= 1 are (1 - a) (m_c / n) RE[d] (Model_Recommender.py:82-96): C scaled copies of ONE row.
-        // Fetched from the dish-vector table they were C more 4 E-byte rows per pair from a table five times the size of
-        // Recipe_Embedding -- as many bytes as the user block's, from beyond the caches -- and the row gather runs at this part's
-        // gather rate (24 GB/s per CU), which is what the tile time was: 33 k cycles of gatherer against 31 k of consumer.  Now a
-        // period of block c >= 1 requests its 128 bytes of RE[d] (51 MB at config 2's sizes: cache-resident, the same line again
-        // for every category the dish has) and the build applies b * ((m_c / n) * r) -- the table's own expression, so z is the
-        // same to the bit.  Block 0 (the high-level vector) still comes from the table.
-        uint32_t cu[8], cd[8], nu[8], nd[8];                              // this tile / the next one: user row offset, dish id
+        uint32_t cu[8], cd[8], nu[8], nd[8];                              // this tile / the next one
         unsigned badmask = 0, nbadmask = 0;
         v4f ra[2][8], rb_[2][8];
         v2f_pc base[8];
@@ -942,31 +931,15 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
                 if (!valid || ul < 0 || ul >= p.U) ul = 0;
                 if (!valid || did < 0 || (int64_t)did >= p.I) dl = 0;
                 nu[i] = (uint32_t)ul * (uint32_t)(K / 4) + (uint32_t)s;
-                nd[i] = (uint32_t)dl;
+                nd[i] = (uint32_t)dl * (uint32_t)(K / 4) + (uint32_t)s;
             }
         };
-        const int E4 = (8 << pshift);                                     // float4 per Recipe_Embedding row (E = 32 << pshift)
-        const unsigned char *rep = reinterpret_cast<const unsigned char *>(p.re);
-        float scn[8], scb[8];                                             // m_c / n of the pairs: as requested for the block coming up / of the block being built
-        int set_half[2] = {0, 0};                                         // the period each row set was requested for (uniform)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) scb[i] = scn[i] = 0.f;
         auto gather = [&](int set, const uint32_t (&iu)[8], const uint32_t (&id)[8], int half) __attribute__((always_inline)) {
-            set_half[set] = half;
             if (M2D_MLP_DIAG & 8) return;                                 // diag bit 3: no row requests
-            const int blk = half >> pshift, qin = half & ((1 << pshift) - 1);       // uniform
-            const unsigned char *bu = pm + half * 128;
-            const unsigned char *bd = blk == 0 ? dt + half * 128 : rep + qin * 128;
-            const uint32_t dmul = blk == 0 ? (uint32_t)(K / 4) : (uint32_t)E4;
-            // the block's first period: its factor of every pair, requested with the rows and taken over by that period's build
-            // (blocks of ONE period -- E = 32 -- would have two requests in flight: they read it at build time instead)
-            if (blk != 0 && qin == 0 && pshift > 0) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) scn[i] = p.dscale[(size_t)id[i] * p.C + (blk - 1)];
-            }
+            const unsigned char *bu = pm + half * 128, *bd = dt + half * 128;       // uniform
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                uint32_t ou = iu[i], od = id[i] * dmul + (uint32_t)s;
+                uint32_t ou = iu[i], od = id[i];
                 asm volatile("" : "+v"(ou), "+v"(od));                    // keep the 64-bit products out of registers
                 // user rows are read about once per batch: non-temporal, so they do not push the dish vectors (each
                 // read ~10 times) out of L2 / the Infinity Cache
@@ -984,16 +957,9 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
         auto build = [&](int set) __attribute__((always_inline)) {
             if (M2D_MLP_DIAG & 2) return;                                 // diag bit 1: no z build
             unsigned char *zs = pcs + PC_Z_OFF + zb * PC_ZSET + z_w;
-            const int bblk = set_half[set] >> pshift;                      // the block this row set belongs to (uniform)
-            if (bblk != 0 && (set_half[set] & ((1 << pshift) - 1)) == 0) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) scb[i] = pshift > 0 ? scn[i] : p.dscale[(size_t)cd[i] * p.C + (bblk - 1)];
-            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                v4f dv = rb_[set][i];
-                if (bblk != 0) dv = p.b * (scb[i] * dv);                  // Dt[d][block] = b * ((m_c / n) * RE[d]): the table's expression
-                const v4f zz = ra[set][i] * dv;
+                const v4f zz = ra[set][i] * rb_[set][i];
                 const v2f_pc z01 = {zz.x, zz.y}, z23 = {zz.z, zz.w};
                 base[i] += z01 + z23;
                 *reinterpret_cast<v4f *>(zs + (i >> 2) * 4096 + (i & 3) * 128) = zz;
@@ -1160,7 +1126,6 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
     a.dbg = g_m2d_mlp_diag_buffer;
     a.w1x3 = a.w2x3 = nullptr;
     a.perm = nullptr; a.tile_blocks = nullptr; a.ntiles_dev = nullptr; a.pshift = 0;
-    a.re = h->re; a.dscale = h->dish_scale; a.b = h->b; a.C = h->C;
     const bool mfma_ok = a.H1 == MH1 && a.H2 == MH2 && a.K % 64 == 0 && h->opt_variant != 9;
     const int kch = a.K / 64;
     int pad_kch = 0;                          // K % 64 != 0: chunks of the zero-padded form (0 = none instantiated)
