@@ -12,12 +12,14 @@ namespace {
 // entries from ONE thread through a scratch-memory pointer array: ~0.2 ms for a single user with 64 splits, most
 // of that call's latency.)  Splits cover increasing dish ranges, so on equal scores the lower split (= lower lane)
 // wins, which keeps ties in ascending-id order.
+// (returns, in the lane that finished a user's list, the user's refinement word -- see m2d_topk_refine -- or -1)
 template <int LPU>
-__global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k,
-                                                             float *out_scores, int32_t *out_ids, const float *tie_in, float *tie_out,
-                                                             int32_t *tie_list, int64_t I, const float *ex_in = nullptr, float *ex_out = nullptr,
-                                                             const float *plan = nullptr, int32_t *rcount = nullptr)
+__device__ __forceinline__ int32_t merge_splits_body(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k,
+                                                     float *out_scores, int32_t *out_ids, const float *tie_in, float *tie_out,
+                                                     int32_t *tie_list, int64_t I, const float *ex_in, float *ex_out,
+                                                     const float *plan, int32_t *rcount)
 {
+    int32_t ret_ent = -1;
     const int lane = threadIdx.x & 63, w = lane & (LPU - 1);
     const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPU;
     const bool live = u < nU && w < nsplit;
@@ -145,8 +147,21 @@ __global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, co
                 if (to_repair) atomicAdd(&rcount[1], 1);
             }
         }
-        if (rcount && tie_list && u < nU && w == 0) rcount[8 + u] = refine_ent;      // a word per user, no atomics (m2d_topk_refine compacts)
+        if (rcount && tie_list && u < nU && w == 0) {
+            rcount[8 + u] = refine_ent;                      // a word per user, no atomics (m2d_topk_refine compacts)
+            ret_ent = refine_ent;
+        }
     }
+    return ret_ent;
+}
+
+template <int LPU>
+__global__ __launch_bounds__(256) void m2d_topk_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k,
+                                                             float *out_scores, int32_t *out_ids, const float *tie_in, float *tie_out,
+                                                             int32_t *tie_list, int64_t I, const float *ex_in = nullptr, float *ex_out = nullptr,
+                                                             const float *plan = nullptr, int32_t *rcount = nullptr)
+{
+    (void)merge_splits_body<LPU>(ps, pi, nU, nsplit, k, out_scores, out_ids, tie_in, tie_out, tie_list, I, ex_in, ex_out, plan, rcount);
 }
 
 // Users with fewer than k ranked dishes (every finite-scored dish is already in their list, the rest of the
@@ -225,27 +240,13 @@ __global__ __launch_bounds__(256) void m2d_topk_refine_flag(RefineArgs p)
 // the repair's arithmetic.  A lane emulates the sixteen lanes the repair gives a dish: partial j = the fma chain over float4
 // columns j, j + 16, ... of the row (it.x w.x first ... as there), then the rotation sum's tree -- (p_j + p_j+8), then + the
 // same of j + 4, of j + 2, of j + 1; the adds commute, so the tree does not depend on the rotations' direction.
+// the listed users of a block (s_list[0 .. count): position in the call | left-out dishes to take along << 30), 32 lanes each
 template <int CH>                                           // float4 columns per emulated lane: E <= 64 CH
-__global__ __launch_bounds__(256) void m2d_topk_refine(RefineArgs p)
+__device__ __forceinline__ void refine_listed_users(const RefineArgs &p, const int32_t *s_list, const int count, v4f (*s_w)[32])
 {
     constexpr int C = 4;
     const int lane = threadIdx.x & 63, half = lane >> 5, i = lane & 31;
     const int k = p.k, E = p.E, E4 = E >> 2, W = (C + 1) * E;
-    // a block takes 64 users: their words are compacted in LDS (a list with one global counter cost 40 us of serialised atomics)
-    __shared__ int32_t s_list[64];
-    __shared__ int s_count;
-    __shared__ v4f s_w[8][32];                              // per half-wave: the pattern's low-level operand, a float4 column per lane
-    if (threadIdx.x == 0) s_count = 0;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int64_t uu = (int64_t)blockIdx.x * 64 + threadIdx.x;
-        const int32_t e = uu < p.nU ? p.counter[8 + uu] : -1;
-        if (e != -1) s_list[atomicAdd(&s_count, 1)] = e;
-    }
-    __syncthreads();
-    const int count = s_count;
-    if (count == 0) return;
-    if (threadIdx.x == 0) atomicAdd(&p.counter[0], count);
     for (int f = (threadIdx.x >> 6) * 2 + half; f < ((count + 1) & ~1); f += 8) {
         const bool fvalid = f < count;                      // (both halves of a wave run the same trip count: the shuffles below see a full EXEC)
         const int32_t ent = fvalid ? s_list[f] : 0;
@@ -343,6 +344,52 @@ __global__ __launch_bounds__(256) void m2d_topk_refine(RefineArgs p)
     }
 }
 
+
+// A/B ("variant" = 15; DESIGN_LABBOOK.md section C): the LAST merge pass with the refinement in its tail -- the block's near-tied
+// users are compacted in LDS and re-scored by the same 32-lanes-per-user routine, one launch less per call.  The lists, the
+// left-out records and the plan words the routine reads were written by this block (workgroup-scope visibility: the barrier).
+template <int LPU, int CH>
+__global__ __launch_bounds__(256) void m2d_topk_merge_refine(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k,
+                                                             float *out_scores, int32_t *out_ids, const float *tie_in, float *tie_out,
+                                                             int32_t *tie_list, int64_t I, const float *ex_in, float *ex_out,
+                                                             const float *plan, int32_t *rcount, RefineArgs rf)
+{
+    __shared__ int32_t s_list[256 / LPU];
+    __shared__ int s_count;
+    __shared__ v4f s_w[8][32];
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    const int32_t ent = merge_splits_body<LPU>(ps, pi, nU, nsplit, k, out_scores, out_ids, tie_in, tie_out, tie_list, I, ex_in, ex_out,
+                                               plan, rcount);
+    if (ent != -1) s_list[atomicAdd(&s_count, 1)] = ent;
+    __syncthreads();
+    const int count = s_count;
+    if (count == 0) return;
+    if (threadIdx.x == 0) atomicAdd(&rf.counter[0], count);
+    refine_listed_users<CH>(rf, s_list, count, s_w);
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void m2d_topk_refine(RefineArgs p)
+{
+    // a block takes 64 users: their words are compacted in LDS (a list with one global counter cost 40 us of serialised atomics)
+    __shared__ int32_t s_list[64];
+    __shared__ int s_count;
+    __shared__ v4f s_w[8][32];                              // per half-wave: the pattern's low-level operand, a float4 column per lane
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int64_t uu = (int64_t)blockIdx.x * 64 + threadIdx.x;
+        const int32_t e = uu < p.nU ? p.counter[8 + uu] : -1;
+        if (e != -1) s_list[atomicAdd(&s_count, 1)] = e;
+    }
+    __syncthreads();
+    const int count = s_count;
+    if (count == 0) return;
+    if (threadIdx.x == 0) atomicAdd(&p.counter[0], count);
+    refine_listed_users<CH>(p, s_list, count, s_w);
+}
+
 }  // namespace
 
 void m2d_launch_merge_splits(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k, float *out_s, int32_t *out_i,
@@ -378,6 +425,21 @@ void m2d_launch_merge_splits2(const float *ps, const int32_t *pi, int64_t nU, in
     float *ex_mid = ex ? ex + (size_t)nU * nsplit * 8 : nullptr;
     m2d_launch_merge_splits(ps, pi, nU * G, 64, k, tmp_s, tmp_i, st, tie, tie_mid, nullptr, 0, ex, ex_mid);      // a "user" of this pass is (user, group)
     m2d_launch_merge_splits(tmp_s, tmp_i, nU, G, k, out_s, out_i, st, tie_mid, tie_final, tie_list, I, ex_mid, ex_final, plan, rcount);
+}
+
+// the last merge pass with the refinement in its tail (8 or 16 dish ranges, one pass): true if it was launched
+bool m2d_topk_launch_merge_refine(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k, float *out_s, int32_t *out_i,
+                                  hipStream_t st, const float *tie_in, float *tie_out, int32_t *tie_list, int64_t I, const float *ex_in,
+                                  float *ex_out, const float *plan, int32_t *rcount, const RefineArgs &rf)
+{
+    int lpu = 1;
+    while (lpu < nsplit) lpu <<= 1;
+    if (!(lpu == 8 || lpu == 16) || !ex_in || !plan || !rcount || !tie_list) return false;
+    const unsigned grid = (unsigned)((nU * lpu + 255) / 256);
+#define M2D_MR(L, CHV) if (lpu == L && (rf.E <= 64) == (CHV == 1)) hipLaunchKernelGGL((m2d_topk_merge_refine<L, CHV>), dim3(grid), dim3(256), 0, st, ps, pi, nU, nsplit, k, out_s, out_i, tie_in, tie_out, tie_list, I, ex_in, ex_out, plan, rcount, rf);
+    M2D_MR(8, 1) M2D_MR(16, 1) M2D_MR(8, 2) M2D_MR(16, 2)
+#undef M2D_MR
+    return true;
 }
 
 void m2d_topk_launch_fill_absent(float *scores, int32_t *ids, int64_t nU, int k, int64_t I, hipStream_t st)
