@@ -132,9 +132,6 @@ M2D_INTERNAL void m2d_launch_merge_splits2(const float *ps, const int32_t *pi, i
                                            float *out_s, int32_t *out_i, hipStream_t st, float *tie, float *tie_final, int32_t *tie_list,
                                            int64_t I, float *ex = nullptr, float *ex_final = nullptr, const float *plan = nullptr,
                                            int32_t *rcount = nullptr);
-M2D_INTERNAL bool m2d_topk_launch_merge_refine(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k, float *out_s, int32_t *out_i,
-                                               hipStream_t st, const float *tie_in, float *tie_out, int32_t *tie_list, int64_t I,
-                                               const float *ex_in, float *ex_out, const float *plan, int32_t *rcount, const RefineArgs &rf);
 M2D_INTERNAL void m2d_topk_launch_fill_absent(float *scores, int32_t *ids, int64_t nU, int k, int64_t I, hipStream_t st);
 M2D_INTERNAL void m2d_topk_launch_tie_compact(const float *tie_final, int64_t nU, int32_t *tie_list, float *scores, int32_t *ids, int k,
                                               int64_t I, int refined, hipStream_t st);

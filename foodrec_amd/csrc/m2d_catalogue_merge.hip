@@ -345,30 +345,6 @@ __device__ __forceinline__ void refine_listed_users(const RefineArgs &p, const i
 }
 
 
-// A/B ("variant" = 15; DESIGN_LABBOOK.md section C): the LAST merge pass with the refinement in its tail -- the block's near-tied
-// users are compacted in LDS and re-scored by the same 32-lanes-per-user routine, one launch less per call.  The lists, the
-// left-out records and the plan words the routine reads were written by this block (workgroup-scope visibility: the barrier).
-template <int LPU, int CH>
-__global__ __launch_bounds__(256) void m2d_topk_merge_refine(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k,
-                                                             float *out_scores, int32_t *out_ids, const float *tie_in, float *tie_out,
-                                                             int32_t *tie_list, int64_t I, const float *ex_in, float *ex_out,
-                                                             const float *plan, int32_t *rcount, RefineArgs rf)
-{
-    __shared__ int32_t s_list[256 / LPU];
-    __shared__ int s_count;
-    __shared__ v4f s_w[8][32];
-    if (threadIdx.x == 0) s_count = 0;
-    __syncthreads();
-    const int32_t ent = merge_splits_body<LPU>(ps, pi, nU, nsplit, k, out_scores, out_ids, tie_in, tie_out, tie_list, I, ex_in, ex_out,
-                                               plan, rcount);
-    if (ent != -1) s_list[atomicAdd(&s_count, 1)] = ent;
-    __syncthreads();
-    const int count = s_count;
-    if (count == 0) return;
-    if (threadIdx.x == 0) atomicAdd(&rf.counter[0], count);
-    refine_listed_users<CH>(rf, s_list, count, s_w);
-}
-
 template <int CH>
 __global__ __launch_bounds__(256) void m2d_topk_refine(RefineArgs p)
 {
@@ -425,21 +401,6 @@ void m2d_launch_merge_splits2(const float *ps, const int32_t *pi, int64_t nU, in
     float *ex_mid = ex ? ex + (size_t)nU * nsplit * 8 : nullptr;
     m2d_launch_merge_splits(ps, pi, nU * G, 64, k, tmp_s, tmp_i, st, tie, tie_mid, nullptr, 0, ex, ex_mid);      // a "user" of this pass is (user, group)
     m2d_launch_merge_splits(tmp_s, tmp_i, nU, G, k, out_s, out_i, st, tie_mid, tie_final, tie_list, I, ex_mid, ex_final, plan, rcount);
-}
-
-// the last merge pass with the refinement in its tail (8 or 16 dish ranges, one pass): true if it was launched
-bool m2d_topk_launch_merge_refine(const float *ps, const int32_t *pi, int64_t nU, int nsplit, int k, float *out_s, int32_t *out_i,
-                                  hipStream_t st, const float *tie_in, float *tie_out, int32_t *tie_list, int64_t I, const float *ex_in,
-                                  float *ex_out, const float *plan, int32_t *rcount, const RefineArgs &rf)
-{
-    int lpu = 1;
-    while (lpu < nsplit) lpu <<= 1;
-    if (!(lpu == 8 || lpu == 16) || !ex_in || !plan || !rcount || !tie_list) return false;
-    const unsigned grid = (unsigned)((nU * lpu + 255) / 256);
-#define M2D_MR(L, CHV) if (lpu == L && (rf.E <= 64) == (CHV == 1)) hipLaunchKernelGGL((m2d_topk_merge_refine<L, CHV>), dim3(grid), dim3(256), 0, st, ps, pi, nU, nsplit, k, out_s, out_i, tie_in, tie_out, tie_list, I, ex_in, ex_out, plan, rcount, rf);
-    M2D_MR(8, 1) M2D_MR(16, 1) M2D_MR(8, 2) M2D_MR(16, 2)
-#undef M2D_MR
-    return true;
 }
 
 void m2d_topk_launch_fill_absent(float *scores, int32_t *ids, int64_t nU, int k, int64_t I, hipStream_t st)

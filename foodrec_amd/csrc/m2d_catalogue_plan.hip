@@ -915,15 +915,9 @@ int launch_grouped(m2d_engine *h, const int E8, const int KR, const bool BF16X3,
     f.pm = h->pm; f.re = h->re; f.ce = h->ce; f.cats = h->dish_cats; f.plan = a.plan; f.tie_final = tie_final; f.ex = ex_final;
     f.users = users; f.tie_list = tie_list; f.counter = h->topk_refine_counter; f.nU = nU; f.U = h->U; f.I = h->I;
     f.user_base = h->user_base; f.E = h->E; f.k = k; f.a = h->a; f.b = h->b; f.out_scores = final_s; f.out_ids = final_i;
-    bool refined_in_merge = false;
     if (nsplit > 1) {
-        // "variant" = 15 (A/B): the refinement in the tail of the one merge pass
-        if (ext && h->opt_variant == 15 && nsplit <= 64)
-            refined_in_merge = m2d_topk_launch_merge_refine(a.out_scores, a.out_ids, nU, nsplit, k, final_s, final_i, st, h->topk_flags, tie_final,
-                                                            tie_list, h->I, a.ex_out, ex_final, a.plan, h->topk_refine_counter, f);
-        if (!refined_in_merge)
-            m2d_launch_merge_splits2(a.out_scores, a.out_ids, nU, nsplit, k, tmp_s, tmp_i, final_s, final_i, st, h->topk_flags, tie_final, tie_list,
-                                     h->I, a.ex_out, ex_final, ext ? a.plan : nullptr, ext ? h->topk_refine_counter : nullptr);
+        m2d_launch_merge_splits2(a.out_scores, a.out_ids, nU, nsplit, k, tmp_s, tmp_i, final_s, final_i, st, h->topk_flags, tie_final, tie_list,
+                                 h->I, a.ex_out, ex_final, ext ? a.plan : nullptr, ext ? h->topk_refine_counter : nullptr);
         M2D_HIP_TRY(h, hipGetLastError());
     }
     {   // users whose final k-th score is tied with a score left out: re-ranked in dish-id order (none is the common case)
@@ -939,7 +933,7 @@ int launch_grouped(m2d_engine *h, const int E8, const int KR, const bool BF16X3,
         r.part_i = reinterpret_cast<int32_t *>(r.part_s + (size_t)REPAIR_CAP * REPAIR_SPLITS * k);
         if (nsplit == 1)                                     // (with dish ranges the last merge pass has listed the tied users)
             m2d_topk_launch_tie_compact(tie_final, nU, tie_list, final_s, final_i, (int)k, h->I, ext ? 1 : 0, st);
-        if (ext && !refined_in_merge)                        // (may add to the repair's list; with dish ranges the last merge pass has
+        if (ext)                                             // (may add to the repair's list; with dish ranges the last merge pass has
             m2d_topk_launch_refine(f, nsplit == 1, st);      //  flagged the near-tied users)
         const int rc = m2d_topk_launch_repair(h, r, HV, st);
         if (rc != M2D_OK) return rc;

@@ -646,10 +646,6 @@ def test_split_bf16_lists_are_the_exact_f32_kernels_lists(E, k, I, coef):
         for key, (s, i, refined) in res.items():
             if key[0] == x3:
                 assert np.array_equal(s.view(np.int32), base.view(np.int32)), key
-    for x3 in (1, 0):                                       # "variant" = 15 (A/B): the refinement in the tail of the merge pass -- same bits
-        eng.set_option("topk_bf16x3", x3); eng.set_option("topk_prune", 1); eng.set_option("variant", 15)
-        s, i = eng.topk_users(users, k); eng.check()
-        assert np.array_equal(i.cpu().numpy(), i_ref) and np.array_equal(s.cpu().numpy().view(np.int32), res[x3, 0, 101][0].view(np.int32)), x3
     eng.set_option("topk_bf16x3", 1); eng.set_option("topk_prune", 1); eng.set_option("variant", 0)
     eng.set_option("topk_refine", 0)                        # without it the two kernels disagree on some near-tie (what was measured)
     s_off, i_off = eng.topk_users(users, k); eng.check()
