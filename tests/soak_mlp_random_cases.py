@@ -26,12 +26,13 @@ for it in range(n):
     head = ((rng.standard_normal((K, 256)) * 4 / np.sqrt(K)).astype(np.float32), (rng.standard_normal(256) * 0.1).astype(np.float32),
             (rng.standard_normal((256, 64)) / 4).astype(np.float32), (rng.standard_normal(64) * 0.1).astype(np.float32),
             (rng.standard_normal(64) / 2).astype(np.float32), 0.125)
-    eng = ScoringEngine(PM, RE, CE); eng.set_dish_categories(dc); eng.set_mlp_head(*head)
+    coef = [0.99, 0.9, 0.5, 0.0, 1.25, 1.0][(seed0 + it) % 6]            # --high_level_score_coefficient (no draw: the seeds' tables stay what they were)
+    eng = ScoringEngine(PM, RE, CE, coef=coef); eng.set_dish_categories(dc); eng.set_mlp_head(*head)
     eng.set_option("skip_masked", int(rng.integers(0, 2)))
     eng.set_option("mlp_form", int(rng.integers(0, 3) == 0))
     got = eng.score_pairs_mlp(torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda")); eng.check()
     pick = rng.integers(0, B, min(B, 3000))
-    ref = oracle.inference_mlp(PM, RE, CE, dc, *head, users[pick], items[pick])
+    ref = oracle.inference_mlp(PM, RE, CE, dc, *head, users[pick], items[pick], coef=coef)
     assert_scores_close(got.cpu().numpy()[pick], ref, what="case %d seed %d C%d E%d B%d" % (it, seed0 + it, C, E, B))
     if it % 10 == 0: print("ok", it, C, E, B, eng.last_kernel(), flush=True)
 print("all", n, "cases agree")

@@ -51,7 +51,8 @@ for it in range(n):
                                               pats_per_dish=[3, 12, 15] if rng.integers(0, 2) else None)
         style = 10
     x3 = int(rng.integers(0, 2)) if E in (64, 128) else 0
-    eng = ScoringEngine(PM.astype(np.float32), RE.astype(np.float32), CE.astype(np.float32)); eng.set_dish_categories(cats)
+    coef = [0.99, 0.99, 0.9, 0.5, 0.0, 1.25, 1.0, 0.99][(seed0 + it) % 8]    # --high_level_score_coefficient (Train_recommender.py:61-62; no draw: the seeds' tables stay what they were)
+    eng = ScoringEngine(PM.astype(np.float32), RE.astype(np.float32), CE.astype(np.float32), coef=coef); eng.set_dish_categories(cats)
     eng.set_option("topk_bf16x3", x3)
     nU = int(rng.integers(1, min(U, 2100) + 1)) if serving else int(rng.integers(257, min(U, 30000) + 1))
     users = rng.integers(0, U, nU).astype(np.int32)
@@ -80,7 +81,7 @@ for it in range(n):
     all_items = np.arange(I); nv = min(k, I)
     PMf, REf, CEf = PM.astype(np.float32), RE.astype(np.float32), CE.astype(np.float32)
     for r in rng.integers(0, nU, 6):
-        ref = oracle.inference_f64(PMf, REf, CEf, np.full(I, users[r]), all_items, cats)
+        ref = oracle.inference_f64(PMf, REf, CEf, np.full(I, users[r]), all_items, cats, coef)
         g = i0[r, :nv]
         assert np.all(g >= 0) and np.all(g < I) and len(set(g.tolist())) == nv, (it, g)
         assert_scores_close(s0[r, :nv], ref[g], what="case %d seed %d" % (it, seed0 + it))
@@ -97,6 +98,6 @@ for it in range(n):
             tied_out = [d for d in np.flatnonzero(ref32 == ref32[g[nv - 1]]) if d not in set(g.tolist())]
             if x3 == 0 and tied_out and (ref32[g] == ref32[g[nv - 1]]).any():
                 pass                                                       # (f64 -> f32 equality is not the kernel's: informative only)
-    print("ok", it, kern, "E%d U%d I%d k%d nU%d style%d %s repaired %d" % (E, U, I, k, nU, style, adv or "", eng.get_option("topk_repaired")), flush=True)
+    print("ok", it, kern, "E%d U%d I%d k%d nU%d style%d %s coef %s repaired %d" % (E, U, I, k, nU, style, adv or "", coef, eng.get_option("topk_repaired")), flush=True)
     eng.close()
 print("all", n, "cases agree")
