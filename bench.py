@@ -1235,8 +1235,9 @@ def main():
                                 "dense_equivalent_frac": dense_ex / peak,
                                 "traffic": None, "kernel_avg_ms": avg_ms, "flop_per_pair": fl, "pairs_per_launch": B,
                                 "algorithmic_tflops": tf, "f32_mfma_equivalent_frac": tf / 157.3,
-                                "dtype": ("split bf16 for layers 1-2 (3 x v_mfma_f32_32x32x16_bf16 per product, fp32 "
-                                          "accumulate)" if x3 else "f32 (v_mfma_f32_32x32x2_f32, exact)"),
+                                "dtype": ("split bf16 for layers 1-2 (3 x %s per product, fp32 accumulate)"
+                                          % ("v_mfma_f32_16x16x32_bf16" if kernel_used.startswith("m2d_mlp_pc") else "v_mfma_f32_32x32x16_bf16")
+                                          if x3 else "f32 (v_mfma_f32_32x32x2_f32, exact)"),
                                 "hbm_algorithmic_GBps": hbm, "hbm_frac": hbm / HBM_PEAK_GBS}
             line["dtype"] = "bf16x3" if x3 else "f32"
             if not a.no_cpu_baseline and world == 1:

@@ -433,38 +433,43 @@ constexpr int PC_LDS_BYTES = PC_B1_OFF + (MH1 + 2 * MH2) * 4;
 constexpr int PC_PAIRS = 128;             // pairs per tile
 typedef int v4i_pc __attribute__((ext_vector_type(4)));
 
-// W1 [K, 256] f32 -> per 32 k-values one ring stage of two halves (16 k-values each), a half = [hi: 256 n x 32 B |
-// lo: same]; the two 16-byte slots of a row (k-values 8 h .. 8 h + 7) are swapped for rows with (n >> 3) & 1, so the
-// b128 fragment reads of 16 rows (32 B apart: rows 8 apart share a bank range) are conflict-free.
+// W1 [K, 256] f32 -> per 32 k-values (one step of v_mfma_f32_16x16x32_bf16) one ring stage of two halves, a half = the 128
+// hidden units n = 128 hf .. 128 hf + 127 as [hi: 8 tiles x 1 KiB | lo: the same], a tile = 16 units x 64 B (k-values 0 .. 31 of the
+// period); the four 16-byte slots of a row (k-values 8 g .. 8 g + 7: lane group g's fragment) sit at slot g ^ 2 ((n >> 3) & 1), so
+// that the four 16-lane groups a ds_read_b128 is served in -- {0-3, 12-15, 20-27}, ... -- each touch sixteen different 16-byte
+// slots of the 256-byte bank row (rows are 64 B: four rows per bank row).  Halves by hidden units, not by k: the consumers are done
+// with a period's first half at its middle barrier, which is what lets the ring do with 3.5 stages.
 __global__ __launch_bounds__(256) void m2d_mlp_image_pc_w1(const float *w1, int K, __bf16 *out)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one (k, n) element
     if (t >= (int64_t)K * MH1) return;
     const int k = (int)(t / MH1), n = (int)(t % MH1);
-    const int kk = k & 15, hh = kk >> 3, j = kk & 7;
+    const int kk = k & 31, g = kk >> 3, j = kk & 7;
     const float x = w1[t];
     const __bf16 hi = (__bf16)x;
-    __bf16 *half = out + (size_t)(k >> 4) * (PC_HALF / 2);
-    const int e = n * 16 + ((hh ^ ((n >> 3) & 1)) << 3) + j;
+    __bf16 *half = out + ((size_t)(k >> 5) * 2 + (n >> 7)) * (PC_HALF / 2);
+    const int e = ((n & 127) >> 4) * 512 + (n & 15) * 32 + ((g ^ (((n >> 3) & 1) << 1)) << 3) + j;
     half[e] = hi;
     half[PC_HALF / 4 + e] = (__bf16)(x - (float)hi);
 }
 
-// W2 [256, 64] f32 -> two ring stages = four halves (layer-2 k-steps 4 q .. 4 q + 3), each [hi, lo][mt 2][ks 4][h 2]
-// [m 32][j 8]: the 16 bytes at (mt, ks, h, m) are W2[n][32 mt + m] for the 8 hidden units lane half h of layer-1
-// accumulator tile ks >> 1 holds in registers 8 (ks & 1) + j (as m2d_mlp_split_w2).
+// W2 [256, 64] f32 -> two ring stages = four halves; half q holds layer-2 steps s = 2 q, 2 q + 1 (32 hidden units each) as
+// [s & 1: 8 KiB][h2 tile mt (16 units): 2 KiB][hi 1 KiB | lo 1 KiB], a 1-KiB tile = 16 units x 64 B with the slots swizzled as
+// above.  The k-values of a step come in the order the layer-1 accumulators hold them: lane group g's fragment element j is
+// hidden unit 32 s + 16 (j >> 2) + 4 g + (j & 3) -- rows 4 g .. 4 g + 3 of accumulator tiles 2 s and 2 s + 1 -- so relu(acc1) is the
+// B operand with no lane movement.
 __global__ __launch_bounds__(256) void m2d_mlp_image_pc_w2(const float *w2, __bf16 *out)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;                   // [ks 16][mt 2][h 2][m 32][j 8]
+    const int t = blockIdx.x * 256 + threadIdx.x;                   // [s 8][mt 4][m 16][g 4][j 8]
     if (t >= MH1 * MH2) return;
-    const int j = t & 7, m = (t >> 3) & 31, hh = (t >> 8) & 1, mt = (t >> 9) & 1, ks = t >> 10;
-    const int n = 32 * (ks >> 1) + 16 * (ks & 1) + (j & 3) + 8 * (j >> 2) + 4 * hh;
-    const float x = w2[n * MH2 + 32 * mt + m];
+    const int j = t & 7, g = (t >> 3) & 3, m = (t >> 5) & 15, mt = (t >> 9) & 3, s = t >> 11;
+    const int n = 32 * s + 16 * (j >> 2) + 4 * g + (j & 3);
+    const float x = w2[n * MH2 + 16 * mt + m];
     const __bf16 hi = (__bf16)x;
-    __bf16 *half = out + (size_t)(ks >> 2) * (PC_HALF / 2);
-    const int e = mt * 2048 + (ks & 3) * 512 + hh * 256 + m * 8 + j;
+    __bf16 *half = out + (size_t)(s >> 1) * (PC_HALF / 2);
+    const int e = (s & 1) * 4096 + mt * 1024 + m * 32 + ((g ^ (((m >> 3) & 1) << 1)) << 3) + j;
     half[e] = hi;
-    half[2 * 2048 + e] = (__bf16)(x - (float)hi);
+    half[512 + e] = (__bf16)(x - (float)hi);
 }
 
 // ---- pairs grouped by dish mask pattern ------------------------------------------------------------------------
@@ -597,29 +602,6 @@ __device__ __forceinline__ void pc_wait_vmem()
 typedef float v2f_pc __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_pc __attribute__((ext_vector_type(2)));
 
-#ifndef M2D_MLP_SHAPE16
-#define M2D_MLP_SHAPE16 0
-#endif
-#ifndef M2D_MLP_NT_DISH
-#define M2D_MLP_NT_DISH 0
-#endif
-#if M2D_MLP_SHAPE16
-// (timing only) quarter 2 half + Q of a 32 x 32 accumulator as the C / D of one v_mfma_f32_16x16x32_bf16
-template <int Q>
-__device__ __forceinline__ void mlp_diag_mfma16(v16f &acc, const int half, const bf16x8 a, const bf16x8 b)
-{
-    if (half) {
-        v4f t = {acc[8 + 4 * Q], acc[9 + 4 * Q], acc[10 + 4 * Q], acc[11 + 4 * Q]};
-        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, t, 0, 0, 0);
-        acc[8 + 4 * Q] = t.x; acc[9 + 4 * Q] = t.y; acc[10 + 4 * Q] = t.z; acc[11 + 4 * Q] = t.w;
-    } else {
-        v4f t = {acc[4 * Q], acc[1 + 4 * Q], acc[2 + 4 * Q], acc[3 + 4 * Q]};
-        t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, t, 0, 0, 0);
-        acc[4 * Q] = t.x; acc[1 + 4 * Q] = t.y; acc[2 + 4 * Q] = t.z; acc[3 + 4 * Q] = t.w;
-    }
-}
-#endif
-
 template <int KCH>
 __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
 {
@@ -653,29 +635,36 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
 
     if (wave < 4) {
         // ======================================= consumer =======================================
-        const int pl = lane & 31, h = lane >> 5;
+        // v_mfma_f32_16x16x32_bf16: the wave's 256 hidden units x 32 pairs as 16 x 2 tiles of 16 x 16 (lane: column c = lane & 15,
+        // row group g = lane >> 4 -- an A / B fragment holds k = 8 g .. 8 g + 7 of a 32-deep step, a C / D tile rows 4 g .. 4 g + 3).
+        // Round 5: the head is the one kernel here that the chip clocks down (1.98 GHz on v_mfma_f32_32x32x16_bf16); this shape
+        // holds 2.13 GHz at the same output tile per wave, LDS reads and registers (MI355X_MICROARCH.md "DVFS give-back" 7).
+        const int c16 = lane & 15, g4 = lane >> 4;
 #if M2D_MLP_DIAG
         unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, n_t = 0, t0_ = 0, t1_;
 #endif
-        const unsigned a_off = pl * 32 + ((h ^ ((pl >> 3) & 1)) << 4);     // this lane's 16 B of a W1 row, tile 0
-        // z set: [blk = 2 k-step + h][k-values 0-3 | 4-7 of the lane's 8][pair slot ^ (2 blk + part)][16 B]
-        const unsigned z_off[2][2] = {{wave * 4096u + h * 1024 + ((pl ^ (2 * h)) << 4),
-                                       wave * 4096u + h * 1024 + 512 + ((pl ^ (2 * h + 1)) << 4)},
-                                      {wave * 4096u + (2 + h) * 1024 + ((pl ^ (4 + 2 * h)) << 4),
-                                       wave * 4096u + (2 + h) * 1024 + 512 + ((pl ^ (5 + 2 * h)) << 4)}};
-        const unsigned w2_off = (h * 32 + pl) * 16;
+        // this lane's 16 B of a W1 / W2 image row (16 rows x 64 B per 1-KiB tile; slot g swizzled by the row: see the image kernels)
+        const unsigned a_off = c16 * 64 + ((g4 ^ ((c16 >> 3) << 1)) << 4);
+        // z set: [blk = k-block of 8 = g][k-values 0-3 | 4-7 of the lane's 8][pair slot ^ (2 blk + part)][16 B]
+        unsigned z_off[2][2];                                             // [pair tile ct][part]
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+                z_off[ct][part] = wave * 4096u + g4 * 1024u + part * 512u + (((16 * ct + c16) ^ (2 * g4 + part)) << 4);
         unsigned hb = 0, zb = 0;                                          // half-buffer of this period's first half; z set
-        bf16x8 ah[4], al[4], bA[2][2], bB[2][2];                          // b?[k-step][hi, lo]
+        bf16x8 ah[4], al[4], bA[2][2], bB[2][2];                          // b?[pair tile][hi, lo]
         v4f zraw[4];
         auto hb_add = [](unsigned x, unsigned d) { const unsigned y = x + d; return y >= PC_NHB ? y - PC_NHB : y; };
+        // hidden tile nt (16 units) of a half (128 units): [hi: 8 tiles x 1 KiB | lo: the same]
         auto frag = [&](unsigned half_off, int nt, bf16x8 &fh, bf16x8 &fl) __attribute__((always_inline)) {
             const unsigned char *q = pcs + half_off + nt * 1024 + a_off;
             fh = *reinterpret_cast<const bf16x8 *>(q);
             fl = *reinterpret_cast<const bf16x8 *>(q + PC_HALF / 2);
         };
-        // chunk c = 2 k-step + part: 4 of the next period's z values -> their place in the split B operand
-        auto split = [&](int c, bf16x8 (&nb)[2][2]) __attribute__((always_inline)) {
-            const v4f zz = zraw[c];
+        // chunk ch = 2 ct + part: 4 of the next period's z values -> their place in the split B operand of pair tile ct
+        auto split = [&](int ch, bf16x8 (&nb)[2][2]) __attribute__((always_inline)) {
+            const v4f zz = zraw[ch];
             const v2f_pc z01 = {zz.x, zz.y}, z23 = {zz.z, zz.w};
             const uint32_t h01 = __builtin_bit_cast(uint32_t, __builtin_convertvector(z01, bf16x2_pc));
             const uint32_t h23 = __builtin_bit_cast(uint32_t, __builtin_convertvector(z23, bf16x2_pc));
@@ -683,18 +672,19 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
             const v2f_pc f23 = {__builtin_bit_cast(float, h23 << 16), __builtin_bit_cast(float, h23 & 0xffff0000u)};
             const bf16x2_pc l01 = __builtin_convertvector(z01 - f01, bf16x2_pc), l23 = __builtin_convertvector(z23 - f23, bf16x2_pc);
             const bf16x2_pc g01 = __builtin_bit_cast(bf16x2_pc, h01), g23 = __builtin_bit_cast(bf16x2_pc, h23);
-            const int ks = c >> 1, o = 4 * (c & 1);
-            nb[ks][0][o] = g01.x; nb[ks][0][o + 1] = g01.y; nb[ks][0][o + 2] = g23.x; nb[ks][0][o + 3] = g23.y;
-            nb[ks][1][o] = l01.x; nb[ks][1][o + 1] = l01.y; nb[ks][1][o + 2] = l23.x; nb[ks][1][o + 3] = l23.y;
+            const int ct = ch >> 1, o = 4 * (ch & 1);
+            nb[ct][0][o] = g01.x; nb[ct][0][o + 1] = g01.y; nb[ct][0][o + 2] = g23.x; nb[ct][0][o + 3] = g23.y;
+            nb[ct][1][o] = l01.x; nb[ct][1][o + 1] = l01.y; nb[ct][1][o + 2] = l23.x; nb[ct][1][o + 3] = l23.y;
         };
         auto zread = [&](unsigned zset) __attribute__((always_inline)) {
             const unsigned char *q = pcs + PC_Z_OFF + zset * PC_ZSET;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) zraw[c] = *reinterpret_cast<const v4f *>(q + z_off[c >> 1][c & 1]);
+            for (int ch = 0; ch < 4; ++ch) zraw[ch] = *reinterpret_cast<const v4f *>(q + z_off[ch >> 1][ch & 1]);
         };
-        v16f acc1[8];
-        // one layer-1 period: 2 k-steps x 8 hidden tiles x 3 MFMAs; fragments two steps ahead (4 register sets), the
-        // barrier after the first k-step, the NEXT period's operands read and split under the last steps
+        v4f acc1[16][2];                                                  // [hidden tile][pair tile]
+        // one layer-1 period (32 k-values = one MFMA step): 16 hidden tiles x 2 pair tiles x 3 MFMAs; fragments two tiles ahead
+        // (4 register sets), the barrier after the first half's 8 tiles (hidden units 0 .. 127: that half-stage is then done with),
+        // the NEXT period's operands read and split under the last tiles
         auto period = [&](bf16x8 (&b)[2][2], bf16x8 (&nb)[2][2]) __attribute__((always_inline)) {
             const unsigned h0 = hb * PC_HALF, h1 = hb_add(hb, 1) * PC_HALF, h2 = hb_add(hb, 2) * PC_HALF;
 #pragma unroll
@@ -705,30 +695,20 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
                 frag(jt < 8 ? h0 : jt < 16 ? h1 : h2, jt & 7, ah[jt & 3], al[jt & 3]);
                 if (it == 10) zread(zb ^ 1);
                 if (it >= 12) split(it - 12, nb);
-                const int nt = it & 7, ksl = it >> 3;
                 if (M2D_MLP_DIAG & 512) {                                  // diag bit 9 (timing only): LDS reads and the split, no MFMA
-                    asm volatile("" ::"v"(ah[it & 3]), "v"(al[it & 3]), "v"(b[ksl][0]), "v"(b[ksl][1]));
-                    if (M2D_MLP_DIAG & 1024) {                             // + bit 10: idle for about the three MFMAs' wall time
+                    asm volatile("" ::"v"(ah[it & 3]), "v"(al[it & 3]), "v"(b[0][0]), "v"(b[0][1]), "v"(b[1][0]), "v"(b[1][1]));
+                    if (M2D_MLP_DIAG & 1024) {                             // + bit 10: idle for about the six MFMAs' wall time
                         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7");
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     continue;
                 }
-#if M2D_MLP_SHAPE16
-                // TIMING ONLY (wrong scores; scripts/diag/mlp_diag.cpp): the step's flops as six v_mfma_f32_16x16x32_bf16 on quarters of
-                // the same accumulator -- the 2 x 2 arrangement of 16 x 16 tiles over this step's 32 hidden units x 32 pairs, every
-                // fragment feeding two MFMAs as it would (same LDS reads, same registers) -- to read the clock the chip holds on that shape
-                mlp_diag_mfma16<0>(acc1[nt], ksl, al[it & 3], b[ksl][0]);
-                mlp_diag_mfma16<0>(acc1[nt], ksl, ah[it & 3], b[ksl][1]);
-                mlp_diag_mfma16<0>(acc1[nt], ksl, ah[it & 3], b[ksl][0]);
-                mlp_diag_mfma16<1>(acc1[nt], ksl, ah[it & 3], b[ksl][1]);      // (another order: identical chains would be merged)
-                mlp_diag_mfma16<1>(acc1[nt], ksl, ah[it & 3], b[ksl][0]);
-                mlp_diag_mfma16<1>(acc1[nt], ksl, al[it & 3], b[ksl][0]);
-#else
-                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[it & 3], b[ksl][0], acc1[nt], 0, 0, 0);
-                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[it & 3], b[ksl][1], acc1[nt], 0, 0, 0);
-                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[it & 3], b[ksl][0], acc1[nt], 0, 0, 0);
-#endif
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    acc1[it][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[it & 3], b[ct][0], acc1[it][ct], 0, 0, 0);
+                    acc1[it][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[it & 3], b[ct][1], acc1[it][ct], 0, 0, 0);
+                    acc1[it][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[it & 3], b[ct][0], acc1[it][ct], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             hb = hb_add(hb, 2);
@@ -744,58 +724,61 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
         frag(0, 1, ah[1], al[1]);
         zread(0);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) split(c, bA);
+        for (int ch = 0; ch < 4; ++ch) split(ch, bA);
         for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-            // where this lane's score goes: requested now, needed after layer 3 (-1: a padding slot)
-            const int64_t slot = tile * PC_PAIRS + wave * 32 + pl;
-            const int32_t pi = p.perm ? p.perm[slot] : (slot < p.B ? (int32_t)slot : -1);
+            // where this lane's scores go (lanes 0-15: pairs c and 16 + c of the wave's 32): requested now, needed after layer 3
+            // (-1: a padding slot)
+            int32_t pi[2];
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt)
+            for (int ct = 0; ct < 2; ++ct) {
+                const int64_t slot = tile * PC_PAIRS + wave * 32 + 16 * ct + c16;
+                pi[ct] = p.perm ? p.perm[slot] : (slot < p.B ? (int32_t)slot : -1);
+            }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc1[nt][r] = sb1[hidden_unit<true>(nt, r, h)];
+            for (int nt = 0; nt < 16; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc1[nt][0][r] = acc1[nt][1][r] = sb1[16 * nt + 4 * g4 + r];
             const int nper = nper_of(tile_word(tile));                    // even (blocks of >= 2 periods, or every block)
 #pragma unroll 1
             for (int kc = 0; kc < nper / 2; ++kc) {
                 period(bA, bB);
                 period(bB, bA);
             }
-            // ---- layer 2: relu(acc1) split hi / lo is the B operand; W2 is ring stages NH and NH + 1 ----
+            // ---- layer 2: relu(acc1) split hi / lo is the B operand -- a step's 32 hidden units are accumulator tiles 2 s and
+            // 2 s + 1, rows 4 g .. 4 g + 3 of each (the W2 image holds its k-values in that order); W2 is ring stages NH, NH + 1 ----
             MACC(t_a);
-            v16f acc2[2];
+            v4f acc2[4][2];                                               // [h2 tile][pair tile]
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[mt][r] = sb2[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h];
+                for (int r = 0; r < 4; ++r) acc2[mt][0][r] = acc2[mt][1][r] = sb2[16 * mt + 4 * g4 + r];
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                if ((ks & 7) == 4) { MACC(t_c); pc_barrier(); MACC(t_b); }
-                bf16x8 bh, bl;
+            for (int s = 0; s < 8; ++s) {
+                if ((s & 3) == 2) { MACC(t_c); pc_barrier(); MACC(t_b); }
+                bf16x8 bh[2], bl[2];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float hv = fmaxf(acc1[ks >> 1][8 * (ks & 1) + j], 0.f);
-                    const __bf16 hi = (__bf16)hv;
-                    bh[j] = hi;
-                    bl[j] = (__bf16)(hv - (float)hi);
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float hv = fmaxf(acc1[2 * s + (j >> 2)][ct][j & 3], 0.f);
+                        const __bf16 hi = (__bf16)hv;
+                        bh[ct][j] = hi;
+                        bl[ct][j] = (__bf16)(hv - (float)hi);
+                    }
+                // half (s >> 1) & 1 of the stage: [step s & 1: 8 KiB][h2 tile mt: 2 KiB][hi 1 KiB | lo 1 KiB]
+                const unsigned char *img = pcs + hb_add(hb, (s >> 1) & 1) * PC_HALF + (s & 1) * 8192 + a_off;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const bf16x8 wh = *reinterpret_cast<const bf16x8 *>(img + mt * 2048);
+                    const bf16x8 wl = *reinterpret_cast<const bf16x8 *>(img + mt * 2048 + 1024);
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        acc2[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, bh[ct], acc2[mt][ct], 0, 0, 0);
+                        acc2[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bl[ct], acc2[mt][ct], 0, 0, 0);
+                        acc2[mt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, bh[ct], acc2[mt][ct], 0, 0, 0);
+                    }
                 }
-                const unsigned char *img = pcs + hb_add(hb, (ks >> 2) & 1) * PC_HALF + (ks & 3) * 1024 + w2_off;
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const bf16x8 wh = *reinterpret_cast<const bf16x8 *>(img + mt * 4096);
-                    const bf16x8 wl = *reinterpret_cast<const bf16x8 *>(img + (2 + mt) * 4096);
-#if M2D_MLP_SHAPE16
-                    mlp_diag_mfma16<0>(acc2[mt], ks & 1, wl, bh);
-                    mlp_diag_mfma16<0>(acc2[mt], ks & 1, wh, bl);
-                    mlp_diag_mfma16<0>(acc2[mt], ks & 1, wh, bh);
-                    mlp_diag_mfma16<1>(acc2[mt], ks & 1, wh, bl);
-                    mlp_diag_mfma16<1>(acc2[mt], ks & 1, wh, bh);
-                    mlp_diag_mfma16<1>(acc2[mt], ks & 1, wl, bh);
-#else
-                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bh, acc2[mt], 0, 0, 0);
-                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bl, acc2[mt], 0, 0, 0);
-                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc2[mt], 0, 0, 0);
-#endif
-                }
-                if ((ks & 7) == 7) { hb = hb_add(hb, 2); zb ^= 1; }
+                if ((s & 3) == 3) { hb = hb_add(hb, 2); zb ^= 1; }
             }
             // the next tile's period 0 was published by the last barrier
             MACC(t_c);
@@ -803,16 +786,19 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
             frag(hb * PC_HALF, 1, ah[1], al[1]);
             zread(zb);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) split(c, bA);
+            for (int ch = 0; ch < 4; ++ch) split(ch, bA);
             // ---- layer 3 and the reference score (summed by the producer; NaN there = an id was out of range) ----
-            float o = 0.f;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int ct = 0; ct < 2; ++ct) {
+                float o = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    o = fmaf(sw3[32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h], fmaxf(acc2[mt][r], 0.f), o);
-            o += __shfl_xor(o, 32, 64);
-            if (h == 0 && pi >= 0) p.out[pi] = sbase[tpar * 128 + wave * 32 + pl] + (o + p.b3);
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o = fmaf(sw3[16 * mt + 4 * g4 + r], fmaxf(acc2[mt][ct][r], 0.f), o);
+                o += __shfl_xor(o, 16, 64);
+                o += __shfl_xor(o, 32, 64);
+                if (g4 == 0 && pi[ct] >= 0) p.out[pi[ct]] = sbase[tpar * 128 + wave * 32 + 16 * ct + c16] + (o + p.b3);
+            }
             tpar ^= 1;
 #if M2D_MLP_DIAG
             MACC(t_d); ++n_t;
@@ -944,11 +930,7 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
                 // user rows are read about once per batch: non-temporal, so they do not push the dish vectors (each
                 // read ~10 times) out of L2 / the Infinity Cache
                 ra[set][i] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(bu + (uint64_t)ou * 16));
-#if M2D_MLP_NT_DISH
-                rb_[set][i] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(bd + (uint64_t)od * 16));      // (A/B, scripts/diag)
-#else
                 rb_[set][i] = *reinterpret_cast<const v4f *>(bd + (uint64_t)od * 16);
-#endif
                 __builtin_amdgcn_sched_barrier(0);                        // one pair of addresses live at a time
             }
         };
