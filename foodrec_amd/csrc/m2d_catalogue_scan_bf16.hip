@@ -562,10 +562,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
         }
     };
 
-    // the interleaved body: M(q-1) into accN, L(q), the compares + max tree of tile q-2 (accP), and -- INS -- the
-    // parked insertion, slot ranges from the end of the list up, one range per k-step group
+    // the interleaved body: M(q-1) into accN, L(q), the max tree of tile q-2 (accP), and -- INS -- the parked insertion,
+    // slot ranges from the end of the list up, one range per k-step group
     auto body = [&](auto ins_tag, v16f (&accN)[G], const v16f (&accP)[G], const int img_prev, const int img_off,
-                    const float (&thr_rel)[G], unsigned long long (&m)[G][16], float (&mx)[G]) __attribute__((always_inline)) {
+                    float (&mx)[G]) __attribute__((always_inline)) {
         constexpr bool INS = decltype(ins_tag)::value;
         constexpr bool PIN = WAVES == 4;
         float x[G], old_last[G];
@@ -576,17 +576,6 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
             mx[g] = -INFINITY;
             old_last[g] = rs[g][KR - 1];
             old_id[g] = ri[g][KR - 1];
-        }
-        // As common code of the two bodies (with / without the parked insertion) the sixteen compares are hoisted in front
-        // of the branch, ahead of the first MFMA.  Blocks of four waves: an opaque copy of the threshold per body keeps them
-        // where they are written, in the issue slots between this body's MFMAs (pruned call at 100 k dishes 0.591 -> 0.581 ms).
-        // Blocks of eight waves are better off with the hoisted form (every-tile scan 2.516 against 2.527 ms, 1 M dishes
-        // 20.30 against 20.51).
-        float tr[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            tr[g] = thr_rel[g];
-            if constexpr (WAVES == 4) asm volatile("" : "+v"(tr[g]));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -618,10 +607,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
 #pragma unroll
             for (int g = 0; g < G; ++g) {
 #pragma unroll
-                for (int r = ks * RPK; r < (ks + 1) * RPK; ++r) {
-                    m[g][r] = __ballot(accP[g][r] >= tr[g]);           // one v_cmp into an SGPR pair; folded into a
-                    mx[g] = fmaxf(mx[g], accP[g][r]);                  // per-lane row map only if some lane has a candidate
-                }
+                for (int r = ks * RPK; r < (ks + 1) * RPK; ++r) mx[g] = fmaxf(mx[g], accP[g][r]);      // the tile's maximum per lane: one
+                                                                       // compare of it against the threshold settles most tiles (below)
                 if (PIN && INS) asm volatile("" : "+v"(mx[g]));
                 if constexpr (INS) {
                     // slots [lo, hi) of the list, highest ranges first
@@ -782,8 +769,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
         const int img_prev = (int)((((q - 1) / TPS) & 1) * STAGE_BYTES + ((q - 1) & (TPS - 1)) * TILE_BYTES) + lane_off;
         unsigned long long m[G][16];                       // lane masks: row r of tile q-2 beats the lane's threshold
         float mx[G];
-        if (pend) body(std::true_type{}, accN, accP, img_prev, img_off, thr_rel, m, mx);
-        else body(std::false_type{}, accN, accP, img_prev, img_off, thr_rel, m, mx);
+        if (pend) body(std::true_type{}, accN, accP, img_prev, img_off, mx);
+        else body(std::false_type{}, accN, accP, img_prev, img_off, mx);
         if (nvalid < 32) {                                 // a group's last tile, or a dummy tile: padding rows never rank
 #pragma unroll
             for (int g = 0; g < G; ++g) {
@@ -800,13 +787,22 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
 #endif
         pend = false;
 #if M2D_DIAG & 8
-        asm volatile("" ::"s"(anyc), "s"(m[0][0] | m[0][5] | m[0][10] | m[0][15]), "v"(mx[0]), "v"(mx[G - 1]));
+        asm volatile("" ::"s"(anyc), "v"(mx[0]), "v"(mx[G - 1]));
 #endif
         if ((M2D_DIAG & 8) ? false : anyc != 0ull) {       // some lane of tile q-2 beat its threshold
             const int pt2 = ((q - 2) / TPS == q / TPS ? ps_0 : ps_m1) * TPS + (int)((q - 2) & (TPS - 1));   // physical tile of tile q - 2
             const int32_t sbase = (int32_t)((t_begin + pt2) * 32) + 4 * h;
             // per-lane 16-bit map of candidate rows (bit 15 - r), built here -- in the quarter of the steps that have a
             // candidate -- from the sixteen lane masks: map = 2 map + mask bit, one v_addc each
+            // The sixteen lane masks "row r of the tile beats the lane's threshold" are worked out HERE, in the steps that have a
+            // candidate.  Through round 4 they were part of every step's body, four compares between the MFMAs of each k-step group:
+            // an MFMA leaves vector issue free three quarters of its time, but the body was short of exactly that -- 1 009 cycles per
+            // step and wave for 768 of the SIMD's two waves' matrix work -- and 85 % of an every-tile scan's steps have no candidate.
+            // Same masks, same lists; body 1 009 -> 910 cycles, every tile 2.38 -> 2.27 ms, pruned 0.508 -> 0.500 ms (round 5).
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m[g][r] = __ballot(accP[g][r] >= thr_rel[g]);
             uint32_t rowmap[G];
             bool cand[G];
             unsigned long long multi = 0ull;

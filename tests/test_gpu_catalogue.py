@@ -480,6 +480,8 @@ def test_high_level_only_blend(E, x3, nU):
     _check(eng, PM, RE, CE, cats, users_np[:40], k)
     s16, i16 = eng.topk_users(users[:64], 16); eng.check()    # k = 16, and a catalogue with fewer rankable dishes than k
     _assert_ids_are_the_oracles_where_clear(i16.cpu().numpy(), PM, RE, CE, cats, users_np[:64], 16, 1.0, gap=3e-6)
+    with pytest.raises(IndexError):                           # an id outside the shard is latched here as in the scan kernels
+        eng.topk_users(torch.tensor([3, U + 7], dtype=torch.int32, device="cuda"), k); eng.check()
     few = np.zeros_like(cats); few[[5, 17, 900], 1] = 1; few[[3, 40], 2] = 1
     eng.set_dish_categories(few)
     _check(eng, PM, RE, CE, few, users_np[:20], k)
