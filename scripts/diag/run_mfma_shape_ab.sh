@@ -3,10 +3,12 @@
 # v_mfma_f32_32x32x16_bf16 (what ships) against v_mfma_f32_16x16x32_bf16 on the same accumulator registers, same LDS reads, same
 # vector work (-DM2D_DIAG=256 / -DM2D_MLP_SHAPE16=1).  Wall time from unstamped builds, in-kernel clock (s_memtime / s_memrealtime)
 # from stamped ones; the two shapes alternate on one GPU.  Output: gpurun_out/r05/shape_ab.txt
+# The MLP half (-DM2D_MLP_SHAPE16) exists at commit 64ea750 only: the consumers have run on 16x16x32 for real since 94a2c20
+# (profiles/r05_mfma_shape_ab.txt keeps that commit's record); at today's code ONLY=retrieval is the part that still means something.
 set -o pipefail
 OUT=gpurun_out/r05; mkdir -p $OUT/diag
 CC="/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-fast-math -Wno-inline-asm -Wno-unused-value"
-ONLY=${ONLY:-both}        # retrieval | mlp | both
+ONLY=${ONLY:-retrieval}   # retrieval | mlp | both (mlp: at commit 64ea750)
 if [ $ONLY != mlp ]; then for M in 0 256 16 272; do $CC -DM2D_DIAG=$M scripts/diag/topk_diag.cpp -o $OUT/diag/topk_$M 2> $OUT/diag/build_topk_$M.log & done; fi
 $CC -DM2D_MLP_SHAPE16=0 scripts/diag/mlp_diag.cpp -o $OUT/diag/mlp_s0 2> $OUT/diag/build_mlp_s0.log &
 $CC -DM2D_MLP_SHAPE16=1 scripts/diag/mlp_diag.cpp -o $OUT/diag/mlp_s1 2> $OUT/diag/build_mlp_s1.log &
