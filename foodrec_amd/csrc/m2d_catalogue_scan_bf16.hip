@@ -431,7 +431,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
             last_end = s1;
         }
     }
-    const int64_t n = (int64_t)vstages * TPS;                       // tiles the steps below go through ("virtual" tiles 0 .. n - 1)
+    const int n = vstages * TPS;                                    // tiles the steps below go through ("virtual" tiles 0 .. n - 1)
     // walker over the ranges: the physical stage of the next virtual stage (beyond the last: a stage number no range holds)
     int w_idx = -1, w_stage = 0, w_left = 0;
     auto next_stage = [&]() __attribute__((always_inline)) {
@@ -634,14 +634,49 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
         }
     };
 
-    auto step = [&](v16f (&accN)[G], v16f (&accP)[G], const int64_t q) __attribute__((always_inline)) {
+    // Plain steps.  Most steps of a scan multiply a full tile of the pattern the operands were built for, well inside the block's
+    // range: for those, what a step does between two bodies besides the stage's DMA pieces -- the group walk, the pattern test,
+    // the range checks, the threshold arithmetic -- repeats the previous step's answers.  A general step therefore also counts
+    // how many of its stage's following steps are plain (`plain_left`); those go from the DMA issue straight to the body, and the
+    // relative thresholds are kept and redone only after something moved a threshold or alpha (`thr_dirty`).  Round 5, one GPU,
+    // versions alternating: every tile 2.253 -> 2.205 ms, pruned 0.506 -> 0.500 ms, 1 M dishes 19.35 -> 19.0 / 2.77 -> 2.74 ms.
+    // That is all there is in that section: with the compare and the thresholds moved into the body's gaps and the stage's
+    // pieces issued in one burst (or inside the body) the every-tile form gained another 1 % and the pruned one lost 3 % (not
+    // kept; DESIGN_LABBOOK.md section C).  The timing-only build without the section (-DM2D_DIAG=1024: 1.36 ms) is fast for other
+    // reasons: no candidates, and operands that are constants -- the part holds 2.39 GHz on those and 2.0-2.15 GHz on real rows.
+    int plain_left = 0;
+    bool thr_dirty = true;                                 // wave-uniform
+    float thr_rel[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) thr_rel[g] = INFINITY;
+
+#if M2D_DIAG & 4096
+    // (diagnostic) time line of workgroup (0, 0)'s first steps: p.dbg + 7 000 000 + ((wave * 512 + q) * 4 + {0: step start, 1: body start,
+    // 2: body end, 3: step end}), s_memtime; scripts/diag/topk_diag.cpp prints two SIMD-mates side by side
+    const bool trace_me = p.dbg && bx == 0 && by == 0;
+#define TRACE(q_, k_) do { if (trace_me && (q_) < 512) { unsigned long long tt_; STAMP(tt_); if (lane == 0) p.dbg[7000000 + (((size_t)wave * 512 + (q_)) * 4 + (k_))] = tt_; } } while (0)
+#else
+#define TRACE(q_, k_)
+#endif
+    auto step = [&](v16f (&accN)[G], v16f (&accP)[G], const int q) __attribute__((always_inline)) {
 #if M2D_DIAG & 16
         STAMP(t0_);
 #endif
-        const int sub = (int)(q & (TPS - 1));
+        TRACE(q, 0);
+        const int sub = q & (TPS - 1);
         if (sub == 0) {                                    // tile q opens stage q / TPS: it must have landed, for every wave
+#if (M2D_DIAG & 528) == 528
+            unsigned long long s0_, s1_, s2_;              // (diagnostic 512: the stage wait apart from the barrier, in the slots of body / slow path)
+            STAMP(s0_);
+            wait_all_vmem();
+            STAMP(s1_);
+            __syncthreads();
+            STAMP(s2_);
+            t_body += s1_ - s0_; t_slow += s2_ - s1_; ++n_slow;
+#else
             wait_all_vmem();
             __syncthreads();                               // also: every wave is done reading the buffer refilled next
+#endif
             ps_m1 = ps_0;
             ps_0 = ps_p1;
             ps_p1 = next_stage();
@@ -657,15 +692,31 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
             // before any wave goes on to the steps that refill that region.
             asm volatile("s_barrier" ::: "memory");
         }
-        if (sub < TPS - 1) issue_pieces(ps_p1, (int)(q / TPS + 1), sub * PCNT, PCNT);
+        if (sub < TPS - 1) issue_pieces(ps_p1, q / TPS + 1, sub * PCNT, PCNT);
 #if M2D_DIAG & 16
         STAMP(t1_); t_bar += t1_ - t0_; t0_ = t1_;
 #endif
+#if M2D_DIAG & 1024
+        {   // TIMING ONLY (wrong lists): a step reduced to the stage barrier, the DMA pieces and the interleaved body -- no group walk,
+            // no threshold arithmetic, no candidate test -- to read what everything between two bodies costs a scan
+            const int img_off_ = (int)(((q / TPS) & 1) * STAGE_BYTES + sub * TILE_BYTES) + lane_off;
+            const int img_prev_ = (int)((((q - 1) / TPS) & 1) * STAGE_BYTES + ((q - 1) & (TPS - 1)) * TILE_BYTES) + lane_off;
+            float mx_[G];
+            body(std::false_type{}, accN, accP, img_prev_, img_off_, mx_);
+#pragma unroll
+            for (int g = 0; g < G; ++g) asm volatile("" ::"v"(mx_[g]));
+            return;
+        }
+#endif
 #pragma unroll
         for (int g = 0; g < G; ++g) alpha_prev[g] = alpha[g];   // tile q-2 was multiplied under the previous step's alpha
-        int nvalid = 0;
+        int nvalid = 32;
+        const bool plain = (M2D_DIAG & 2048) ? false : plain_left > 0;
+        if (plain) --plain_left;
+        else {
+        nvalid = 0;
         // physical tile of virtual tile q - 1 (the one being multiplied): its stage is v or v - 1
-        const int pt1 = ((q - 1) / TPS == q / TPS ? ps_0 : ps_m1) * TPS + (int)((q - 1) & (TPS - 1));
+        const int pt1 = ((q - 1) / TPS == q / TPS ? ps_0 : ps_m1) * TPS + ((q - 1) & (TPS - 1));
         if (q - 1 < n && pt1 < n_phys) {
             const int64_t t = t_begin + pt1;
             while (t >= g_end) {                            // next non-empty group (scalar; at most 15 times per block)
@@ -754,23 +805,41 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                     }
                 }
             }
+            if (nvalid == 32) {
+                // the steps of this stage after this one multiply tiles pt_next, pt_next + 1, ... of the stage ps_0: plain as long
+                // as they are full tiles of this group, inside the dish range and inside the steps' count
+                const int pt_next = sub == 0 ? ps_0 * TPS : pt1 + 1;
+                const int64_t full = g_beg + (g_tot >> 5) - (t_begin + pt_next);
+                int c = TPS - 1 - sub;
+                c = full < c ? (int)full : c;
+                c = n_phys - pt_next < c ? n_phys - pt_next : c;
+                c = n - q < c ? n - q : c;
+                plain_left = c > 0 ? c : 0;
+            }
+        }
         }
         // accumulators carry no alpha: compare against thr - alpha -- less the two roundings between `acc >= thr - alpha` and
         // `acc + alpha >= thr` (the sum is quantised at ulp(alpha), many ulps of acc under the 0.99 : 0.01 blend), so that every
         // score whose TOTAL reaches thr gets to the insertion, which compares totals: an equal total refused here would be a
         // tie nobody records (seen as a tie-listed user that one split count listed and another did not)
-        float thr_rel[G];
+        // (kept from step to step; redone after a general step -- alpha_prev follows alpha one step late, so also in the step after
+        //  one -- and after anything that moved a threshold: an insertion, the exchange at a stage's start)
+        if (thr_dirty || !plain) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const float d = thr[g] - alpha_prev[g];
-            thr_rel[g] = d - 2.4e-7f * (fabsf(thr[g]) + fabsf(alpha_prev[g])) - dlt2[g];   // 2^-22 (|thr| + |alpha|); thr = +inf: NaN, no candidate
+            for (int g = 0; g < G; ++g) {
+                const float d = thr[g] - alpha_prev[g];
+                thr_rel[g] = d - 2.4e-7f * (fabsf(thr[g]) + fabsf(alpha_prev[g])) - dlt2[g];   // 2^-22 (|thr| + |alpha|); thr = +inf: NaN, no candidate
+            }
         }
-        const int img_off = (int)(((q / TPS) & 1) * STAGE_BYTES + sub * TILE_BYTES) + lane_off;   // tile q
-        const int img_prev = (int)((((q - 1) / TPS) & 1) * STAGE_BYTES + ((q - 1) & (TPS - 1)) * TILE_BYTES) + lane_off;
+        thr_dirty = !plain || pend;                        // pend: this step's body inserts, and ends on share_threshold
+        const int img_off = (((q / TPS) & 1) * STAGE_BYTES + sub * TILE_BYTES) + lane_off;   // tile q
+        const int img_prev = ((((q - 1) / TPS) & 1) * STAGE_BYTES + ((q - 1) & (TPS - 1)) * TILE_BYTES) + lane_off;
         unsigned long long m[G][16];                       // lane masks: row r of tile q-2 beats the lane's threshold
         float mx[G];
+        TRACE(q, 1);
         if (pend) body(std::true_type{}, accN, accP, img_prev, img_off, mx);
         else body(std::false_type{}, accN, accP, img_prev, img_off, mx);
+        TRACE(q, 2);
         if (nvalid < 32) {                                 // a group's last tile, or a dummy tile: padding rows never rank
 #pragma unroll
             for (int g = 0; g < G; ++g) {
@@ -783,14 +852,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
 #pragma unroll
         for (int g = 0; g < G; ++g) anyc |= __ballot(mx[g] >= thr_rel[g]);
 #if M2D_DIAG & 16
-        STAMP(t1_); t_body += t1_ - t0_; t0_ = t1_; ++n_step;
+        STAMP(t1_); if (!(M2D_DIAG & 512)) t_body += t1_ - t0_; t0_ = t1_; ++n_step;
 #endif
         pend = false;
 #if M2D_DIAG & 8
         asm volatile("" ::"s"(anyc), "v"(mx[0]), "v"(mx[G - 1]));
 #endif
         if ((M2D_DIAG & 8) ? false : anyc != 0ull) {       // some lane of tile q-2 beat its threshold
-            const int pt2 = ((q - 2) / TPS == q / TPS ? ps_0 : ps_m1) * TPS + (int)((q - 2) & (TPS - 1));   // physical tile of tile q - 2
+            const int pt2 = ((q - 2) / TPS == q / TPS ? ps_0 : ps_m1) * TPS + ((q - 2) & (TPS - 1));   // physical tile of tile q - 2
             const int32_t sbase = (int32_t)((t_begin + pt2) * 32) + 4 * h;
             // per-lane 16-bit map of candidate rows (bit 15 - r), built here -- in the quarter of the steps that have a
             // candidate -- from the sixteen lane masks: map = 2 map + mask bit, one v_addc each
@@ -892,19 +961,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                     }
                     share_threshold(g);
                 }
+                thr_dirty = true;
 #if M2D_DIAG & 16
                 ++n_ins;
 #endif
             }
 #if M2D_DIAG & 16
             asm volatile("" ::"v"(thr[0]), "v"(px[0]));
-            STAMP(t1_); t_slow += t1_ - t0_; ++n_slow;
+            STAMP(t1_); if (!(M2D_DIAG & 512)) { t_slow += t1_ - t0_; ++n_slow; }
             if (q <= TPS + 2) { t_slow_first += t1_ - t0_; ++n_slow_first; }
 #endif
         }
+        TRACE(q, 3);
     };
 
-    for (int64_t q = 1; q <= n + 1 && n > 0; q += 2) {
+    for (int q = 1; q <= n + 1 && n > 0; q += 2) {
         step(acc0, acc1, q);
         step(acc1, acc0, q + 1);
     }

@@ -17,7 +17,7 @@ int m2d_ensure_finite_scan(m2d_engine *, hipStream_t) { return M2D_OK; }   // (m
 
 int main(int argc, char **argv)
 {
-    const int64_t U = 65536, I = 100000;
+    const int64_t U = getenv("M2D_DIAG_USERS") ? atoll(getenv("M2D_DIAG_USERS")) : 65536, I = getenv("M2D_DIAG_DISHES") ? atoll(getenv("M2D_DIAG_DISHES")) : 100000;
     const int C = 4, E = 64, k = 10;
     m2d_engine h;
     h.U = U; h.I = I; h.C = C; h.E = E; h.a = 0.99f; h.b = 1.0f - 0.99f;
@@ -50,7 +50,7 @@ int main(int argc, char **argv)
     hipMemcpy(users, hu.data(), U * 4, hipMemcpyHostToDevice);
     h.pm = dpm; h.re = dre; h.ce = dce; h.dish_cats = dcats;
 #if M2D_DIAG & 16
-    unsigned long long *dbg; hipMalloc(&dbg, 65536 * 8 * 8); hipMemset(dbg, 0, 65536 * 8 * 8);
+    unsigned long long *dbg; hipMalloc(&dbg, (size_t)1048576 * 8 * 8); hipMemset(dbg, 0, (size_t)1048576 * 8 * 8);
     g_m2d_diag_buffer = dbg;
 #endif
     hipEvent_t e0, e1;
@@ -82,10 +82,10 @@ int main(int argc, char **argv)
     }
 #if M2D_DIAG & 16
     {
-        std::vector<unsigned long long> hd(65536 * 8);
+        std::vector<unsigned long long> hd((size_t)1048576 * 8);
         hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
         double m = 0, e = 0, b = 0, sl = 0, ns = 0, st = 0, ck = 0, rt = 0, nw = 0, maxck = 0;
-        for (int w = 0; w < 65536; ++w) { m += hd[w*8]; e += hd[w*8+1]; b += hd[w*8+2]; sl += hd[w*8+3]; ns += hd[w*8+4]; st += hd[w*8+5]; ck += hd[w*8+6]; rt += hd[w*8+7]; nw += hd[w*8+6] != 0; if ((double)hd[w*8+6] > maxck) maxck = (double)hd[w*8+6]; }
+        for (int w = 0; w < 1048576; ++w) { m += hd[w*8]; e += hd[w*8+1]; b += hd[w*8+2]; sl += hd[w*8+3]; ns += hd[w*8+4]; st += hd[w*8+5]; ck += hd[w*8+6]; rt += hd[w*8+7]; nw += hd[w*8+6] != 0; if ((double)hd[w*8+6] > maxck) maxck = (double)hd[w*8+6]; }
 #if M2D_DIAG & 32
         printf("first stage of an item (steps 1 .. 10): %.0f candidate steps per wave-item, %.0f cycles each; whole item: %.0f candidate steps, %.0f cycles each\n", e / nw, e ? rt / e : 0.0, ns / nw, ns ? sl / ns : 0.0);
         rt = 0;
@@ -94,6 +94,21 @@ int main(int argc, char **argv)
         // pipelined bf16 kernel: d[0] = interleaved body, d[1] = sorted_insert calls, d[2] = stage wait + barrier, d[3] = slow path
         printf("per step per wave (cycles): body %.0f  slow path %.0f (%.1f%% of steps, %.0f each, %.2f inserts each)  wait+barrier %.0f  [%.0f steps/wave]\n",
                m / st, sl / st, 100.0 * ns / st, ns ? sl / ns : 0.0, ns ? e / ns : 0.0, b / st, st / (nw > 0 ? nw : 1));
+    }
+#endif
+#if M2D_DIAG & 4096
+    {   // time line of workgroup (0, 0): waves w and w + 4 share a SIMD (8-wave blocks)
+        std::vector<unsigned long long> tr(8 * 512 * 4);
+        hipMemcpy(tr.data(), dbg + 7000000, tr.size() * 8, hipMemcpyDeviceToHost);
+        const unsigned long long t00 = tr[(0 * 512 + 1) * 4];
+        const int q0 = getenv("M2D_TRACE_FROM") ? atoi(getenv("M2D_TRACE_FROM")) : 41;
+        for (int w : {0, 4}) {
+            printf("wave %d: step: start (+gap since the previous step's end) | pre-body  body  post\n", w);
+            for (int q = q0; q < q0 + 40; ++q) {
+                const unsigned long long *e = &tr[((size_t)w * 512 + q) * 4], *pe = &tr[((size_t)w * 512 + q - 1) * 4];
+                printf("  q %3d: %8lld (+%4lld) | %5lld %5lld %5lld\n", q, (long long)(e[0] - t00), (long long)(e[0] - pe[3]), (long long)(e[1] - e[0]), (long long)(e[2] - e[1]), (long long)(e[3] - e[2]));
+            }
+        }
     }
 #endif
     const double flops = 2.0 * K * (double)U * (double)I;
