@@ -331,6 +331,7 @@ def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10, ke
                           "scanned_fraction": (scanned / full if scanned and full else None),
                           "frac_if_every_tile_were_scanned": 3 * 2.0 * E * n_users * I / ms / 1e9 / 2500.0,
                           "dtype": "split bf16 (x = hi + lo, 3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
+                          **bare_loop_fields(3 * flops / ms / 1e9),
                           "note": "pipelined kernel; `frac` prices the flops EXECUTED: users are sorted by the mask patterns that "
                                   "can reach their top-k and a block steps through those patterns' tiles only (Cauchy-Schwarz bounds widened by the f32 / split-bf16 rounding of the sums of absolute terms; "
                                   "DESIGN.md 4.4), so most (user, dish) pairs are decided without being multiplied -- pairs_per_s "
@@ -576,6 +577,18 @@ def scaling_path_block(torch, dist, foodrec_amd, dev, world, rank, users_total, 
 
 
 XGMI_LINK_GBS = 153.0      # one xGMI link, per direction (7 links per GPU, point to point)
+# What the matrix pipe sustains on this part in a loop of nothing but v_mfma_f32_32x32x16_bf16 from registers, every CU, two waves
+# per SIMD (scripts/diag/mfma_chain_probe.cpp, profiles/r05_mfma_chain_probe.txt): the clock it holds depends on the operands.
+BARE_BF16_MFMA_LOOP = {"zero_operands_TFLOPs": 2460.0, "random_operands_TFLOPs": 1865.0,
+                       "source": "profiles/r05_mfma_chain_probe.txt: 2.38 GHz on zeros, 1.83 GHz on N(0, 1) bf16 operands; `peak` stays "
+                                 "the spec figure (2 500 at 2.4 GHz), these say how much of it a power-limited part can be asked for"}
+
+
+def bare_loop_fields(achieved_tflops):
+    return {"bare_mfma_loop": BARE_BF16_MFMA_LOOP,
+            "frac_of_bare_mfma_loop_random_operands": achieved_tflops / BARE_BF16_MFMA_LOOP["random_operands_TFLOPs"]}
+
+
 
 
 def projected_world8_block(torch, foodrec_amd, dev, users_total, I, E, k, topk_path_ms_n1, rounds=(262144, 0, 524288), repeats=3):
@@ -1239,6 +1252,8 @@ def main():
                                           % ("v_mfma_f32_16x16x32_bf16" if kernel_used.startswith("m2d_mlp_pc") else "v_mfma_f32_32x32x16_bf16")
                                           if x3 else "f32 (v_mfma_f32_32x32x2_f32, exact)"),
                                 "hbm_algorithmic_GBps": hbm, "hbm_frac": hbm / HBM_PEAK_GBS}
+            if x3:
+                line["roofline"].update(bare_loop_fields(ex))
             line["dtype"] = "bf16x3" if x3 else "f32"
             if not a.no_cpu_baseline and world == 1:
                 cb, ok = mlp_baseline(torch, PM, RE, CE, mlp_cats, mlp_head, users, items, user_base, mlp_sample, a.cpu_seconds)
@@ -1291,6 +1306,8 @@ def main():
                                         "decided by a bound, without being multiplied",
                                 "dtype": ("split bf16 (3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)" if x3 else
                                           "f32 (v_mfma_f32_32x32x2_f32, exact)")}
+            if x3:
+                line["roofline"].update(bare_loop_fields(tf))
             line["dtype"] = "bf16x3" if x3 else "f32"
             # "scored" is claimed only for the pairs that were multiplied: the tiles the blocks stepped through.  Every pair
             # of the catalogue is DECIDED (ranked or excluded by a bound) at the rate beside it.
