@@ -322,16 +322,21 @@ def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10, ke
         scanned, full = eng.get_option("topk_tiles_scanned"), eng.get_option("topk_tiles_full")
         if scanned > 0:
             flops = 2.0 * E * eng.get_option("topk_block_users") * 32 * scanned     # a block's user lanes (256, or 128) x a tile's 32 dishes
+    # split bf16: three products per tile -- or, the hi x hi first form (catalogues of more than 8 192 tiles), one product per tile
+    # and the two cross products for the (wave, tile) pairs that could still hold a candidate
+    completed = eng.get_option("topk_tiles_completed") if kernel.startswith("m2d_topk_grouped") else -1
+    ex3 = 3 * flops if completed < 0 else flops + 2 * (2.0 * E * 32 * 32 * completed)
     return {"users": n_users, "dishes": I, "k": k, "median_ms": ms, "users_per_s": n_users / ms * 1e3,
             "pairs_per_s": n_users * I / ms * 1e3, "tflops": flops / ms / 1e9,
             "dense_equivalent_tflops": dense / ms / 1e9,
-            "roofline": ({"bound": "mfma", "achieved": 3 * flops / ms / 1e9, "peak": 2500.0, "unit": "TFLOP/s",
-                          "frac": 3 * flops / ms / 1e9 / 2500.0, "flop_per_pair": 3 * flops / n_users / I,
+            "roofline": ({"bound": "mfma", "achieved": ex3 / ms / 1e9, "peak": 2500.0, "unit": "TFLOP/s",
+                          "frac": ex3 / ms / 1e9 / 2500.0, "flop_per_pair": ex3 / n_users / I,
+                          "hi_first_form": completed >= 0, "wave_tiles_given_cross_products": (completed if completed >= 0 else None),
                           "tiles_scanned": scanned, "tiles_without_pruning": full,
                           "scanned_fraction": (scanned / full if scanned and full else None),
                           "frac_if_every_tile_were_scanned": 3 * 2.0 * E * n_users * I / ms / 1e9 / 2500.0,
-                          "dtype": "split bf16 (x = hi + lo, 3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
-                          **bare_loop_fields(3 * flops / ms / 1e9),
+                          "dtype": ("split bf16 (x = hi + lo): hi x hi for every tile, lo x hi + hi x lo for the tiles that can hold a candidate (v_mfma_f32_32x32x16_bf16, fp32 accumulate)" if completed >= 0 else "split bf16 (x = hi + lo, 3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)"),
+                          **bare_loop_fields(ex3 / ms / 1e9),
                           "note": "pipelined kernel; `frac` prices the flops EXECUTED: users are sorted by the mask patterns that "
                                   "can reach their top-k and a block steps through those patterns' tiles only (Cauchy-Schwarz bounds widened by the f32 / split-bf16 rounding of the sums of absolute terms; "
                                   "DESIGN.md 4.4), so most (user, dish) pairs are decided without being multiplied -- pairs_per_s "
@@ -1284,6 +1289,14 @@ def main():
                     scanned_frac = sc_ / fu_
             tf_all = fl / (avg_ms * 1e-3) / 1e12
             tf = tf_all * (scanned_frac if scanned_frac is not None else 1.0)
+            # the hi x hi first form (E = 64, catalogues of more than 8 192 tiles): one product per tile stepped through, the two cross
+            # products for the share of (wave, tile) pairs that could still hold a candidate (the step's last launch stands for the step)
+            cross_share = None
+            if x3 and kernel_used.startswith("m2d_topk_grouped") and not a.topk_with_ingredients:
+                cmp_ = eng.get_option("topk_tiles_completed")
+                if cmp_ >= 0 and sc_ > 0:
+                    cross_share = cmp_ * 32.0 / (sc_ * eng.get_option("topk_block_users"))
+                    tf = tf / 3.0 * (1.0 + 2.0 * cross_share)
             peak = 2500.0 if x3 else 157.3
             line["config"]["workload"] = (("BASELINE configs[%d]: %d users over %d GPU(s) (%d per GPU) x %d replicated dishes, E=%d: "
                                            "full-catalogue top-10 for EVERY user of the shard in rounds of %d, then ONE all-gather of "
@@ -1298,13 +1311,16 @@ def main():
                 "the dense exact-f32 kernel contracts over (C + 1) E" if a.topk_weighted_masks else "") + (
                 " -- WITH the build-defined ingredient table (%d rows, 1-20 per dish)" % a.ingredients if a.topk_with_ingredients else "")
             line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
-                                "traffic": None, "step_avg_ms": avg_ms, "flop_per_pair_executed": fl / units,
+                                "traffic": None, "step_avg_ms": avg_ms, "flop_per_pair_executed": (fl / units if cross_share is None else fl / units / 3.0 * (1.0 + 2.0 * cross_share)),
                                 "dense_equivalent_tflops": 2.0 * K * units / (avg_ms * 1e-3) / 1e12,
                                 "scanned_fraction": scanned_frac, "frac_if_every_tile_were_scanned": tf_all / peak,
+                                "hi_first_form": cross_share is not None, "share_of_wave_tiles_given_cross_products": cross_share,
                                 "note": "`frac` prices the flops EXECUTED (the tiles the blocks stepped through), and `value` counts the pairs "
                                         "of those tiles; pairs_decided_per_s counts every (user, dish) pair of the catalogue -- most are "
                                         "decided by a bound, without being multiplied",
-                                "dtype": ("split bf16 (3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)" if x3 else
+                                "dtype": (("split bf16: hi x hi for every tile, lo x hi + hi x lo for the tiles that can hold a candidate "
+                                           "(v_mfma_f32_32x32x16_bf16, fp32 accumulate)" if cross_share is not None else
+                                           "split bf16 (3 x v_mfma_f32_32x32x16_bf16, fp32 accumulate)") if x3 else
                                           "f32 (v_mfma_f32_32x32x2_f32, exact)")}
             if x3:
                 line["roofline"].update(bare_loop_fields(tf))

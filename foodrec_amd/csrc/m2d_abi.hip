@@ -799,7 +799,7 @@ int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value)
         }
         *value = !strcmp(name, "topk_refined") ? c[0] : c[1];
     }
-    else if (!strcmp(name, "topk_tiles_scanned") || !strcmp(name, "topk_tiles_full")) {
+    else if (!strcmp(name, "topk_tiles_scanned") || !strcmp(name, "topk_tiles_full") || !strcmp(name, "topk_tiles_completed")) {
         // diagnostic (synchronises the device): 32-dish tiles the blocks of the last pipelined retrieval launch stepped
         // through, and what they would have stepped through without pattern pruning
         *value = 0;
@@ -809,8 +809,10 @@ int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value)
             if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
                 hipMemcpy(&v, h->topk_tiles_counter, sizeof v, hipMemcpyDeviceToHost) != hipSuccess)
                 return M2D_ERR_HIP;
-            *value = (int64_t)v;
+            // (bits 36 ..: the hi x hi first form's count of (wave, tile) pairs whose cross products were multiplied; -1: another form ran)
+            *value = !strcmp(name, "topk_tiles_completed") ? (h->topk_apx_last ? (int64_t)(v >> 36) : -1) : (int64_t)(v & ((1ull << 36) - 1));
         }
+        else if (!strcmp(name, "topk_tiles_completed")) *value = -1;
     }
     else if (!strcmp(name, "topk_grouped")) *value = h->opt_topk_grouped;
     else if (!strcmp(name, "mlp_bf16x3")) *value = h->opt_mlp_bf16x3;

@@ -117,6 +117,7 @@ struct ScanShape {
     bool pipe;       // split bf16: the pipelined form (else the first form)
     int waves;       // waves per block: 8 (256 users) or 4 (128 users; pipelined split bf16, E = 64)
     bool keep;       // the lists' left-out scores are kept for m2d_topk_refine (GroupedArgs::ex_out)
+    bool apx;        // pipelined split bf16, E = 64, 8 waves: hi x hi product first, cross products for the tiles with a candidate
 };
 
 // ---- launchers other units call (all enqueue on `st`; int results are M2D_* codes) ---------------------------------------------

@@ -746,7 +746,12 @@ int launch_grouped(m2d_engine *h, const int E8, const int KR, const bool BF16X3,
     const bool half_ok = BF16X3 && !HV && E == 64 && pipe;
     // (k > 10 with the left-out bookkeeping: 232 registers since the launch bounds say two waves per SIMD -- it took 261 and one
     //  wave per SIMD before, and the launcher kept eight-wave blocks for it: 65 536 users x 100 k dishes, k = 16: 0.764 -> 0.666 ms)
-    const bool half = half_ok && (h->opt_topk_block == 128 || (h->opt_topk_block == 0 && M2D_TOPK_HALF_BLOCKS && h->opt_topk_prune != 0 &&
+    // The hi x hi first form of that kernel (APX in m2d_catalogue_scan_bf16.hip) for the catalogues where a tile with a candidate is
+    // the exception: more than 8 192 tiles -- where blocks of 256 users are taken anyway.  The rule looks at the catalogue alone:
+    // that form's scores are not the three-product kernels' bits, and every launch shape of one problem must return the same lists
+    // ("topk_block" = 128 is therefore not honoured there).  "topk_form" 3 / 4 (diagnostic): that form for any catalogue / never.
+    const bool apx = half_ok && h->opt_topk_form != 4 && (h->grp_tiles > 8192 || h->opt_topk_form == 3);
+    const bool half = half_ok && !apx && (h->opt_topk_block == 128 || (h->opt_topk_block == 0 && M2D_TOPK_HALF_BLOCKS && h->opt_topk_prune != 0 &&
                                                               h->opt_variant < 100 && nU >= 16384 && h->grp_tiles <= 8192));
     const int WV = half ? 4 : WAVES;                         // waves per block
     const int TPS = grouped_tiles_per_stage(E) * WV / WAVES;
@@ -906,7 +911,8 @@ int launch_grouped(m2d_engine *h, const int E8, const int KR, const bool BF16X3,
     }
     const dim3 grid = a.items ? dim3((unsigned)(ublocks * nsplit)) : dim3((unsigned)ublocks, (unsigned)nsplit);
     {
-        const ScanShape shape{E, KR, BF16X3, HV, PAD, pipe, WV, a.ex_out != nullptr};
+        const ScanShape shape{E, KR, BF16X3, HV, PAD, pipe, WV, a.ex_out != nullptr, apx};
+        h->topk_apx_last = apx;
         const int rc = BF16X3 ? m2d_topk_scan_bf16_launch(h, a, shape, grid, lds, st) : m2d_topk_scan_f32_launch(h, a, shape, grid, lds, st);
         if (rc != M2D_OK) return rc;
     }

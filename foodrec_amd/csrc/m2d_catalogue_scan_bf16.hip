@@ -273,9 +273,17 @@ __device__ __forceinline__ void diag_mfma16(v16f &acc, const int ks, const bf16x
 }
 #endif
 
-template <int E, int KR, int G, bool HV = false, int WAVES = 8 / G, bool KEEP = false>
+// APX = true (E = 64, blocks of 256 users; launch_grouped takes it for catalogues of more than 8 192 tiles, where a tile with a
+// candidate is the exception): the body multiplies only the hi x hi product of a tile -- a third of the matrix work, half the LDS
+// reads -- and compares against the threshold LESS a bound of what the two cross products can add (eps = 2^-7 * 1.02 |w_P[u]| *
+// the pattern's largest row norm: |x - hi(x)| <= 2^-8 |x| for both operands, Cauchy-Schwarz); a tile that still has a candidate
+// gets its cross products then, from its rows still in LDS, and is handled from exact scores as before.  A score is
+// hi x hi + (lo x hi + hi x lo), each part accumulated on its own: not the bits of the three-product kernels, so the launcher's
+// choice depends on the catalogue alone -- every launch shape of one problem takes the same arithmetic (lists bit for bit).
+template <int E, int KR, int G, bool HV = false, int WAVES = 8 / G, bool KEEP = false, bool APX = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(GroupedArgs p)
 {
+    static_assert(!APX || (E == 64 && !HV && WAVES == 8 && G == 1), "the hi x hi first form: E = 64, blocks of eight waves");
     constexpr int C = 4;
     constexpr int KS = E / 16;                             // k-steps (16 k-values) per tile
     constexpr int S8 = E / 8;                              // 16-B slots per bf16 row
@@ -361,7 +369,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
     }
     // the block's patterns: the union over its users.  Tiles of every other pattern are not even fetched.
     __shared__ uint32_t s_umask;
+    __shared__ __align__(16) uint32_t s_prog[8];           // (APX) stages whose step "sub 1" wave w has finished, see issue of pieces 6 and 7
     if (threadIdx.x == 0) s_umask = 0u;
+    if (APX && threadIdx.x < 8) s_prog[threadIdx.x] = 0u;
     __syncthreads();
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) umask_lane |= __shfl_xor(umask_lane, off, 64);
@@ -377,6 +387,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
 
     bf16x8 wh[G][KS], wl[G][KS];                           // w_P[u] for k = 16 s + 8 h + (0..7), split hi / lo
     float alpha[G], alpha_prev[G];                         // alpha_P of the tile being multiplied / being compared
+    float eps[G], eps_prev[G];                             // (APX) what the cross products can add to a score of that tile, at most
     int cur_pat = -1;
     int gp = 0;                                            // group walk: pattern, its tile range and row count
     int64_t g_beg = 0, g_end = 0;
@@ -397,6 +408,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
         px[g] = -INFINITY;
         pid[g] = -1;
         alpha[g] = alpha_prev[g] = 0.f;
+        eps[g] = eps_prev[g] = 0.f;
     }
     bool pend = false;                                     // wave-uniform: some (px, pid) waits to be inserted
     unsigned long long tie_mask[G];                        // lanes with a tie event at their list's present last value (tie_update)
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
         for (int ks = 0; ks < AR; ++ks) {                  // the first AR k-steps of tile 0
             const unsigned char *a = smem8 + (lane_off ^ (ks << 5));
             ah[ks] = *reinterpret_cast<const bf16x8 *>(a);
-            al[ks] = *reinterpret_cast<const bf16x8 *>(a + 32 * ROW_BYTES);
+            if (!APX) al[ks] = *reinterpret_cast<const bf16x8 *>(a + 32 * ROW_BYTES);
         }
     }
 
@@ -595,15 +607,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                 diag_mfma16<1>(accN[g], ks, ah[st], wh[g][ks], false);
                 diag_mfma16<1>(accN[g], ks, al[st], wh[g][ks], false);
 #else
-                accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[st], wh[g][ks], ks == 0 ? zero16 : accN[g], 0, 0, 0);
-                accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], wl[g][ks], accN[g], 0, 0, 0);
-                accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], wh[g][ks], accN[g], 0, 0, 0);
+                if constexpr (APX) {
+                    accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], wh[g][ks], ks == 0 ? zero16 : accN[g], 0, 0, 0);
+                } else {
+                    accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[st], wh[g][ks], ks == 0 ? zero16 : accN[g], 0, 0, 0);
+                    accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], wl[g][ks], accN[g], 0, 0, 0);
+                    accN[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[st], wh[g][ks], accN[g], 0, 0, 0);
+                }
 #endif
             }
             // k-step ks + AR of this tile (q-1), or k-step ks + AR - KS of the next (q)
             const unsigned char *a = smem8 + (ks + AR < KS ? (img_prev ^ ((ks + AR) << 5)) : (img_off ^ ((ks + AR - KS) << 5)));
             ah[st] = *reinterpret_cast<const bf16x8 *>(a);
-            al[st] = *reinterpret_cast<const bf16x8 *>(a + 32 * ROW_BYTES);
+            if (!APX) al[st] = *reinterpret_cast<const bf16x8 *>(a + 32 * ROW_BYTES);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
 #pragma unroll
@@ -632,6 +648,57 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                 share_threshold(g);
             }
         }
+    };
+
+    // (APX) the cross products of tile qt, from its rows in LDS (hi and lo fragments read again), under the operands in registers --
+    // so before a pattern switch rebuilds those: a step that switches completes tile q - 2 first, candidate or not (`accP_exact`).
+    // Its own accumulator, added to the hi x hi one at the end: the same bits wherever the tile sits in a launch.
+    bool accP_exact = false;                               // wave-uniform
+    unsigned n_completed = 0;                              // (diagnostic) tiles this wave completed
+    auto complete = [&](v16f (&acc)[G], const int qt) __attribute__((always_inline)) {
+        if (qt < 0) return;
+        ++n_completed;
+        const int img2 = (((qt / TPS) & 1) * STAGE_BYTES + (qt & (TPS - 1)) * TILE_BYTES) + lane_off;
+        v16f x2[G];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const unsigned char *a2 = smem8 + (img2 ^ (ks << 5));
+            const bf16x8 h2 = *reinterpret_cast<const bf16x8 *>(a2), l2 = *reinterpret_cast<const bf16x8 *>(a2 + 32 * ROW_BYTES);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                x2[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l2, wh[g][ks], ks == 0 ? zero16 : x2[g], 0, 0, 0);
+                x2[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h2, wl[g][ks], x2[g], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) acc[g] += x2[g];
+    };
+    // (APX) Tile q - 2's rows must still be in LDS when a step completes it.  In a stage's steps "sub 0" and "sub 1" that tile is
+    // tile 6 / 7 of the PREVIOUS stage's buffer, which this stage's steps refill for the next one -- region r by piece r, pieces 6
+    // and 7 in step "sub 5".  A wave that is that far ahead of another would overwrite what that one is about to read.  So a
+    // wave says when it has finished its step "sub 1" (at the head of "sub 2": its LDS reads are carried out in order, the word
+    // after them), and reads everybody's word before it issues pieces 6 and 7 -- one wide LDS read per stage, met at once unless the
+    // block's waves are more than a step apart.  A wait that is never met gives up after 2^20 polls (error latched) rather than hang.
+    auto prog_signal = [&](const uint32_t v) __attribute__((always_inline)) {
+        asm volatile("" ::: "memory");
+        if (lane == 0) *((volatile __attribute__((address_space(3))) uint32_t *)s_prog + wave) = v;   // (LDS said so: a generic
+                                                                  // volatile pointer compiles to flat_*, which counts on vmcnt too)
+        asm volatile("" ::: "memory");
+    };
+    typedef int v4i_pg __attribute__((ext_vector_type(4)));
+    auto prog_wait = [&](const int32_t target) __attribute__((always_inline)) {
+        volatile __attribute__((address_space(3))) v4i_pg *w = (volatile __attribute__((address_space(3))) v4i_pg *)s_prog;
+        for (int spin = 0;; ++spin) {
+            const v4i_pg v0 = w[0], v1 = w[1];
+            const int d = __builtin_amdgcn_readfirstlane(min(min(min(v0.x, v0.y), min(v0.z, v0.w)), min(min(v1.x, v1.y), min(v1.z, v1.w))) - target);
+            if (d >= 0) break;
+            if (spin > (1 << 20)) {
+                if (lane == 0 && atomicCAS(&p.err[0], 0, M2D_ERR_HIP) == 0) { p.err[1] = 0x5bad; p.err[2] = target; p.err[3] = 0; }
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        asm volatile("" ::: "memory");
     };
 
     // Plain steps.  Most steps of a scan multiply a full tile of the pattern the operands were built for, well inside the block's
@@ -692,7 +759,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
             // before any wave goes on to the steps that refill that region.
             asm volatile("s_barrier" ::: "memory");
         }
-        if (sub < TPS - 1) issue_pieces(ps_p1, q / TPS + 1, sub * PCNT, PCNT);
+        if constexpr (APX) {
+            static_assert(!APX || (TPS == 8 && PCNT == 2 && PPW == 8), "pieces 6 and 7 = regions 6 and 7");
+            // pieces 0 .. 5 in steps sub 0 .. 2 as ever; 6 and 7 in step sub 5, behind the look at the others' words: by then a wave
+            // may be three steps ahead of the slowest before it has to wait (in step sub 3 the fast wave of a SIMD pair waited in
+            // most stages: 1 400 cycles per stage), and the pieces still have three steps to land
+            if (sub == 2) prog_signal((uint32_t)(q / TPS + 1));
+            if (sub < 3) issue_pieces(ps_p1, q / TPS + 1, sub * PCNT, PCNT);
+            if (sub == 5) {
+                prog_wait(q / TPS + 1);
+                issue_pieces(ps_p1, q / TPS + 1, 6, 2);
+            }
+        } else if (sub < TPS - 1) issue_pieces(ps_p1, q / TPS + 1, sub * PCNT, PCNT);
 #if M2D_DIAG & 16
         STAMP(t1_); t_bar += t1_ - t0_; t0_ = t1_;
 #endif
@@ -709,7 +787,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
         }
 #endif
 #pragma unroll
-        for (int g = 0; g < G; ++g) alpha_prev[g] = alpha[g];   // tile q-2 was multiplied under the previous step's alpha
+        for (int g = 0; g < G; ++g) {
+            alpha_prev[g] = alpha[g];                          // tile q-2 was multiplied under the previous step's alpha
+            eps_prev[g] = eps[g];
+        }
+        accP_exact = false;
         int nvalid = 32;
         const bool plain = (M2D_DIAG & 2048) ? false : plain_left > 0;
         if (plain) --plain_left;
@@ -731,10 +813,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
             // block's users can rank a dish of that pattern, its tiles are dummies (no row valid) and the operands stay
             if (!((umask >> gp) & 1u)) nvalid = 0;
             else if (gp != cur_pat) {
+                if constexpr (APX) {                            // tile q - 2 belongs to the operands that are about to go
+                    complete(accP, q - 2);
+                    accP_exact = true;
+                }
                 cur_pat = gp;
                 const int pat = gp;
                 const float inv_n = 1.0f / (float)__builtin_popcount(pat);
                 const float beta = p.b * inv_n;
+                const float rmax_pat = APX ? __int_as_float(p.grp[GRP_RMAX + pat]) : 0.f;   // the pattern's largest row norm (NaN rows: +inf)
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     float hs = 0.f;
@@ -768,6 +855,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                             }
                         }
                     }
+                    float ww = 0.f;                                      // (APX) |w_P[u]|^2, this lane's half of the k-values
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {                   // unrolled: every register index is static
                         v4f w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
@@ -799,9 +887,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                             const __bf16 xh = (__bf16)xx[i];
                             vh[i] = xh;
                             vl[i] = (__bf16)(xx[i] - (float)xh);
+                            if (APX) ww = fmaf(xx[i], xx[i], ww);
                         }
                         wh[g][ks] = vh;
                         wl[g][ks] = vl;
+                    }
+                    if constexpr (APX) {
+                        // |x - hi| <= 2^-8 |x| for a dish value and for a w value: |sum (lo_d hi_w + hi_d lo_w)| <= 2^-7 (1 + 2^-8)
+                        // sum |d_k| |w_k| <= that times |d| |w|; 1.02 covers the norms' and the accumulations' own roundings
+                        ww += __shfl_xor(ww, 32, 64);
+                        eps[g] = 1.02f * 0.0078125f * sqrtf(ww) * rmax_pat;
                     }
                 }
             }
@@ -850,7 +945,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
         }
         unsigned long long anyc = 0ull;
 #pragma unroll
-        for (int g = 0; g < G; ++g) anyc |= __ballot(mx[g] >= thr_rel[g]);
+        for (int g = 0; g < G; ++g) anyc |= __ballot(mx[g] >= (APX ? thr_rel[g] - eps_prev[g] : thr_rel[g]));   // (APX: mx is of hi x hi scores)
 #if M2D_DIAG & 16
         STAMP(t1_); if (!(M2D_DIAG & 512)) t_body += t1_ - t0_; t0_ = t1_; ++n_step;
 #endif
@@ -858,7 +953,26 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
 #if M2D_DIAG & 8
         asm volatile("" ::"s"(anyc), "v"(mx[0]), "v"(mx[G - 1]));
 #endif
-        if ((M2D_DIAG & 8) ? false : anyc != 0ull) {       // some lane of tile q-2 beat its threshold
+        bool cand_step = (M2D_DIAG & 8) ? false : anyc != 0ull;
+        if constexpr (APX) {
+            if (cand_step) {                                // a hi x hi score came within eps of a threshold: the tile's exact scores
+#if M2D_DIAG & 16
+                ++n_ins;                                    // (APX builds: d[1] counts the tiles completed, not the multi-candidate tiles)
+#endif
+                if (!accP_exact) complete(accP, q - 2);
+                unsigned long long any2 = 0ull;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    float m2 = -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m2 = fmaxf(m2, accP[g][r]);
+                    mx[g] = m2;
+                    any2 |= __ballot(m2 >= thr_rel[g]);
+                }
+                cand_step = any2 != 0ull;
+            }
+        }
+        if (cand_step) {                                    // some lane of tile q-2 beat its threshold
             const int pt2 = ((q - 2) / TPS == q / TPS ? ps_0 : ps_m1) * TPS + ((q - 2) & (TPS - 1));   // physical tile of tile q - 2
             const int32_t sbase = (int32_t)((t_begin + pt2) * 32) + 4 * h;
             // per-lane 16-bit map of candidate rows (bit 15 - r), built here -- in the quarter of the steps that have a
@@ -963,7 +1077,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                 }
                 thr_dirty = true;
 #if M2D_DIAG & 16
-                ++n_ins;
+                if (!APX) ++n_ins;
 #endif
             }
 #if M2D_DIAG & 16
@@ -999,7 +1113,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
     }
     wait_all_vmem();                                       // no LDS-DMA may land after the lists are published below
     __syncthreads();
-    if (p.tiles_scanned && threadIdx.x == 0) atomicAdd(p.tiles_scanned, (unsigned long long)n);
+    // diagnostic: tiles stepped through (per block; bits 0 .. 35) and, APX, (wave, tile) pairs whose cross products were multiplied (bits 36 ..)
+    if (p.tiles_scanned && lane == 0 && (wave == 0 || (APX && n_completed)))
+        atomicAdd(p.tiles_scanned, (wave == 0 ? (unsigned long long)n : 0ull) + ((unsigned long long)n_completed << 36));
 #if M2D_DIAG & 16
     if (lane == 0 && p.dbg) {
         unsigned long long *d = p.dbg + ((size_t)(by * ((p.nU + 255) / 256) + bx) * WAVES + wave) * 8;
@@ -1037,6 +1153,8 @@ int m2d_topk_scan_bf16_launch(m2d_engine *h, const GroupedArgs &a, const ScanSha
         if (s.hv) M2D_SCAN_GO((m2d_topk_grouped_bf16_pipe2<EV, KRV, 1, true>), 512)                                               \
         if (!s.pipe) M2D_SCAN_GO((m2d_topk_grouped_bf16<EV, 8, KRV>), 512)                                                        \
         if constexpr (EV == 64) {                                                                                                 \
+            if (s.apx && s.keep) M2D_SCAN_GO((m2d_topk_grouped_bf16_pipe2<EV, KRV, 1, false, 8, true, true>), 512)                \
+            if (s.apx) M2D_SCAN_GO((m2d_topk_grouped_bf16_pipe2<EV, KRV, 1, false, 8, false, true>), 512)                         \
             if (s.waves == 4 && s.keep) M2D_SCAN_GO((m2d_topk_grouped_bf16_pipe2<EV, KRV, 1, false, 4, true>), 256)               \
             if (s.waves == 4) M2D_SCAN_GO((m2d_topk_grouped_bf16_pipe2<EV, KRV, 1, false, 4>), 256)                               \
         }                                                                                                                         \

@@ -102,6 +102,7 @@ struct m2d_engine {
     float *topk_plan = nullptr;         // pipelined retrieval kernel: per-user plan records | launch order | sort histogram | tile counter
     size_t topk_plan_cap = 0;           // floats
     unsigned long long *topk_tiles_counter = nullptr;   // tiles the blocks of the last pipelined launch stepped through (inside topk_plan)
+    bool topk_apx_last = false;         // the last pipelined retrieval launch took the hi x hi first form (see "topk_tiles_completed")
     int64_t topk_tiles_full = 0;        // ... and what they would have stepped through without pattern pruning
     int32_t *topk_tie_list = nullptr;   // [0] users the tie repair re-ranked in the last pattern-grouped call (get_option "topk_repaired")
     int64_t topk_flags_used = 0;        // users of the last pattern-grouped call (get_option "topk_repaired" counts the non-NaN values)
@@ -119,7 +120,7 @@ struct m2d_engine {
     int opt_mlp_bf16x3 = 1;             // MLP head layer 1 (build-defined) on split-bf16 MFMA; 0 = exact-f32 MFMA
     int opt_topk_bf16x3 = 1;            // retrieval (build-defined) on split-bf16 MFMA; 0 = exact-f32 MFMA
     int opt_topk_grouped = 1;           // 0/1-mask catalogues: pattern-grouped retrieval (contraction over E); 0 = dense kernel
-    int opt_topk_form = 0;              // split-bf16 retrieval kernel: 0 / 2 = pipelined form, 1 = first form
+    int opt_topk_form = 0;              // split-bf16 retrieval kernel: 0 / 2 = pipelined form, 1 = first form; 3 / 4 = hi x hi first form always / never
     int opt_topk_refine = 1;            // near-tied lists are finished in the tie repair's plain-f32 arithmetic (m2d_topk_refine): 0 = off (A/B)
     int64_t topk_refined = 0;           // diagnostics of the last call (device counters, read on request)
     float *topk_ex = nullptr;           // what the lists leave out, per (user, dish range) / (user, group) / user: 4 floats each

@@ -27,6 +27,7 @@ int main(int argc, char **argv)
     const size_t K = (C + 1) * E;
     std::vector<float> pm(U * K), re(I * E), ce(C * E), cats(I * C, 1.0f);
     if (getenv("M2D_DIAG_PRUNE")) h.opt_topk_prune = atoi(getenv("M2D_DIAG_PRUNE"));
+    if (getenv("M2D_DIAG_FORM")) h.opt_topk_form = atoi(getenv("M2D_DIAG_FORM"));      // 3 / 4: the hi x hi first form always / never
     if (argc > 1) h.opt_variant = atoi(argv[1]);
     unsigned s = 1;
     auto rnd1 = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffffff) / 16777216.0f - 0.5f; };   // 24 bits: 16-bit draws tie often enough to send thousands of users through the tie repair

@@ -87,7 +87,7 @@ def topk_case(rng, what):
     eng = ScoringEngine(PM, RE, CE, coef=COEF); eng.set_dish_categories(dc)
     for name in ("topk_bf16x3", "topk_grouped"):
         eng.set_option(name, int(rng.integers(0, 4) != 0))
-    eng.set_option("topk_form", int(rng.integers(0, 3)))
+    eng.set_option("topk_form", int(rng.integers(0, 5)))
     nU = int(rng.integers(1, 300))
     users = rng.integers(0, U, nU).astype(np.int32)
     s, ids = eng.topk_users(dev(users), k); eng.check()

@@ -315,7 +315,7 @@ def test_structural_ties_resolve_to_the_lower_id(E, forced):
     eng.set_dish_categories(cats)
     users = torch.arange(U, dtype=torch.int32, device="cuda")
     ref_s, ref_i = oracle.topk_catalogue(PM, RE, CE, cats, range(3), k)
-    forms = [(0, 0)] if E in (32, 200) else [(1, 0), (1, 1), (0, 0)]          # (topk_bf16x3, topk_form)
+    forms = [(0, 0)] if E in (32, 200) else [(1, 0), (1, 1), (0, 0)] + ([(1, 3)] if E == 64 else [])   # (topk_bf16x3, topk_form; 3: hi x hi first)
     for x3, form in forms:
         eng.set_option("topk_bf16x3", x3); eng.set_option("topk_form", form); eng.set_option("variant", forced)
         s, ids = eng.topk_users(users, k); eng.check()
@@ -396,6 +396,51 @@ def test_both_forms_of_the_split_bf16_kernel_agree(E, k):
     _explain_mismatches(PM, RE, CE, cats, np.arange(U), s1, i1, s2, i2)     # differing positions: scores closer than the rounding
     eng.set_option("topk_form", 1)
     _check(eng, PM, RE, CE, cats, np.arange(0, U, 7), k)                # the first form on its own against the oracle
+
+
+@pytest.mark.parametrize("k,low_scale,coef", [(10, 1.0, 0.99), (16, 1.0, 0.99), (10, 6.0, 0.99), (10, 0.05, 0.99), (10, 1.0, 0.5), (10, 1.0, 0.0),
+                                              (16, 1.0, 1.25), (10, 1.0, 0.9)])
+def test_hi_first_form_same_lists_in_every_launch_shape(k, low_scale, coef):
+    """E = 64, catalogues of more than 8 192 tiles (here forced, "topk_form" = 3): the body multiplies the hi x hi product only and
+    compares against the threshold less a bound of the two cross products; a tile that then still has a candidate gets them from
+    its rows in LDS.  A score is hi x hi + (lo x hi + hi x lo): its own arithmetic, so every launch shape must agree with every
+    other bit for bit (pruned or not, any split count, a pattern switch right behind a candidate tile, tiles 6 and 7 of a stage
+    completed out of the previous stage's buffer), the ids are the exact-f32 kernel's, and the three-product form's scores are
+    within its rounding."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    U, I, E = 1500, 9000, 64
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=E + 141 + k, n_nan=6, dup=50)
+    PM[:, 1:] *= low_scale
+    PM[7] = 0.0
+    eng = ScoringEngine(PM, RE, CE, coef=coef)
+    eng.set_dish_categories(cats)
+    users = torch.as_tensor(np.random.default_rng(15).permutation(U).astype(np.int32), device="cuda")
+    eng.set_option("topk_form", 3)
+    out = {}
+    for prune in (0, 1, 2, 4):
+        eng.set_option("topk_prune", prune)
+        for forced in (0, 101, 103, 108):
+            eng.set_option("variant", forced)
+            s, i = eng.topk_users(users, k); eng.check()
+            assert eng.last_kernel() == "m2d_topk_grouped_bf16x3"
+            assert eng.get_option("topk_block_users") == 256
+            out[prune, forced] = (s.cpu().numpy(), i.cpu().numpy())
+    base = out[0, 101]
+    for key, (s, i) in out.items():
+        assert np.array_equal(i, base[1]) and np.array_equal(s, base[0], equal_nan=True), key
+    eng.set_option("variant", 0); eng.set_option("topk_prune", 1)
+    _check(eng, PM, RE, CE, cats, users.cpu().numpy()[:80], k, dup=50)
+    _check(eng, PM, RE, CE, cats, np.array([7, 3, 7]), k)
+    eng.set_option("topk_form", 4)                            # the three-product form: the same ids, scores within the rounding
+    s4, i4 = eng.topk_users(users, k); eng.check()
+    s4, i4 = s4.cpu().numpy(), i4.cpu().numpy()
+    assert np.array_equal(i4, base[1])
+    fin = np.isfinite(s4)
+    assert np.all(np.abs(s4[fin] - base[0][fin]) <= 2e-5 * np.maximum(1.0, np.abs(s4[fin])))
+    eng.set_option("topk_bf16x3", 0)                          # and the exact-f32 kernel's ids
+    s0, i0 = eng.topk_users(users, k); eng.check()
+    assert np.array_equal(i0.cpu().numpy(), base[1])
 
 
 @pytest.mark.parametrize("E,low_scale,coef", [(64, 1.0, 0.99), (128, 1.0, 0.99), (64, 6.0, 0.99), (128, 0.05, 0.99)] +
@@ -632,8 +677,10 @@ def test_split_bf16_lists_are_the_exact_f32_kernels_lists(E, k, I, coef):
     eng.set_dish_categories(cats)
     users = torch.as_tensor(np.random.default_rng(k).permutation(U).astype(np.int32), device="cuda")
     res = {}
-    for x3 in (1, 0):
-        eng.set_option("topk_bf16x3", x3)
+    for x3 in (1, 3, 0):                                    # 3: split bf16, the hi x hi first form ("topk_form" 3; its own arithmetic)
+        if x3 == 3 and E != 64:
+            continue
+        eng.set_option("topk_bf16x3", 1 if x3 else 0); eng.set_option("topk_form", 3 if x3 == 3 else 4)
         for prune, forced in ((1, 0), (0, 101), (1, 105)):
             eng.set_option("topk_prune", prune); eng.set_option("variant", forced)
             s, i = eng.topk_users(users, k); eng.check()
@@ -643,11 +690,14 @@ def test_split_bf16_lists_are_the_exact_f32_kernels_lists(E, k, I, coef):
         assert np.array_equal(i, i_ref), (key, int((i != i_ref).any(1).sum()), refined)
     if coef != 1.0:
         assert res[1, 1, 0][2] > 0                          # some lists were near-tied and went through the refinement
-    for x3 in (1, 0):                                       # and inside one kernel every option form returns the same bits
+    for x3 in (1, 3, 0):                                    # and inside one kernel every option form returns the same bits
+        if (x3, 0, 101) not in res:
+            continue
         base = res[x3, 0, 101][0]
         for key, (s, i, refined) in res.items():
             if key[0] == x3:
                 assert np.array_equal(s.view(np.int32), base.view(np.int32)), key
+    eng.set_option("topk_form", 0)
     eng.set_option("topk_bf16x3", 1); eng.set_option("topk_prune", 1); eng.set_option("variant", 0)
     eng.set_option("topk_refine", 0)                        # without it the two kernels disagree on some near-tie (what was measured)
     s_off, i_off = eng.topk_users(users, k); eng.check()
