@@ -855,7 +855,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                             }
                         }
                     }
-                    float ww = 0.f;                                      // (APX) |w_P[u]|^2, this lane's half of the k-values
+                    float ww = 0.f;                                      // (APX) the largest |w_k| of this lane's half of the k-values
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {                   // unrolled: every register index is static
                         v4f w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
@@ -887,16 +887,32 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                             const __bf16 xh = (__bf16)xx[i];
                             vh[i] = xh;
                             vl[i] = (__bf16)(xx[i] - (float)xh);
-                            if (APX) ww = fmaf(xx[i], xx[i], ww);
+                            if (APX) ww = fmaxf(ww, fabsf(xx[i]));          // (first the largest magnitude: the squares are summed scaled by it)
                         }
                         wh[g][ks] = vh;
                         wl[g][ks] = vl;
                     }
                     if constexpr (APX) {
                         // |x - hi| <= 2^-8 |x| for a dish value and for a w value: |sum (lo_d hi_w + hi_d lo_w)| <= 2^-7 (1 + 2^-8)
-                        // sum |d_k| |w_k| <= that times |d| |w|; 1.02 covers the norms' and the accumulations' own roundings
-                        ww += __shfl_xor(ww, 32, 64);
-                        eps[g] = 1.02f * 0.0078125f * sqrtf(ww) * rmax_pat;
+                        // sum |d_k| |w_k| <= that times |d| |w|; 1.02 covers the norms' and the accumulations' own roundings.
+                        // |w| = s sqrt(sum (w_k / s)^2) with s the largest |w_k| -- squares of values around 1, no under- or overflow on
+                        // the way (w_k read back as hi + lo: off by 2^-16 of itself); a vanishing s: |w| <= sqrt(E) s
+                        const float smax = fmaxf(ww, __shfl_xor(ww, 32, 64));
+                        float nw = 8.0f * smax;
+                        if (smax >= 1e-30f) {
+                            const float inv = 1.0f / smax;
+                            float q2 = 0.f;
+#pragma unroll
+                            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    const float t = ((float)wh[g][ks][i] + (float)wl[g][ks][i]) * inv;
+                                    q2 = fmaf(t, t, q2);
+                                }
+                            q2 += __shfl_xor(q2, 32, 64);
+                            nw = smax * sqrtf(q2);
+                        }
+                        eps[g] = 1.02f * 0.0078125f * nw * rmax_pat;
                     }
                 }
             }

@@ -110,16 +110,25 @@ COEF_CASES = [c + (coef,) for coef in COEFS for c in (("anti", 64, 1, 1e-4, 6.0,
                                                        ("hc_cancel", 64, 1, 1e-4, 1.0, 7000))]
 
 
-@pytest.mark.parametrize("style,E,x3,eps,low_scale,I,coef", [c + (0.99,) for c in CASES] + COEF_CASES)
+# the split-bf16 cases at E = 64 again under the hi x hi first form of the pipelined kernel ("topk_form" 3; x3 = 3 below): the tiles'
+# cross products are multiplied only where hi x hi comes within a bound of a threshold -- under cancellation the scores that
+# matter are small beside |w| |r|, which is what that bound is made of
+HI_FIRST_CASES = [(c[0], c[1], 3) + c[3:] + (0.99,) for c in CASES if c[1] == 64 and c[2] == 1] + \
+                 [(c[0], c[1], 3) + c[3:] for c in COEF_CASES if c[1] == 64 and c[2] == 1]
+
+
+@pytest.mark.parametrize("style,E,x3,eps,low_scale,I,coef", [c + (0.99,) for c in CASES] + COEF_CASES + HI_FIRST_CASES)
 def test_pruned_lists_equal_the_plain_scan_under_cancellation(style, E, x3, eps, low_scale, I, coef):
     import torch
     from foodrec_amd import ScoringEngine
     U, k = 100_352, 10                                     # 392 blocks of 256 users
+    hi_first, x3 = x3 == 3, min(x3, 1)
     seed = 9000 + sum(map(ord, style)) + E + 7 * x3 + I + int(-np.log10(eps)) if eps else 9000 + sum(map(ord, style)) + E + I
     PM, RE, CE, cats = adversarial_tables(style, E, U, I, seed, eps=eps, low_scale=low_scale)
     eng = ScoringEngine(PM, RE, CE, coef=coef)
     eng.set_dish_categories(cats)
     eng.set_option("topk_bf16x3", x3)
+    eng.set_option("topk_form", 3 if hi_first else 0)
     users = torch.arange(U, dtype=torch.int32, device="cuda")
     out = lists_of_every_form(eng, users, k)
     assert eng.last_kernel() == (("m2d_topk_grouped_bf16x3" if x3 else "m2d_topk_grouped") if coef != 1.0 else "m2d_topk_high_level_only")
