@@ -750,7 +750,7 @@ int launch_grouped(m2d_engine *h, const int E8, const int KR, const bool BF16X3,
     // the exception: more than 8 192 tiles -- where blocks of 256 users are taken anyway.  The rule looks at the catalogue alone:
     // that form's scores are not the three-product kernels' bits, and every launch shape of one problem must return the same lists
     // ("topk_block" = 128 is therefore not honoured there).  "topk_form" 3 / 4 (diagnostic): that form for any catalogue / never.
-    const bool apx = half_ok && h->opt_topk_form != 4 && (h->grp_tiles > 8192 || h->opt_topk_form == 3);
+    const bool apx = BF16X3 && !HV && pipe && (E == 64 || E == 128) && h->opt_topk_form != 4 && (h->grp_tiles > 8192 || h->opt_topk_form == 3);
     const bool half = half_ok && !apx && (h->opt_topk_block == 128 || (h->opt_topk_block == 0 && M2D_TOPK_HALF_BLOCKS && h->opt_topk_prune != 0 &&
                                                               h->opt_variant < 100 && nU >= 16384 && h->grp_tiles <= 8192));
     const int WV = half ? 4 : WAVES;                         // waves per block

@@ -277,13 +277,13 @@ __device__ __forceinline__ void diag_mfma16(v16f &acc, const int ks, const bf16x
 // candidate is the exception): the body multiplies only the hi x hi product of a tile -- a third of the matrix work, half the LDS
 // reads -- and compares against the threshold LESS a bound of what the two cross products can add (eps = 2^-7 * 1.02 |w_P[u]| *
 // the pattern's largest row norm: |x - hi(x)| <= 2^-8 |x| for both operands, Cauchy-Schwarz); a tile that still has a candidate
-// gets its cross products then, from its rows still in LDS, and is handled from exact scores as before.  A score is
-// hi x hi + (lo x hi + hi x lo), each part accumulated on its own: not the bits of the three-product kernels, so the launcher's
+// gets its cross products then, from its rows still in LDS, and is handled from exact scores as before.  A score is the
+// hi x hi sums of all k-steps with the cross products added behind them: not the bits of the three-product kernels, so the launcher's
 // choice depends on the catalogue alone -- every launch shape of one problem takes the same arithmetic (lists bit for bit).
 template <int E, int KR, int G, bool HV = false, int WAVES = 8 / G, bool KEEP = false, bool APX = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(GroupedArgs p)
 {
-    static_assert(!APX || (E == 64 && !HV && WAVES == 8 && G == 1), "the hi x hi first form: E = 64, blocks of eight waves");
+    static_assert(!APX || ((E == 64 || E == 128) && !HV && WAVES == 8 && G == 1), "the hi x hi first form: blocks of eight waves");
     constexpr int C = 4;
     constexpr int KS = E / 16;                             // k-steps (16 k-values) per tile
     constexpr int S8 = E / 8;                              // 16-B slots per bf16 row
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
         issue_pieces(ps_0, 0, 0, PPW);
         wait_all_vmem();
         __syncthreads();
-        issue_pieces(ps_p1, 1, 0, PCNT);                   // what step "0" of the first stage would have issued
+        issue_pieces(ps_p1, 1, 0, (APX && KS > AR) ? 4 : PCNT);   // what step "0" of the first stage would have issued
 #pragma unroll
         for (int ks = 0; ks < AR; ++ks) {                  // the first AR k-steps of tile 0
             const unsigned char *a = smem8 + (lane_off ^ (ks << 5));
@@ -652,26 +652,23 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
 
     // (APX) the cross products of tile qt, from its rows in LDS (hi and lo fragments read again), under the operands in registers --
     // so before a pattern switch rebuilds those: a step that switches completes tile q - 2 first, candidate or not (`accP_exact`).
-    // Its own accumulator, added to the hi x hi one at the end: the same bits wherever the tile sits in a launch.
+    // Accumulated onto the tile's hi x hi sums, k-step by k-step: one order for every tile, the same bits wherever it sits in a launch.
     bool accP_exact = false;                               // wave-uniform
     unsigned n_completed = 0;                              // (diagnostic) tiles this wave completed
     auto complete = [&](v16f (&acc)[G], const int qt) __attribute__((always_inline)) {
         if (qt < 0) return;
         ++n_completed;
         const int img2 = (((qt / TPS) & 1) * STAGE_BYTES + (qt & (TPS - 1)) * TILE_BYTES) + lane_off;
-        v16f x2[G];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const unsigned char *a2 = smem8 + (img2 ^ (ks << 5));
             const bf16x8 h2 = *reinterpret_cast<const bf16x8 *>(a2), l2 = *reinterpret_cast<const bf16x8 *>(a2 + 32 * ROW_BYTES);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                x2[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l2, wh[g][ks], ks == 0 ? zero16 : x2[g], 0, 0, 0);
-                x2[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h2, wl[g][ks], x2[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l2, wh[g][ks], acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h2, wl[g][ks], acc[g], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int g = 0; g < G; ++g) acc[g] += x2[g];
     };
     // (APX) Tile q - 2's rows must still be in LDS when a step completes it.  In a stage's steps "sub 0" and "sub 1" that tile is
     // tile 6 / 7 of the PREVIOUS stage's buffer, which this stage's steps refill for the next one -- region r by piece r, pieces 6
@@ -749,7 +746,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
             ps_p1 = next_stage();
             if (SHARE && p.shared_thr) exchange_thresholds();
         }
-        if (KS > AR && sub == 1) {
+        if (KS > AR && !APX && sub == 1) {
             // With more k-steps than fragment sets (E = 128: KS = 8, AR = 4) a tile's last KS - AR k-steps are read one step
             // after its first ones: the LAST tile of the previous stage was still being read during step "sub 0", after that
             // stage's barrier.  Its LDS region is refilled by the pieces issued at sub = TPS - 2; nothing kept a wave that
@@ -759,8 +756,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
             // before any wave goes on to the steps that refill that region.
             asm volatile("s_barrier" ::: "memory");
         }
-        if constexpr (APX) {
-            static_assert(!APX || (TPS == 8 && PCNT == 2 && PPW == 8), "pieces 6 and 7 = regions 6 and 7");
+        if constexpr (APX && KS > AR) {
+            // E = 128, the hi x hi first form: a stage is four tiles of two pieces; beside the last tile's late k-steps (above) the
+            // steps "sub 0" and "sub 1" may read tiles 2 and 3 of the previous stage's buffer again (a tile with a candidate gets
+            // its cross products two steps after it was multiplied).  Pieces 0 .. 3 (tiles 0, 1) at the stage's first step, the
+            // barrier at the head of step "sub 2" -- every wave is past "sub 1" -- and pieces 4 .. 7 behind it.
+            static_assert(!(APX && KS > AR) || (TPS == 4 && PPW == 8), "two pieces per tile, four tiles per stage");
+            if (sub == 0) issue_pieces(ps_p1, q / TPS + 1, 0, 4);
+            if (sub == 2) {
+                asm volatile("s_barrier" ::: "memory");
+                issue_pieces(ps_p1, q / TPS + 1, 4, 4);
+            }
+        } else if constexpr (APX) {
+            static_assert(!APX || KS > AR || (TPS == 8 && PCNT == 2 && PPW == 8), "pieces 6 and 7 = regions 6 and 7");
             // pieces 0 .. 5 in steps sub 0 .. 2 as ever; 6 and 7 in step sub 5, behind the look at the others' words: by then a wave
             // may be three steps ahead of the slowest before it has to wait (in step sub 3 the fast wave of a SIMD pair waited in
             // most stages: 1 400 cycles per stage), and the pieces still have three steps to land
@@ -855,7 +863,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                             }
                         }
                     }
-                    float ww = 0.f;                                      // (APX) the largest |w_k| of this lane's half of the k-values
+                    float ww = 0.f, wmax = 0.f;                          // (APX) sum of squares and largest magnitude of this lane's half of w_P[u]
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {                   // unrolled: every register index is static
                         v4f w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
@@ -887,7 +895,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                             const __bf16 xh = (__bf16)xx[i];
                             vh[i] = xh;
                             vl[i] = (__bf16)(xx[i] - (float)xh);
-                            if (APX) ww = fmaxf(ww, fabsf(xx[i]));          // (first the largest magnitude: the squares are summed scaled by it)
+                            if (APX) {
+                                ww = fmaf(xx[i], xx[i], ww);
+                                wmax = fmaxf(wmax, fabsf(xx[i]));
+                            }
                         }
                         wh[g][ks] = vh;
                         wl[g][ks] = vl;
@@ -895,23 +906,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                     if constexpr (APX) {
                         // |x - hi| <= 2^-8 |x| for a dish value and for a w value: |sum (lo_d hi_w + hi_d lo_w)| <= 2^-7 (1 + 2^-8)
                         // sum |d_k| |w_k| <= that times |d| |w|; 1.02 covers the norms' and the accumulations' own roundings.
-                        // |w| = s sqrt(sum (w_k / s)^2) with s the largest |w_k| -- squares of values around 1, no under- or overflow on
-                        // the way (w_k read back as hi + lo: off by 2^-16 of itself); a vanishing s: |w| <= sqrt(E) s
-                        const float smax = fmaxf(ww, __shfl_xor(ww, 32, 64));
-                        float nw = 8.0f * smax;
-                        if (smax >= 1e-30f) {
-                            const float inv = 1.0f / smax;
-                            float q2 = 0.f;
-#pragma unroll
-                            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                                for (int i = 0; i < 8; ++i) {
-                                    const float t = ((float)wh[g][ks][i] + (float)wl[g][ks][i]) * inv;
-                                    q2 = fmaf(t, t, q2);
-                                }
-                            q2 += __shfl_xor(q2, 32, 64);
-                            nw = smax * sqrtf(q2);
-                        }
+                        // |w|: the root of the sum of squares where that sum is a normal number (squares lost to underflow are then
+                        // far below what the 1.02 covers), else sqrt(E) times the largest |w_k| -- never less than |w|
+                        ww += __shfl_xor(ww, 32, 64);
+                        wmax = fmaxf(wmax, __shfl_xor(wmax, 32, 64));
+                        const float nw = (ww >= 1e-30f && ww < INFINITY) ? sqrtf(ww) : sqrtf((float)EU) * wmax;
                         eps[g] = 1.02f * 0.0078125f * nw * rmax_pat;
                     }
                 }
@@ -1173,6 +1172,10 @@ int m2d_topk_scan_bf16_launch(m2d_engine *h, const GroupedArgs &a, const ScanSha
             if (s.apx) M2D_SCAN_GO((m2d_topk_grouped_bf16_pipe2<EV, KRV, 1, false, 8, false, true>), 512)                         \
             if (s.waves == 4 && s.keep) M2D_SCAN_GO((m2d_topk_grouped_bf16_pipe2<EV, KRV, 1, false, 4, true>), 256)               \
             if (s.waves == 4) M2D_SCAN_GO((m2d_topk_grouped_bf16_pipe2<EV, KRV, 1, false, 4>), 256)                               \
+        }                                                                                                                         \
+        if constexpr (EV == 128) {                                                                                                \
+            if (CAN_KEEP && s.apx && s.keep) M2D_SCAN_GO((m2d_topk_grouped_bf16_pipe2<EV, KRV, 1, false, 8, CAN_KEEP, true>), 512)    \
+            if (s.apx && !s.keep) M2D_SCAN_GO((m2d_topk_grouped_bf16_pipe2<EV, KRV, 1, false, 8, false, true>), 512)              \
         }                                                                                                                         \
         if (CAN_KEEP && s.keep) M2D_SCAN_GO((m2d_topk_grouped_bf16_pipe2<EV, KRV, 1, false, 8, CAN_KEEP>), 512)                   \
         M2D_SCAN_GO((m2d_topk_grouped_bf16_pipe2<EV, KRV, 1>), 512)                                                               \

@@ -54,7 +54,7 @@ for it in range(n):
     coef = [0.99, 0.99, 0.9, 0.5, 0.0, 1.25, 1.0, 0.99][(seed0 + it) % 8]    # --high_level_score_coefficient (Train_recommender.py:61-62; no draw: the seeds' tables stay what they were)
     eng = ScoringEngine(PM.astype(np.float32), RE.astype(np.float32), CE.astype(np.float32), coef=coef); eng.set_dish_categories(cats)
     eng.set_option("topk_bf16x3", x3)
-    hi_first = bool(x3 and E == 64 and (seed0 + it) % 3 == 0)        # "topk_form" 3: the hi x hi first form of the pipelined kernel (E = 64), forced
+    hi_first = bool(x3 and E in (64, 128) and (seed0 + it) % 3 == 0)     # "topk_form" 3: the hi x hi first form of the pipelined kernel, forced
     eng.set_option("topk_form", 3 if hi_first else 0)
     nU = int(rng.integers(1, min(U, 2100) + 1)) if serving else int(rng.integers(257, min(U, 30000) + 1))
     users = rng.integers(0, U, nU).astype(np.int32)
