@@ -322,7 +322,7 @@ def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10, ke
         scanned, full = eng.get_option("topk_tiles_scanned"), eng.get_option("topk_tiles_full")
         if scanned > 0:
             flops = 2.0 * E * eng.get_option("topk_block_users") * 32 * scanned     # a block's user lanes (256, or 128) x a tile's 32 dishes
-    # split bf16: three products per tile -- or, the hi x hi first form (catalogues of more than 8 192 tiles), one product per tile
+    # split bf16: three products per tile -- or, the hi x hi first form (large catalogues), one product per tile
     # and the two cross products for the (wave, tile) pairs that could still hold a candidate
     completed = eng.get_option("topk_tiles_completed") if kernel.startswith("m2d_topk_grouped") else -1
     ex3 = 3 * flops if completed < 0 else flops + 2 * (2.0 * E * 32 * 32 * completed)
@@ -1289,7 +1289,7 @@ def main():
                     scanned_frac = sc_ / fu_
             tf_all = fl / (avg_ms * 1e-3) / 1e12
             tf = tf_all * (scanned_frac if scanned_frac is not None else 1.0)
-            # the hi x hi first form (E = 64, catalogues of more than 8 192 tiles): one product per tile stepped through, the two cross
+            # the hi x hi first form (large catalogues): one product per tile stepped through, the two cross
             # products for the share of (wave, tile) pairs that could still hold a candidate (the step's last launch stands for the step)
             cross_share = None
             if x3 and kernel_used.startswith("m2d_topk_grouped") and not a.topk_with_ingredients:

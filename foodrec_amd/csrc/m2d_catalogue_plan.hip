@@ -747,10 +747,14 @@ int launch_grouped(m2d_engine *h, const int E8, const int KR, const bool BF16X3,
     // (k > 10 with the left-out bookkeeping: 232 registers since the launch bounds say two waves per SIMD -- it took 261 and one
     //  wave per SIMD before, and the launcher kept eight-wave blocks for it: 65 536 users x 100 k dishes, k = 16: 0.764 -> 0.666 ms)
     // The hi x hi first form of that kernel (APX in m2d_catalogue_scan_bf16.hip) for the catalogues where a tile with a candidate is
-    // the exception: more than 8 192 tiles -- where blocks of 256 users are taken anyway.  The rule looks at the catalogue alone:
-    // that form's scores are not the three-product kernels' bits, and every launch shape of one problem must return the same lists
-    // ("topk_block" = 128 is therefore not honoured there).  "topk_form" 3 / 4 (diagnostic): that form for any catalogue / never.
-    const bool apx = BF16X3 && !HV && pipe && (E == 64 || E == 128) && h->opt_topk_form != 4 && (h->grp_tiles > 8192 || h->opt_topk_form == 3);
+    // the exception.  It pays once fewer than about a quarter (E = 64) / a half (E = 128) of the (wave, tile) pairs still need their
+    // cross products -- 65 536 users, pruned, three-product form against it: E = 64 200 k dishes 0.73 / 0.88 ms, 500 k 1.51 / 1.63,
+    // 1 M 2.81 / 2.63; E = 128 300 k 1.94 / 1.94, 500 k 2.96 / 2.75, 1 M 6.16 / 4.95 -- so: more than 24 576 tiles at E = 64, more
+    // than 10 240 at E = 128.  The rule looks at the catalogue alone: that form's scores are not the three-product kernels' bits, and
+    // every launch shape of one problem must return the same lists (blocks of 256 users there: "topk_block" = 128 is not
+    // honoured).  "topk_form" 3 / 4 (diagnostic): that form for any catalogue / never.
+    const bool apx = BF16X3 && !HV && pipe && (E == 64 || E == 128) && h->opt_topk_form != 4 &&
+                     (h->grp_tiles > (E == 64 ? 24576 : 10240) || h->opt_topk_form == 3);
     const bool half = half_ok && !apx && (h->opt_topk_block == 128 || (h->opt_topk_block == 0 && M2D_TOPK_HALF_BLOCKS && h->opt_topk_prune != 0 &&
                                                               h->opt_variant < 100 && nU >= 16384 && h->grp_tiles <= 8192));
     const int WV = half ? 4 : WAVES;                         // waves per block

@@ -273,8 +273,8 @@ __device__ __forceinline__ void diag_mfma16(v16f &acc, const int ks, const bf16x
 }
 #endif
 
-// APX = true (E = 64, blocks of 256 users; launch_grouped takes it for catalogues of more than 8 192 tiles, where a tile with a
-// candidate is the exception): the body multiplies only the hi x hi product of a tile -- a third of the matrix work, half the LDS
+// APX = true (blocks of 256 users; launch_grouped takes it for the large catalogues, where a tile with a candidate is the
+// exception): the body multiplies only the hi x hi product of a tile -- a third of the matrix work, half the LDS
 // reads -- and compares against the threshold LESS a bound of what the two cross products can add (eps = 2^-7 * 1.02 |w_P[u]| *
 // the pattern's largest row norm: |x - hi(x)| <= 2^-8 |x| for both operands, Cauchy-Schwarz); a tile that still has a candidate
 // gets its cross products then, from its rows still in LDS, and is handled from exact scores as before.  A score is the

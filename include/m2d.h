@@ -262,12 +262,12 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
  * blocks_per_cu    8        1 ... 16     grid size of the pair kernels
  * mlp_form         0        0 / 1        split-bf16 head kernel: 0 = matrix waves fed by gather / DMA waves, 1 = every wave gathers its own rows
  *                                        (same results within the split's rounding)
- * topk_form        0        0 ... 4      split-bf16 retrieval kernel: 0 / 2 = pipelined form, 1 = first form (same lists).  E = 64, catalogues of more than
- *                                        8 192 tiles (262 144 dishes per mask pattern group on average ... 2 M rows of image): the pipelined form multiplies
- *                                        the hi x hi product first and the two cross products only for tiles that can still hold a candidate -- scores are
- *                                        then hi x hi + (lo x hi + hi x lo), within the split's rounding of the three-product kernels' but not their bits,
- *                                        which is why the rule looks at the catalogue alone (blocks of 256 users; "topk_block" = 128 is not honoured
- *                                        there).  3 = that form for any catalogue, 4 = never (both diagnostic)
+ * topk_form        0        0 ... 4      split-bf16 retrieval kernel: 0 / 2 = pipelined form, 1 = first form (same lists).  Large catalogues (more than
+ *                                        24 576 tiles of 32 dishes at E = 64, more than 10 240 at E = 128): the pipelined form multiplies the hi x hi
+ *                                        product of every tile and the two cross products only for tiles that can still hold a candidate -- scores
+ *                                        are within the split's rounding of the three-product kernels' but not their bits, which is why the rule looks
+ *                                        at the catalogue alone (blocks of 256 users; "topk_block" = 128 is not honoured there).  3 = that form for
+ *                                        any catalogue, 4 = never (both diagnostic)
  * topk_prune       1        0 ... 9      pattern-grouped retrieval: 1 = scan starts from a lower bound of the user's k-th score and steps through the
  *                                        tiles of the mask patterns that can reach its top-k only (bounds: alpha_P[u] +- |w_P[u]| max|RE[d]|, widened by
  *                                        what the arithmetic can move a computed score by; users sorted by pattern mask; (user block, dish range) items

@@ -402,7 +402,7 @@ def test_both_forms_of_the_split_bf16_kernel_agree(E, k):
                                                 (64, 10, 1.0, 0.0), (64, 16, 1.0, 1.25), (64, 10, 1.0, 0.9), (128, 10, 1.0, 0.99), (128, 16, 1.0, 0.99),
                                                 (128, 10, 6.0, 0.5), (128, 13, 0.05, 1.25), (128, 10, 1.0, 0.0)])
 def test_hi_first_form_same_lists_in_every_launch_shape(E, k, low_scale, coef):
-    """Catalogues of more than 8 192 tiles (here forced, "topk_form" = 3): the body multiplies the hi x hi product only and
+    """Large catalogues (here forced, "topk_form" = 3): the body multiplies the hi x hi product only and
     compares against the threshold less a bound of the two cross products; a tile that then still has a candidate gets them from
     its rows in LDS.  A score is hi x hi + (lo x hi + hi x lo): its own arithmetic, so every launch shape must agree with every
     other bit for bit (pruned or not, any split count, a pattern switch right behind a candidate tile, tiles 6 and 7 of a stage
