@@ -1153,7 +1153,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
 
 }  // namespace
 
-int m2d_topk_scan_bf16_launch(m2d_engine *h, const GroupedArgs &a, const ScanShape &s, dim3 grid, size_t lds, hipStream_t st)
+// The instantiations are compiled in two translation units, by kernel width (m2d_catalogue_scan_bf16_e64.hip / _e128.hip define
+// M2D_SCAN_E and include this file); a build that includes this file as it is (scripts/diag) gets them all in one.
+#if !defined(M2D_SCAN_E)
+#define M2D_SCAN_LAUNCH m2d_topk_scan_bf16_launch
+#elif M2D_SCAN_E == 64
+#define M2D_SCAN_LAUNCH m2d_topk_scan_bf16_launch_e64
+#else
+#define M2D_SCAN_LAUNCH m2d_topk_scan_bf16_launch_e128
+#endif
+M2D_INTERNAL int M2D_SCAN_LAUNCH(m2d_engine *h, const GroupedArgs &a, const ScanShape &s, dim3 grid, size_t lds, hipStream_t st);
+int M2D_SCAN_LAUNCH(m2d_engine *h, const GroupedArgs &a, const ScanShape &s, dim3 grid, size_t lds, hipStream_t st)
 {
 #define M2D_SCAN_GO(KERN, THREADS)                                                      \
     {                                                                                   \
@@ -1180,7 +1190,12 @@ int m2d_topk_scan_bf16_launch(m2d_engine *h, const GroupedArgs &a, const ScanSha
         if (CAN_KEEP && s.keep) M2D_SCAN_GO((m2d_topk_grouped_bf16_pipe2<EV, KRV, 1, false, 8, CAN_KEEP>), 512)                   \
         M2D_SCAN_GO((m2d_topk_grouped_bf16_pipe2<EV, KRV, 1>), 512)                                                               \
     }
-    M2D_SCAN_BF16(64, 10) M2D_SCAN_BF16(64, 16) M2D_SCAN_BF16(128, 10) M2D_SCAN_BF16(128, 16)
+#if !defined(M2D_SCAN_E) || M2D_SCAN_E == 64
+    M2D_SCAN_BF16(64, 10) M2D_SCAN_BF16(64, 16)
+#endif
+#if !defined(M2D_SCAN_E) || M2D_SCAN_E == 128
+    M2D_SCAN_BF16(128, 10) M2D_SCAN_BF16(128, 16)
+#endif
 #undef M2D_SCAN_BF16
 #undef M2D_SCAN_GO
     h->last_error = "m2d_topk_scan_bf16_launch: no such instantiation";
