@@ -774,7 +774,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
             // most stages: 1 400 cycles per stage), and the pieces still have three steps to land
             if (sub == 2) prog_signal((uint32_t)(q / TPS + 1));
             if (sub < 3) issue_pieces(ps_p1, q / TPS + 1, sub * PCNT, PCNT);
-            if (sub == 5) {
+            if (sub == 5) {                                  // (4, 5 or 6: the same times)
                 prog_wait(q / TPS + 1);
                 issue_pieces(ps_p1, q / TPS + 1, 6, 2);
             }
