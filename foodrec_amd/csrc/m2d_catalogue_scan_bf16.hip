@@ -424,6 +424,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
     // stage numbers (relative to t_begin) kept in lanes -- range i in lane i of r_first / r_cnt.  A stage that straddles a
     // group boundary brings a few tiles of a neighbouring pattern along; they are scored like any other.
     int r_first = 0, r_cnt = 0, nranges = 0, vstages = 0;
+    int first_pat = 0;                                     // the first pattern of the scan that the block needs (its operands: see the prologue)
     {
         int last_end = -1;
         for (int q = 1; q < GRP_MAXPAT; ++q) {
@@ -432,6 +433,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
             const int64_t gt0 = __builtin_amdgcn_readlane(g_first, q), gt1 = gt0 + ((rows + 31) >> 5);
             const int64_t lo = gt0 > t_begin ? gt0 : t_begin, hi = gt1 < t_end ? gt1 : t_end;
             if (lo >= hi) continue;
+            if (first_pat == 0) first_pat = q;
             int s0 = (int)((lo - t_begin) / TPS);
             const int s1 = (int)((hi - 1 - t_begin) / TPS);
             if (s0 <= last_end) s0 = last_end + 1;
@@ -513,10 +515,108 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
     }
     const v16f zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+    // a pattern's operands: alpha_P[u], w_P[u] split hi / lo, (APX) the cross products' bound -- built where a scan reaches a pattern its
+    // block needs, and for the first such pattern ahead of the first stage's arrival (the rows' loads and the stage's DMA in flight
+    // together: two memory round trips at the head of every (user block, dish range) item were one after the other)
+    auto build_operands = [&](const int pat) __attribute__((always_inline)) {
+        const float inv_n = 1.0f / (float)__builtin_popcount(pat);
+        const float beta = p.b * inv_n;
+        const float rmax_pat = APX ? __int_as_float(p.grp[GRP_RMAX + pat]) : 0.f;   // the pattern's largest row norm (NaN rows: +inf)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float hs = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) hs += ((pat >> c) & 1) ? hc[g][c] : 0.f;
+            alpha[g] = HV ? 0.f : p.a * (hs * inv_n);
+            // E = 64: the pattern's rows category by category -- a category's eight float4 in flight together, one wait,
+            // then the adds (the same sums in the same order).  Written k-step by k-step with the category test inside,
+            // the loads came out as sixteen exec-masked pairs, each waited for before the next was issued: sixteen
+            // round trips in a row at every pattern switch, with the block's matrix pipe idle
+            constexpr bool BYCAT = !HV && KS == 4;
+            v4f wacc[BYCAT ? KS : 1][2];
+            if constexpr (BYCAT) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) wacc[ks][0] = wacc[ks][1] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    if ((pat >> c) & 1) {
+                        v4f ld[KS][2];
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            const v4f *row = pmu[g] + (c + 1) * S4 + 4 * ks + 2 * h;
+                            ld[ks][0] = row[0];
+                            ld[ks][1] = row[1];
+                        }
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            wacc[ks][0] += ld[ks][0];
+                            wacc[ks][1] += ld[ks][1];
+                        }
+                    }
+                }
+            }
+            float ww = 0.f, wmax = 0.f;                          // (APX) sum of squares and largest magnitude of this lane's half of w_P[u]
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {                   // unrolled: every register index is static
+                v4f w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (BYCAT) {
+                    w0 = wacc[ks][0] * beta;
+                    w1 = wacc[ks][1] * beta;
+                } else
+                if (HV && ks < KS / 2) {                        // k < EU: a U_high against H[d]
+                    const v4f *row = pmu[g] + 4 * ks + 2 * h;
+                    w0 = row[0] * p.a;
+                    w1 = row[1] * p.a;
+                } else {
+                    const int kk = HV ? ks - KS / 2 : ks;       // k - EU: w_P against RE[d]
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        if ((pat >> c) & 1) {
+                            const v4f *row = pmu[g] + (c + 1) * S4 + 4 * kk + 2 * h;
+                            w0 += row[0];
+                            w1 += row[1];
+                        }
+                    }
+                    w0 *= beta;
+                    w1 *= beta;
+                }
+                const float xx[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                bf16x8 vh, vl;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const __bf16 xh = (__bf16)xx[i];
+                    vh[i] = xh;
+                    vl[i] = (__bf16)(xx[i] - (float)xh);
+                    if (APX) {
+                        ww = fmaf(xx[i], xx[i], ww);
+                        wmax = fmaxf(wmax, fabsf(xx[i]));
+                    }
+                }
+                wh[g][ks] = vh;
+                wl[g][ks] = vl;
+            }
+            if constexpr (APX) {
+                // |x - hi| <= 2^-8 |x| for a dish value and for a w value: |sum (lo_d hi_w + hi_d lo_w)| <= 2^-7 (1 + 2^-8)
+                // sum |d_k| |w_k| <= that times |d| |w|; 1.02 covers the norms' and the accumulations' own roundings.
+                // |w|: the root of the sum of squares where that sum is a normal number (squares lost to underflow are then
+                // far below what the 1.02 covers), else sqrt(E) times the largest |w_k| -- never less than |w|
+                ww += __shfl_xor(ww, 32, 64);
+                wmax = fmaxf(wmax, __shfl_xor(wmax, 32, 64));
+                const float nw = (ww >= 1e-30f && ww < INFINITY) ? sqrtf(ww) : sqrtf((float)EU) * wmax;
+                eps[g] = 1.02f * 0.0078125f * nw * rmax_pat;
+            }
+        }
+    };
+
     if (n > 0) {
         ps_0 = next_stage();
         ps_p1 = next_stage();
         issue_pieces(ps_0, 0, 0, PPW);
+        if (first_pat > 0) {                               // (the scan's first needed pattern: its step finds the operands in place;
+                                                           //  0.502 -> 0.500 ms per serving-size call)
+            cur_pat = first_pat;
+            build_operands(first_pat);
+        }
         wait_all_vmem();
         __syncthreads();
         issue_pieces(ps_p1, 1, 0, (APX && KS > AR) ? 4 : PCNT);   // what step "0" of the first stage would have issued
@@ -826,94 +926,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                     accP_exact = true;
                 }
                 cur_pat = gp;
-                const int pat = gp;
-                const float inv_n = 1.0f / (float)__builtin_popcount(pat);
-                const float beta = p.b * inv_n;
-                const float rmax_pat = APX ? __int_as_float(p.grp[GRP_RMAX + pat]) : 0.f;   // the pattern's largest row norm (NaN rows: +inf)
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    float hs = 0.f;
-#pragma unroll
-                    for (int c = 0; c < C; ++c) hs += ((pat >> c) & 1) ? hc[g][c] : 0.f;
-                    alpha[g] = HV ? 0.f : p.a * (hs * inv_n);
-                    // E = 64: the pattern's rows category by category -- a category's eight float4 in flight together, one wait,
-                    // then the adds (the same sums in the same order).  Written k-step by k-step with the category test inside,
-                    // the loads came out as sixteen exec-masked pairs, each waited for before the next was issued: sixteen
-                    // round trips in a row at every pattern switch, with the block's matrix pipe idle
-                    constexpr bool BYCAT = !HV && KS == 4;
-                    v4f wacc[BYCAT ? KS : 1][2];
-                    if constexpr (BYCAT) {
-#pragma unroll
-                        for (int ks = 0; ks < KS; ++ks) wacc[ks][0] = wacc[ks][1] = v4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int c = 0; c < C; ++c) {
-                            if ((pat >> c) & 1) {
-                                v4f ld[KS][2];
-#pragma unroll
-                                for (int ks = 0; ks < KS; ++ks) {
-                                    const v4f *row = pmu[g] + (c + 1) * S4 + 4 * ks + 2 * h;
-                                    ld[ks][0] = row[0];
-                                    ld[ks][1] = row[1];
-                                }
-#pragma unroll
-                                for (int ks = 0; ks < KS; ++ks) {
-                                    wacc[ks][0] += ld[ks][0];
-                                    wacc[ks][1] += ld[ks][1];
-                                }
-                            }
-                        }
-                    }
-                    float ww = 0.f, wmax = 0.f;                          // (APX) sum of squares and largest magnitude of this lane's half of w_P[u]
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) {                   // unrolled: every register index is static
-                        v4f w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
-                        if constexpr (BYCAT) {
-                            w0 = wacc[ks][0] * beta;
-                            w1 = wacc[ks][1] * beta;
-                        } else
-                        if (HV && ks < KS / 2) {                        // k < EU: a U_high against H[d]
-                            const v4f *row = pmu[g] + 4 * ks + 2 * h;
-                            w0 = row[0] * p.a;
-                            w1 = row[1] * p.a;
-                        } else {
-                            const int kk = HV ? ks - KS / 2 : ks;       // k - EU: w_P against RE[d]
-#pragma unroll
-                            for (int c = 0; c < C; ++c) {
-                                if ((pat >> c) & 1) {
-                                    const v4f *row = pmu[g] + (c + 1) * S4 + 4 * kk + 2 * h;
-                                    w0 += row[0];
-                                    w1 += row[1];
-                                }
-                            }
-                            w0 *= beta;
-                            w1 *= beta;
-                        }
-                        const float xx[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-                        bf16x8 vh, vl;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const __bf16 xh = (__bf16)xx[i];
-                            vh[i] = xh;
-                            vl[i] = (__bf16)(xx[i] - (float)xh);
-                            if (APX) {
-                                ww = fmaf(xx[i], xx[i], ww);
-                                wmax = fmaxf(wmax, fabsf(xx[i]));
-                            }
-                        }
-                        wh[g][ks] = vh;
-                        wl[g][ks] = vl;
-                    }
-                    if constexpr (APX) {
-                        // |x - hi| <= 2^-8 |x| for a dish value and for a w value: |sum (lo_d hi_w + hi_d lo_w)| <= 2^-7 (1 + 2^-8)
-                        // sum |d_k| |w_k| <= that times |d| |w|; 1.02 covers the norms' and the accumulations' own roundings.
-                        // |w|: the root of the sum of squares where that sum is a normal number (squares lost to underflow are then
-                        // far below what the 1.02 covers), else sqrt(E) times the largest |w_k| -- never less than |w|
-                        ww += __shfl_xor(ww, 32, 64);
-                        wmax = fmaxf(wmax, __shfl_xor(wmax, 32, 64));
-                        const float nw = (ww >= 1e-30f && ww < INFINITY) ? sqrtf(ww) : sqrtf((float)EU) * wmax;
-                        eps[g] = 1.02f * 0.0078125f * nw * rmax_pat;
-                    }
-                }
+                build_operands(gp);
             }
             if (nvalid == 32) {
                 // the steps of this stage after this one multiply tiles pt_next, pt_next + 1, ... of the stage ps_0: plain as long
