@@ -1292,10 +1292,11 @@ def main():
             # the hi x hi first form (large catalogues): one product per tile stepped through, the two cross
             # products for the share of (wave, tile) pairs that could still hold a candidate (the step's last launch stands for the step)
             cross_share = None
-            if x3 and kernel_used.startswith("m2d_topk_grouped") and not a.topk_with_ingredients:
+            if x3 and kernel_used.startswith("m2d_topk_grouped"):
                 cmp_ = eng.get_option("topk_tiles_completed")
-                if cmp_ >= 0 and sc_ > 0:
-                    cross_share = cmp_ * 32.0 / (sc_ * eng.get_option("topk_block_users"))
+                sc2_ = eng.get_option("topk_tiles_scanned")              # (with the ingredient table: every tile, no pattern is pruned)
+                if cmp_ >= 0 and sc2_ > 0:
+                    cross_share = cmp_ * 32.0 / (sc2_ * eng.get_option("topk_block_users"))
                     tf = tf / 3.0 * (1.0 + 2.0 * cross_share)
             peak = 2500.0 if x3 else 157.3
             line["config"]["workload"] = (("BASELINE configs[%d]: %d users over %d GPU(s) (%d per GPU) x %d replicated dishes, E=%d: "

@@ -42,6 +42,27 @@ __global__ __launch_bounds__(256) void m2d_grp_norm_stats(const float *re, int64
     }
 }
 
+// ingredient form: the largest |RE[d]| of the catalogue (the groups' norms above are H[d]'s), for the hi x hi first form's bound; float
+// bits order like the values for non-negative floats, a NaN norm counts as +inf
+__global__ __launch_bounds__(256) void m2d_grp_max_norm(const float *re, int64_t I, int E, int32_t *out_bits)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t d0 = (int64_t)blockIdx.x * 256 + wave * 64;
+    float mx = 0.f;
+    for (int r = 0; r < 64 && d0 + r < I; ++r) {
+        float q = 0.f;
+        for (int e = lane; e < E; e += 64) {
+            const float x = re[(d0 + r) * E + e];
+            q = fmaf(x, x, q);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+        const float nr = sqrtf(q);
+        mx = fmaxf(mx, nr == nr ? nr : INFINITY);
+    }
+    if (lane == 0) atomicMax(out_bits, __float_as_int(mx));
+}
+
 __global__ void m2d_grp_norm_params(const double *acc, int64_t I, float *stat)
 {
     const double mean = acc[0] / (double)I;
@@ -640,6 +661,8 @@ int ensure_grouped(m2d_engine *h, hipStream_t st)
     // scan order by the norm of the row that carries the larger term: H[d] (weight a) when the ingredient table is set
     hipLaunchKernelGGL(m2d_grp_norm_stats, dim3(nblk), dim3(256), 0, st, h->dish_high ? h->dish_high : h->re, I, h->E, norm, acc);
     hipLaunchKernelGGL(m2d_grp_norm_params, dim3(1), dim3(1), 0, st, acc, I, stat);
+    M2D_HIP_TRY(h, hipMemsetAsync(stat + 2, 0, sizeof(float), st));            // stat[2]: the largest |RE[d]| (ingredient form only)
+    if (h->dish_high) hipLaunchKernelGGL(m2d_grp_max_norm, dim3(nblk), dim3(256), 0, st, h->re, I, h->E, reinterpret_cast<int32_t *>(stat + 2));
     M2D_HIP_TRY(h, hipMemsetAsync(grp + GRP_RMAX, 0, 16 * sizeof(int32_t), st));
     hipLaunchKernelGGL(m2d_grp_hist, dim3(nblk), dim3(256), 0, st, h->dish_cats, norm, stat, I, h->C, blk_hist, flags, grp + GRP_RMAX);
     hipLaunchKernelGGL(m2d_grp_scan, dim3(1), dim3(GRP_KEYS * GRP_SCAN_SPLIT), 0, st, blk_hist, nblk, grp, h->grp_tile_info);
@@ -753,8 +776,10 @@ int launch_grouped(m2d_engine *h, const int E8, const int KR, const bool BF16X3,
     // than 10 240 at E = 128.  The rule looks at the catalogue alone: that form's scores are not the three-product kernels' bits, and
     // every launch shape of one problem must return the same lists (blocks of 256 users there: "topk_block" = 128 is not
     // honoured).  "topk_form" 3 / 4 (diagnostic): that form for any catalogue / never.
-    const bool apx = BF16X3 && !HV && pipe && (E == 64 || E == 128) && h->opt_topk_form != 4 &&
-                     (h->grp_tiles > (E == 64 ? 24576 : 10240) || h->opt_topk_form == 3);
+    // (The ingredient form multiplies every tile -- no pattern can be pruned -- so tiles with a candidate are the exception from
+    //  small catalogues on: 65 536 users x 20 k dishes 0.89 -> 0.64 ms, 100 k 3.79 -> 2.09 ms, 1 M 36.3 -> 18.5; more than 256 tiles.)
+    const bool apx = BF16X3 && pipe && (E == 64 || E == 128) && h->opt_topk_form != 4 &&
+                     (h->grp_tiles > (HV ? 256 : (E == 64 ? 24576 : 10240)) || h->opt_topk_form == 3);
     const bool half = half_ok && !apx && (h->opt_topk_block == 128 || (h->opt_topk_block == 0 && M2D_TOPK_HALF_BLOCKS && h->opt_topk_prune != 0 &&
                                                               h->opt_variant < 100 && nU >= 16384 && h->grp_tiles <= 8192));
     const int WV = half ? 4 : WAVES;                         // waves per block

@@ -283,7 +283,7 @@ __device__ __forceinline__ void diag_mfma16(v16f &acc, const int ks, const bf16x
 template <int E, int KR, int G, bool HV = false, int WAVES = 8 / G, bool KEEP = false, bool APX = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(GroupedArgs p)
 {
-    static_assert(!APX || ((E == 64 || E == 128) && !HV && WAVES == 8 && G == 1), "the hi x hi first form: blocks of eight waves");
+    static_assert(!APX || ((E == 64 || E == 128) && WAVES == 8 && G == 1), "the hi x hi first form: blocks of eight waves");
     constexpr int C = 4;
     constexpr int KS = E / 16;                             // k-steps (16 k-values) per tile
     constexpr int S8 = E / 8;                              // 16-B slots per bf16 row
@@ -522,6 +522,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
         const float inv_n = 1.0f / (float)__builtin_popcount(pat);
         const float beta = p.b * inv_n;
         const float rmax_pat = APX ? __int_as_float(p.grp[GRP_RMAX + pat]) : 0.f;   // the pattern's largest row norm (NaN rows: +inf)
+        const float rmax_re = (APX && HV) ? __int_as_float(p.grp[GRP_STAT + 2]) : 0.f;   // ingredient form: rmax_pat is of H[d], this the largest |RE[d]|
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float hs = 0.f;
@@ -556,6 +557,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                 }
             }
             float ww = 0.f, wmax = 0.f;                          // (APX) sum of squares and largest magnitude of this lane's half of w_P[u]
+            float wwh = 0.f, wmaxh = 0.f;                        // (APX, ingredient form) the same of a U_high, whose k-values meet H[d]
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {                   // unrolled: every register index is static
                 v4f w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
@@ -588,8 +590,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                     vh[i] = xh;
                     vl[i] = (__bf16)(xx[i] - (float)xh);
                     if (APX) {
-                        ww = fmaf(xx[i], xx[i], ww);
-                        wmax = fmaxf(wmax, fabsf(xx[i]));
+                        if (HV && ks < KS / 2) {
+                            wwh = fmaf(xx[i], xx[i], wwh);
+                            wmaxh = fmaxf(wmaxh, fabsf(xx[i]));
+                        } else {
+                            ww = fmaf(xx[i], xx[i], ww);
+                            wmax = fmaxf(wmax, fabsf(xx[i]));
+                        }
                     }
                 }
                 wh[g][ks] = vh;
@@ -603,7 +610,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
                 ww += __shfl_xor(ww, 32, 64);
                 wmax = fmaxf(wmax, __shfl_xor(wmax, 32, 64));
                 const float nw = (ww >= 1e-30f && ww < INFINITY) ? sqrtf(ww) : sqrtf((float)EU) * wmax;
-                eps[g] = 1.02f * 0.0078125f * nw * rmax_pat;
+                if constexpr (HV) {                         // two operand halves, two row halves: |a U_high| against |H[d]|, |w_P| against |RE[d]|
+                    wwh += __shfl_xor(wwh, 32, 64);
+                    wmaxh = fmaxf(wmaxh, __shfl_xor(wmaxh, 32, 64));
+                    const float nh = (wwh >= 1e-30f && wwh < INFINITY) ? sqrtf(wwh) : sqrtf((float)EU) * wmaxh;
+                    eps[g] = 1.02f * 0.0078125f * (nh * rmax_pat + nw * rmax_re);
+                } else
+                    eps[g] = 1.02f * 0.0078125f * nw * rmax_pat;
             }
         }
     };
@@ -1188,6 +1201,7 @@ int M2D_SCAN_LAUNCH(m2d_engine *h, const GroupedArgs &a, const ScanShape &s, dim
 #define M2D_SCAN_BF16(EV, KRV)                                                                                                   \
     if (s.E == EV && s.KR == KRV) {                                                                                               \
         constexpr bool CAN_KEEP = !(EV == 128 && KRV == 16);                                                                      \
+        if (s.hv && s.apx) M2D_SCAN_GO((m2d_topk_grouped_bf16_pipe2<EV, KRV, 1, true, 8, false, true>), 512)                      \
         if (s.hv) M2D_SCAN_GO((m2d_topk_grouped_bf16_pipe2<EV, KRV, 1, true>), 512)                                               \
         if (!s.pipe) M2D_SCAN_GO((m2d_topk_grouped_bf16<EV, 8, KRV>), 512)                                                        \
         if constexpr (EV == 64) {                                                                                                 \

@@ -263,7 +263,8 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
  * mlp_form         0        0 / 1        split-bf16 head kernel: 0 = matrix waves fed by gather / DMA waves, 1 = every wave gathers its own rows
  *                                        (same results within the split's rounding)
  * topk_form        0        0 ... 4      split-bf16 retrieval kernel: 0 / 2 = pipelined form, 1 = first form (same lists).  Large catalogues (more than
- *                                        24 576 tiles of 32 dishes at E = 64, more than 10 240 at E = 128): the pipelined form multiplies the hi x hi
+ *                                        24 576 tiles of 32 dishes at E = 64, more than 10 240 at E = 128; with the ingredient table, where every tile
+ *                                        is multiplied, more than 256): the pipelined form multiplies the hi x hi
  *                                        product of every tile and the two cross products only for tiles that can still hold a candidate -- scores
  *                                        are within the split's rounding of the three-product kernels' but not their bits, which is why the rule looks
  *                                        at the catalogue alone (blocks of 256 users; "topk_block" = 128 is not honoured there).  3 = that form for

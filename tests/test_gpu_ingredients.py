@@ -140,8 +140,9 @@ def test_abort_shape_from_round_1_repeated_in_one_process():
         gc.collect()
 
 
+@pytest.mark.parametrize("form", [4, 3])                   # the three-product form / the hi x hi first form ("topk_form"; the default picks by size)
 @pytest.mark.parametrize("E,k", [(64, 10), (32, 10), (64, 16), (32, 3)])
-def test_retrieval_with_the_ingredient_table_on_the_grouped_kernel(E, k):
+def test_retrieval_with_the_ingredient_table_on_the_grouped_kernel(E, k, form):
     """Catalogue retrieval with the ingredient table set: dish rows become [H[d] | RE[d]] and the user operand
     [a U_high | w_P], so the pattern-grouped split-bf16 kernel serves it (contraction over 2 E instead of the dense
     kernel's 5 E on exact f32).  Checked against the float64 restatement over the whole catalogue and against the dense
@@ -160,9 +161,16 @@ def test_retrieval_with_the_ingredient_table_on_the_grouped_kernel(E, k):
     eng = ScoringEngine(PM, RE, CE)
     eng.set_dish_categories(dish_cats)
     eng.set_ingredients(ING, off, ids, w)
+    eng.set_option("topk_form", form)
     users = torch.arange(U, dtype=torch.int32, device="cuda")
     s, idx = eng.topk_users(users, k); eng.check()
     assert eng.last_kernel() == "m2d_topk_grouped_bf16x3"
+    assert (eng.get_option("topk_tiles_completed") >= 0) == (form == 3)
+    for forced in (101, 103):                                   # dish ranges: the same lists bit for bit in either form
+        eng.set_option("variant", forced)
+        sv, iv = eng.topk_users(users, k); eng.check()
+        assert torch.equal(iv, idx) and torch.equal(sv.view(torch.int32), s.view(torch.int32)), forced
+    eng.set_option("variant", 0)
     eng.set_option("topk_grouped", 0)
     sd, idd = eng.topk_users(users, k); eng.check()
     assert eng.last_kernel() == "m2d_topk_mfma"
