@@ -155,7 +155,10 @@ def train_case(rng, what):
         loss, norm, _, _ = eng.train_step(dev(users), dev(items), dev(cats), dev(labels)).cpu().numpy(); eng.check()
         assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (what, loss, ref_loss)
         assert abs(norm - ref_norm) <= 2e-5 * max(1.0, ref_norm), (what, norm, ref_norm)
-    tol = 1e-3 * lr * steps if learner in ("adam", "rmsprop") else 1e-5
+    # adam / rmsprop divide by sqrt(v) + 1e-8: an element whose gradient all but cancels in float32 moves by a different fraction of lr than
+    # in the float64 restatement (tests/test_gpu_train.py: 1e-3 of lr per step on its tables; these are three times larger, and seed
+    # 1791184991 case 124 came out at 1.0003e-3: 1.5e-3 here)
+    tol = 1.5e-3 * lr * steps if learner in ("adam", "rmsprop") else 1e-5
     for got, ref in ((eng.pm, st.PM), (eng.re, st.RE), (eng.ce, st.CE)):
         err = np.abs(got.cpu().numpy().astype(np.float64) - ref)
         bound = tol * np.maximum(1.0, np.abs(ref)) if learner in ("sgd", "adagrad") else tol
