@@ -113,7 +113,9 @@ COEF_CASES = [c + (coef,) for coef in COEFS for c in (("anti", 64, 1, 1e-4, 6.0,
 # the split-bf16 cases again under the hi x hi first form of the pipelined kernel ("topk_form" 3; x3 = 3 below): the tiles'
 # cross products are multiplied only where hi x hi comes within a bound of a threshold -- under cancellation the scores that
 # matter are small beside |w| |r|, which is what that bound is made of
-HI_FIRST_CASES = [(c[0], c[1], 3) + c[3:] + (0.99,) for c in CASES if c[2] == 1] + [(c[0], c[1], 3) + c[3:] for c in COEF_CASES if c[2] == 1]
+HI_FIRST_CASES = [(c[0], c[1], 3) + c[3:] + (0.99,) for c in CASES if c[2] == 1 and (c[3], c[4]) in ((1e-4, 1.0), (1e-4, 6.0), (1e-5, 30.0), (0.0, 1.0), (1e-4, 30.0),
+                                                                                         (1e-5, 6.0), (1e-6, 30.0), (1e-3, 0.05), (1e-5, 1.0))] + \
+                 [(c[0], c[1], 3) + c[3:] for c in COEF_CASES if c[2] == 1 and c[-1] in (0.0, 0.5, 1.25)]
 
 
 @pytest.mark.parametrize("style,E,x3,eps,low_scale,I,coef", [c + (0.99,) for c in CASES] + COEF_CASES + HI_FIRST_CASES)
