@@ -332,6 +332,7 @@ def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10, ke
             "roofline": ({"bound": "mfma", "achieved": ex3 / ms / 1e9, "peak": 2500.0, "unit": "TFLOP/s",
                           "frac": ex3 / ms / 1e9 / 2500.0, "flop_per_pair": ex3 / n_users / I,
                           "hi_first_form": completed >= 0, "wave_tiles_given_cross_products": (completed if completed >= 0 else None),
+                          "frac_if_priced_as_three_products": (3 * flops / ms / 1e9 / 2500.0 if completed >= 0 else None),
                           "tiles_scanned": scanned, "tiles_without_pruning": full,
                           "scanned_fraction": (scanned / full if scanned and full else None),
                           "frac_if_every_tile_were_scanned": 3 * 2.0 * E * n_users * I / ms / 1e9 / 2500.0,
@@ -1316,6 +1317,8 @@ def main():
                                 "dense_equivalent_tflops": 2.0 * K * units / (avg_ms * 1e-3) / 1e12,
                                 "scanned_fraction": scanned_frac, "frac_if_every_tile_were_scanned": tf_all / peak,
                                 "hi_first_form": cross_share is not None, "share_of_wave_tiles_given_cross_products": cross_share,
+                                # the same tiles priced as the three-product form would execute them: the rate the hi x hi first form is worth
+                                "frac_if_priced_as_three_products": (tf * 3.0 / (1.0 + 2.0 * cross_share) / peak if cross_share is not None else None),
                                 "note": "`frac` prices the flops EXECUTED (the tiles the blocks stepped through), and `value` counts the pairs "
                                         "of those tiles; pairs_decided_per_s counts every (user, dish) pair of the catalogue -- most are "
                                         "decided by a bound, without being multiplied",
