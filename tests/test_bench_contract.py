@@ -25,6 +25,82 @@ def test_algorithmic_bytes_follow_survey_8d():
     assert b.HBM_PEAK_GBS == 8000.0
 
 
+def test_hbm_only_never_exceeds_the_stream_probe_unlabelled():
+    """benchlib.pairs.hbm_only_estimate: dish rows count as HBM bytes only when the dish table cannot be cache-resident
+    (capacity, not half of it), and a figure above the box's streaming-read probe carries the label `includes cache-served
+    bytes` and no frac_of_stream_probe (round 5 published 1.105 x the probe as HBM-only)."""
+    from benchlib import pairs
+    from benchlib.common import INFINITY_CACHE_BYTES
+    n, C, E = 1 << 20, 4, 64
+    # 1 M dishes x 64 x 4 = 256 000 000 B <= 256 MiB: fits -> assumed cache-served, left out
+    fits = pairs.hbm_only_estimate(n, C, E, 1_000_000, 4.0, 0.25, 5700.0)
+    assert 1_000_000 * E * 4 <= INFINITY_CACHE_BYTES and fits["dish_rows"].startswith("assumed cache-served")
+    assert fits["bytes_per_launch"] == n * (5 * E * 4 + C * 4 + 12)
+    # 1 M dishes x 128 x 4 = 512 MB: cannot be resident -> counted
+    big = pairs.hbm_only_estimate(n, C, 128, 1_000_000, 4.0, 0.6, 5700.0)
+    assert big["dish_rows"].startswith("counted") and big["bytes_per_launch"] == n * (6 * 128 * 4 + C * 4 + 12)
+    for est in (fits, big, pairs.hbm_only_estimate(n, C, 128, 1_000_000, 4.0, 0.5, 5700.0)):
+        over = est["achieved"] > 1.02 * 5700.0
+        assert (est["label"] == pairs.CACHE_LABEL) == over
+        assert (est["frac_of_stream_probe"] is None) == over
+        if not over:
+            assert est["frac_of_stream_probe"] <= 1.02
+
+
+def test_committed_bench_lines_of_this_round_parse_and_respect_the_probe():
+    """profiles/r06_bench_*.json: each file is ONE JSON object (bench.py --out), no frac_of_stream_probe above 1.02
+    anywhere in it, and config.workload within 200 characters."""
+    import glob
+
+    def walk(o, path=""):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                yield from walk(v, path + "/" + k)
+        elif isinstance(o, list):
+            for i, v in enumerate(o):
+                yield from walk(v, path + "/%d" % i)
+        else:
+            yield path, o
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r06_bench_*.json"))):
+        line = json.load(open(f))
+        for path, v in walk(line):
+            if path.endswith("frac_of_stream_probe") and v is not None:
+                assert v <= 1.02, (f, path, v)
+        assert len(line["config"]["workload"]) <= 200, (f, len(line["config"]["workload"]))
+
+
+def test_top_level_scalars_of_the_default_line():
+    """benchlib.line.config_scalars: one scalar per BASELINE config and roofline figure, taken from the nested legs."""
+    from benchlib import line as linelib
+    nested = {"value": 6.5e9, "n_gpus": 1, "config": {"workload": "BASELINE configs[1]: x"},
+              "roofline": {"bound": "hbm", "frac": 0.88, "survey_8d_pairs_per_s": 4.6e9, "survey_8d_frac": 0.91,
+                           "hbm_only_frac_of_spec": 0.73, "hbm_only_masked_frac_of_spec": 0.66, "stream_probe_GBps": 6100.0},
+              "config2_mlp": {"pairs_per_s": 1.3e9, "kernel_avg_ms": 1.6, "roofline": {"frac": 0.35}, "max_rel_vs_restatement": 2e-6},
+              "config4_topk": {"round_ms": 28.0, "round_users": 500000, "roofline": {"frac": 0.3}},
+              "with_ingredient_table": {"pairs_per_s": 5.6e9, "frac": 0.94},
+              "catalogue_topk": {"roofline": {"frac": 0.2}, "every_tile": {"roofline": {"frac": 0.46}}},
+              "scaling_path": {"wall_ms": 326.0, "roofline_frac_of_mfma_peak": 0.43}}
+    sc = linelib.config_scalars(nested)
+    for key in ("cfg2_mlp_e128_pairs_per_s", "cfg2_mlp_e128_ms", "cfg2_mlp_mfma_frac", "cfg2_mlp_max_rel_vs_restatement",
+                "cfg4_topk_e128_round_ms", "cfg4_topk_e128_mfma_frac", "cfg1_ingredients_pairs_per_s", "survey_8d_pairs_per_s",
+                "survey_8d_frac", "hbm_only_frac_of_spec", "hbm_only_masked_frac_of_spec", "stream_probe_GBps",
+                "topk_every_tile_frac", "cfg1_pairs_per_s", "cfg3_topk_e64_path_ms", "parity"):
+        assert key in sc, key
+        assert not isinstance(sc[key], (dict, list))
+    assert sc["cfg2_mlp_mfma_frac"] == 0.35 and sc["topk_every_tile_frac"] == 0.46 and sc["parity"].startswith("partial")
+    assert "cfg2_mlp_e128_ms" not in linelib.config_scalars({"value": 1.0, "n_gpus": 1, "config": {}, "roofline": {}})
+
+
+def test_bench_sources_stay_auditable():
+    """bench.py and benchlib/: lines of at most 120 characters; bench.py itself under 500 lines."""
+    import glob
+    files = [os.path.join(ROOT, "bench.py")] + sorted(glob.glob(os.path.join(ROOT, "benchlib", "*.py")))
+    for f in files:
+        for i, l in enumerate(open(f).read().splitlines(), 1):
+            assert len(l) <= 120, (f, i, len(l))
+    assert len(open(files[0]).read().splitlines()) < 500
+
+
 def test_flags_and_defaults(monkeypatch):
     b = _bench()
     monkeypatch.setattr(sys, "argv", ["bench.py"])
@@ -70,6 +146,9 @@ def test_gpus_n_starts_n_ranks_by_itself():
     line = lines[0]
     assert line["n_gpus"] == 2 and line["dry_run"] is True and line["value"] is None and line["steps"] == 3
     assert line["config"]["shards"] == [[0, 0, 101], [1, 101, 101]]            # rank, user base, users per shard
+    # the N > 1 line is self-verifying: two ranks seen, two distinct "devices" (processes here), the backend named
+    assert line["ranks_seen"] == 2 and line["distinct_devices"] == 2 and line["dist_backend"] == "gloo"
+    assert line["world"]["world_size"] == 2 and len(line["world"]["device_ids"]) == 2
     # a rank that fails makes the parent fail too
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
                          env=dict(env, M2D_BENCH_DRYRUN_FAIL_RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
@@ -143,6 +222,13 @@ def _legs_worker(rank, world, port, out_dir):
             assert key in r2, key
         assert r2["path"] == "sharded_topk_allgather" and r2["rounds_per_gpu"] == 4 and r2["users_total"] == U
         assert r2["own_slice_roundtrip_ok"] is True and r2["allgather_bytes_per_rank"] == U_per * k * 8
+        # per rank, so that a straggler shows in an N > 1 record
+        assert len(r2["shard_ms_per_rank"]) == world and len(r2["allgather_exposed_ms_per_rank"]) == world
+        assert r2["allgather_exposed_ms_max"] >= r2["allgather_exposed_ms_min"] >= 0.0
+        assert max(r2["shard_ms_per_rank"]) == r2["wall_ms"]
+        ident = b.world_identity(torch, dist, dev, world, rank)
+        assert ident["ranks_seen"] == world and ident["distinct_devices"] == world and ident["backend"] == "gloo"
+        assert ident["world_size"] == world and "rccl_version" in ident
         # what the rounds produce is what one call produces, on every rank
         s_all, i_all = sh.topk_all_users(k, round_users=7)
         s_one, i_one = sh.topk_all_users(k)
