@@ -1,6 +1,5 @@
 // extern "C" surface of libm2d.so -- see include/m2d.h for the contract and the reference
 // interfaces each entry point replaces.  No exceptions cross this boundary.
-#include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
@@ -12,36 +11,23 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// plain streaming read.  MODE 0: 4 x 16 B in flight per lane, the four loads a whole grid stride apart (round 1-5's probe);
-// MODE 1 / 2: every block sweeps ONE contiguous slice of the buffer, 4 / 8 x 16 B in flight per lane, the loads of an iteration
-// adjacent (a wave reads 4 / 8 consecutive KiB); NT: non-temporal loads
-template <int MODE, bool NT>
+// plain streaming read: 4 x 16 B in flight per lane, non-temporal, the four loads a whole grid stride apart, TWO workgroups per CU.
+// Round 6 sweep on MI355X over the 1.28 GB Personal_Memory (profiles/r06_stream_probe_sweep.txt):
+// this form 6 970-7 000 GB/s at 2-3 workgroups per CU against 5 560-5 840 at 4-16 (round 1-5's launch: 8 per CU), 6 250 at 32;
+// plain loads 6 310 at 2 per CU; block-contiguous slices (4 or 8 x 16 B per lane) 6 610-6 740 at 2 per CU.
 __global__ __launch_bounds__(256) void m2d_stream_read(const v4f *p, int64_t n4, float *sink)
 {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     v4f acc = {0.f, 0.f, 0.f, 0.f};
-    auto ld = [](const v4f *q) { return NT ? __builtin_nontemporal_load(q) : *q; };
-    if (MODE == 0) {
-        const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-        int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        for (; i + 3 * stride < n4; i += 4 * stride) {
-            const v4f a = ld(p + i), b = ld(p + i + stride), c = ld(p + i + 2 * stride), d = ld(p + i + 3 * stride);
-            acc += (a + b) + (c + d);
-        }
-        for (; i < n4; i += stride) acc += ld(p + i);
-    } else {
-        constexpr int U = MODE == 1 ? 4 : 8;
-        const int64_t per = (n4 + gridDim.x - 1) / gridDim.x;                 // this block's slice [lo, hi)
-        const int64_t lo = per * blockIdx.x, hi = lo + per < n4 ? lo + per : n4;
-        int64_t i = lo + threadIdx.x;
-        for (; i + (U - 1) * 256 < hi; i += U * 256) {
-            v4f t[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) t[u] = ld(p + i + u * 256);
-#pragma unroll
-            for (int u = 0; u < U; u += 2) acc += t[u] + t[u + 1];
-        }
-        for (; i < hi; i += 256) acc += ld(p + i);
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const v4f a = __builtin_nontemporal_load(p + i);
+        const v4f b = __builtin_nontemporal_load(p + i + stride);
+        const v4f c = __builtin_nontemporal_load(p + i + 2 * stride);
+        const v4f d = __builtin_nontemporal_load(p + i + 3 * stride);
+        acc += (a + b) + (c + d);
     }
+    for (; i < n4; i += stride) acc += __builtin_nontemporal_load(p + i);
     const float s = (acc.x + acc.y) + (acc.z + acc.w);
     if (s == 123456.789f) sink[0] = s;   // keeps the loads live; practically never true
 }
@@ -765,20 +751,8 @@ int m2d_stream_read_probe(m2d_engine *h, const void *buf, int64_t bytes, float *
     if (!h || !buf || !sink || bytes <= 0 || (bytes & 15) || !aligned16(buf))
         return fail(h, M2D_ERR_INVALID_ARG, "m2d_stream_read_probe: need a 16-byte aligned buffer and size");
     M2D_HIP_TRY(h, hipSetDevice(h->device));
-    // (experiment seam, round 6: M2D_PROBE_MODE = mode * 2 + nt, M2D_PROBE_GRID = blocks per CU)
-    const char *em = getenv("M2D_PROBE_MODE"), *eg = getenv("M2D_PROBE_GRID");
-    const int mode = em ? atoi(em) : 1, bpc = eg ? atoi(eg) : 8;
-    const dim3 grid(h->num_cu * (bpc > 0 ? bpc : 8));
-    const v4f *p4 = reinterpret_cast<const v4f *>(buf);
-    hipStream_t st = (hipStream_t)stream;
-    switch (mode) {
-    case 0: hipLaunchKernelGGL((m2d_stream_read<0, false>), grid, dim3(256), 0, st, p4, bytes / 16, sink); break;
-    case 1: hipLaunchKernelGGL((m2d_stream_read<0, true>), grid, dim3(256), 0, st, p4, bytes / 16, sink); break;
-    case 2: hipLaunchKernelGGL((m2d_stream_read<1, false>), grid, dim3(256), 0, st, p4, bytes / 16, sink); break;
-    case 3: hipLaunchKernelGGL((m2d_stream_read<1, true>), grid, dim3(256), 0, st, p4, bytes / 16, sink); break;
-    case 4: hipLaunchKernelGGL((m2d_stream_read<2, false>), grid, dim3(256), 0, st, p4, bytes / 16, sink); break;
-    default: hipLaunchKernelGGL((m2d_stream_read<2, true>), grid, dim3(256), 0, st, p4, bytes / 16, sink); break;
-    }
+    hipLaunchKernelGGL(m2d_stream_read, dim3(h->num_cu * 2), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const v4f *>(buf), bytes / 16, sink);
     M2D_HIP_TRY(h, hipGetLastError());
     return M2D_OK;
 }

@@ -1159,9 +1159,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
         atomicAdd(p.tiles_scanned, (wave == 0 ? (unsigned long long)n : 0ull) + ((unsigned long long)n_completed << 36));
 #if M2D_DIAG & 16
     if (lane == 0 && p.dbg) {
-        unsigned long long *d = p.dbg + ((size_t)(by * ((p.nU + 255) / 256) + bx) * WAVES + wave) * 8;
+        // one record per (workgroup, wave) in launch order (a 128-user launch has more user blocks than (nU + 255) / 256: the
+        // round-5 index by (range, user block) made its records overwrite one another)
+        unsigned long long *d = p.dbg + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVES + wave) * 8;
         d[0] = t_body; d[1] = n_ins; d[2] = t_bar; d[3] = t_slow; d[4] = n_slow; d[5] = n_step;
         d[6] = __builtin_amdgcn_s_memtime() - clk0; d[7] = __builtin_amdgcn_s_memrealtime() - rt0;
+#if M2D_DIAG & 8192
+        // the launch's time line (topk_diag M2D_DIAG_DUMP): when the wave started (100 MHz, low 40 bits) beside its duration, and
+        // which (user block, dish range) it ran beside its insert count
+        d[7] = ((rt0 & 0xffffffffffull) << 24) | (d[7] & 0xffffffull);
+        d[1] = (n_ins & 0xfffffull) | ((unsigned long long)(unsigned)bx << 20) | ((unsigned long long)(unsigned)by << 52);
+#endif
 #if M2D_DIAG & 32
         d[7] = t_slow_first; d[1] = n_slow_first;          // candidate handling of an item's first stage (steps 1 .. TPS + 2)
 #endif

@@ -85,6 +85,12 @@ int main(int argc, char **argv)
     {
         std::vector<unsigned long long> hd((size_t)1048576 * 8);
         hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
+        if (getenv("M2D_DIAG_DUMP")) {                      // raw records of the LAST launch, for scripts/diag/scan_breakdown.py
+            FILE *f = fopen(getenv("M2D_DIAG_DUMP"), "wb");
+            size_t nrec = hd.size() / 8;
+            while (nrec > 0 && hd[(nrec - 1) * 8 + 6] == 0) --nrec;
+            if (f) { fwrite(hd.data(), 64, nrec, f); fclose(f); printf("dumped %zu wave records, %d users per block\n", nrec, h.topk_block_users); }
+        }
         double m = 0, e = 0, b = 0, sl = 0, ns = 0, st = 0, ck = 0, rt = 0, nw = 0, maxck = 0;
         for (int w = 0; w < 1048576; ++w) { m += hd[w*8]; e += hd[w*8+1]; b += hd[w*8+2]; sl += hd[w*8+3]; ns += hd[w*8+4]; st += hd[w*8+5]; ck += hd[w*8+6]; rt += hd[w*8+7]; nw += hd[w*8+6] != 0; if ((double)hd[w*8+6] > maxck) maxck = (double)hd[w*8+6]; }
 #if M2D_DIAG & 32
