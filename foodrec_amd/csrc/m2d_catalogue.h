@@ -65,6 +65,7 @@ struct GroupedArgs {
     int32_t *err;
     unsigned long long *dbg;   // scripts/diag only
     int32_t e_real;            // padded form only: the tables' E (rows of `rs` are zero-padded to the kernel's E)
+    int32_t prog_limit;        // hi x hi first form, E = 64: polls of the progress words before a wave gives up (M2D_ERR_KERNEL_TIMEOUT)
     float *tie_val;            // [nU, nsplit] the list's last score when a tie decides what it holds (tie_at_boundary), else NaN
     const float *plan;         // [nU, 8] per user of the call: scan-start bound, <U_high, CE_c> x 4, relevant-pattern mask (m2d_topk_user_plan)
     const int32_t *order;      // [nU] position in the launch -> index into users / plan (users sorted by pattern mask), or null

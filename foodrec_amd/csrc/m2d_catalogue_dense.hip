@@ -475,7 +475,7 @@ int m2d_topk_dense_launch(m2d_engine *h, const int32_t *users, int64_t nU, int32
         const int NB = K / 8;
         // list space: 8 waves up to k = 16, 2 waves beyond (LDS: 2 stages + waves * k * 512 B)
         // k <= 16: register-resident lists (10 or 16 slots); beyond: LDS lists, 2 waves (LDS: 2 stages + waves*k*512 B)
-        const bool lds_lists = k > 16 || h->opt_variant == 8;
+        const bool lds_lists = k > 16;
 #define M2D_TOPK(NBV, WV)                                                                              \
     if (NB == NBV) {                                                                                  \
         if (lds_lists) return launch_mfma<NBV, 2, 0>(h, a, out_scores, out_ids, stream);               \

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void m2d_topk_user_plan(const float *pm, const
     // diagnostic, the sort's histogram -- three memset launches less per call
     {
         const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-        if (gid == 0) { *zero_tie = 0; *zero_tiles = 0ull; }
+        if (gid == 0) { *zero_tie = 0; zero_tiles[0] = 0ull; zero_tiles[1] = 0ull; }
         if (gid < 4 && zero_refine) zero_refine[gid] = 0;   // m2d_topk_refine's counters
         if (zero_hist)
             for (int64_t i = gid; i < nhist; i += (int64_t)gridDim.x * 256) zero_hist[i] = 0;
@@ -792,6 +792,7 @@ int launch_grouped(m2d_engine *h, const int E8, const int KR, const bool BF16X3,
     a.grp = h->grp_work + (size_t)((h->I + 255) / 256) * GRP_KEYS;
     a.users = users; a.nU = nU; a.U = h->U; a.user_base = h->user_base; a.k = k; a.tiles = h->grp_tiles;
     a.a = h->a; a.b = h->b; a.err = h->err_dev; a.dbg = g_m2d_diag_buffer; a.e_real = h->E;
+    a.prog_limit = h->opt_variant == 15 ? 0 : (1 << 24);   // "variant" 15: test hook of the progress-word timeout
     a.plan = nullptr; a.order = nullptr; a.tiles_scanned = nullptr; a.items = nullptr; a.shared_thr = nullptr; a.ex_out = nullptr;
     const int64_t ublocks = (nU + 32 * WV - 1) / (32 * WV);
     int nsplit = pick_splits(h, ublocks, a.tiles, 2 * TPS, 512);
@@ -901,14 +902,14 @@ int launch_grouped(m2d_engine *h, const int E8, const int KR, const bool BF16X3,
         int32_t *order = reinterpret_cast<int32_t *>(plan + (size_t)nU * 8), *hist = order + ((nU + 3) & ~(int64_t)3);      // hist: 16-B aligned
         unsigned long long *counter = reinterpret_cast<unsigned long long *>(hist + PLAN_KEYS);
         const bool prune = h->opt_topk_prune != 0;
-        const bool sorted = prune && !HV && nU > 32 * WV && h->opt_topk_prune != 3;      // 3: pruning without the sort (A/B)
+        const bool sorted = prune && !HV && nU > 32 * WV;
         {
             const int pmode = (HV || !prune) ? 1 : (h->opt_topk_prune == 2 ? 2 : (h->opt_topk_prune == 4 ? 4 : 0));
-            const float *probes = (HV || !prune || h->opt_topk_prune == 6) ? nullptr : h->grp_rs;      // 6: Cauchy-Schwarz bounds only (A/B)
+            const float *probes = (HV || !prune) ? nullptr : h->grp_rs;
             const dim3 pgrid((unsigned)((nU * 16 + 255) / 256));
             // probe rows per user: each costs a row read per user (16: +18 us for 65 536 users) and buys a tighter bound -- 16 rows
             // at 100 k dishes (0.71 ms; 32: 0.73), 32 at 1 M (3.83 ms; 16: 4.02)
-            const int nprobe = h->opt_topk_probes ? h->opt_topk_probes : (a.tiles < 8192 ? 16 : (a.tiles < 65536 ? 32 : PLAN_PROBES));
+            const int nprobe = a.tiles < 8192 ? 16 : (a.tiles < 65536 ? 32 : PLAN_PROBES);
             auto pk = h->E <= 64 ? m2d_topk_user_plan<1> : (h->E <= 128 ? m2d_topk_user_plan<2> : m2d_topk_user_plan<4>);
             hipLaunchKernelGGL(pk, pgrid, dim3(256), 0, st, h->pm, h->ce, users, nU, h->U, h->user_base, h->E, a.grp, (int)k, h->a, h->b, pmode,
                                plan, tie_list, counter, sorted ? hist : nullptr, PLAN_KEYS, probes, h->grp_ew, nprobe, BF16X3 ? 0 : 1, ext ? h->topk_refine_counter : nullptr);
@@ -927,7 +928,7 @@ int launch_grouped(m2d_engine *h, const int E8, const int KR, const bool BF16X3,
             a.order = order;
         }
         if (a.order && nitems > (size_t)h->num_cu && h->opt_topk_prune != 5) {      // 5: grid order (A/B)
-            int32_t *work = reinterpret_cast<int32_t *>(counter + 1), *items = work + nitems;
+            int32_t *work = reinterpret_cast<int32_t *>(counter + 2), *items = work + nitems;      // counter: two words (tiles, completed)
             hipLaunchKernelGGL(m2d_plan_items_work, dim3((unsigned)((ublocks + 3) / 4)), dim3(256), 0, st, plan, order, nU, a.grp, a.tiles,
                                nsplit, work, 32 * WV);
             hipLaunchKernelGGL(m2d_plan_items_sort, dim3(1), dim3(1024), 0, st, work, (int64_t)nitems, a.tiles, nsplit, items);

@@ -802,8 +802,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
             const v4i_pg v0 = w[0], v1 = w[1];
             const int d = __builtin_amdgcn_readfirstlane(min(min(min(v0.x, v0.y), min(v0.z, v0.w)), min(min(v1.x, v1.y), min(v1.z, v1.w))) - target);
             if (d >= 0) break;
-            if (spin > (1 << 20)) {
-                if (lane == 0 && atomicCAS(&p.err[0], 0, M2D_ERR_HIP) == 0) { p.err[1] = 0x5bad; p.err[2] = target; p.err[3] = 0; }
+            // A wave that never shows up would hang the launch: after p.prog_limit polls (2^24 by default: about a second of
+            // s_sleep -- a wave is a few microseconds behind its mates, never this) the call is latched M2D_ERR_KERNEL_TIMEOUT and
+            // the wave goes on; the call's lists are INVALID then (pieces 6 and 7 may land in rows a slower wave still reads) and
+            // m2d_check says so.  tests/test_gpu_catalogue.py forces it with "variant" = 15 (limit 0).
+            if (spin >= p.prog_limit) {
+                if (lane == 0 && atomicCAS(&p.err[0], 0, M2D_ERR_KERNEL_TIMEOUT) == 0) { p.err[1] = target; p.err[2] = (int32_t)blockIdx.x; p.err[3] = 0; }
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -877,7 +881,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
             static_assert(!(APX && KS > AR) || (TPS == 4 && PPW == 8), "two pieces per tile, four tiles per stage");
             if (sub == 0) issue_pieces(ps_p1, q / TPS + 1, 0, 4);
             if (sub == 2) {
-                asm volatile("s_barrier" ::: "memory");
+                // the LDS reads that complete() issued in steps "sub 0 / 1" have RETURNED before any wave refills their region: the
+                // wait is in the barrier's own asm, not left to where the compiler puts it before the consuming MFMAs
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 issue_pieces(ps_p1, q / TPS + 1, 4, 4);
             }
         } else if constexpr (APX) {
@@ -1154,9 +1160,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void m2d_topk_grouped_bf16_pipe2(Gro
     }
     wait_all_vmem();                                       // no LDS-DMA may land after the lists are published below
     __syncthreads();
-    // diagnostic: tiles stepped through (per block; bits 0 .. 35) and, APX, (wave, tile) pairs whose cross products were multiplied (bits 36 ..)
-    if (p.tiles_scanned && lane == 0 && (wave == 0 || (APX && n_completed)))
-        atomicAdd(p.tiles_scanned, (wave == 0 ? (unsigned long long)n : 0ull) + ((unsigned long long)n_completed << 36));
+    // diagnostic: tiles stepped through (per block; word 0) and, APX, (wave, tile) pairs whose cross products were multiplied (word 1:
+    // a word of its own since round 6 -- packed above bit 36 of word 0 the count wrapped past 2.7e8, which a 500 k x 1 M every-tile launch exceeds)
+    if (p.tiles_scanned && lane == 0) {
+        if (wave == 0) atomicAdd(p.tiles_scanned, (unsigned long long)n);
+        if (APX && n_completed) atomicAdd(p.tiles_scanned + 1, (unsigned long long)n_completed);
+    }
 #if M2D_DIAG & 16
     if (lane == 0 && p.dbg) {
         // one record per (workgroup, wave) in launch order (a 128-user launch has more user blocks than (nU + 255) / 256: the

@@ -126,7 +126,6 @@ struct m2d_engine {
     float *topk_ex = nullptr;           // what the lists leave out, per (user, dish range) / (user, group) / user: 4 floats each
     size_t topk_ex_cap = 0;             // floats
     int32_t *topk_refine_counter = nullptr;   // [2] users refined, users sent on to the repair (inside topk_ex's allocation)
-    int opt_topk_probes = 0;            // probe rows per user of the retrieval plan: 0 = by catalogue size, else 8 ... 64 (a multiple of 8; A/B)
     int opt_topk_block = 0;             // users per block of a pruned split-bf16 launch: 0 = the launcher's choice, 128 / 256 forced (A/B)
     int topk_block_users = 256;         // what the last pattern-grouped launch used (the tile counters count tiles of blocks this size)
     int opt_topk_prune = 1;             // pipelined form: blocks step through the tiles of their users' relevant mask patterns only (0 = every tile)

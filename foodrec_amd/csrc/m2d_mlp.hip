@@ -34,6 +34,14 @@ static unsigned long long *g_m2d_mlp_diag_buffer = nullptr;
 #define MSTAMP(x)
 #define MACC(dst)
 #endif
+// diag bit 6 (the barrier-arrival trace): block 0's first gatherer also logs, per step, when it started, had built z, had issued
+// its row requests, had done the tile's last-step sums, and reached the barrier (5 s_memtime words per step, first 96 steps)
+#if M2D_MLP_DIAG & 64
+#define GSTAMP(k) do { if (blockIdx.x == 0 && wave == 4 && (threadIdx.x & 63) == 0 && nbar_ < 96 && p.dbg) { unsigned long long ts_; \
+        MSTAMP(ts_); p.dbg[4096 * 8 + 8 * 128 * 2 + nbar_ * 5 + (k)] = ts_; } } while (0)
+#else
+#define GSTAMP(k)
+#endif
 
 namespace {
 
@@ -593,6 +601,39 @@ __device__ __forceinline__ void pc_barrier()
 }
 #endif
 
+// Cross-lane sums without the LDS crossbar.  __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt(0): an LDS round trip
+// per step, queued behind the consumers' ds_read_b128 streams.  The gatherers' 24 of them (8 rows x 3 steps, serial) were the
+// 5 000-cycle barrier interval of every tile in round 6's arrival trace (profiles/r06_mlp_slack.txt, bars 7 / 17 / 27 ...) --
+// tables in L2 or not.  DPP / permlane swaps stay in the VALU; the sums associate as before (same bits).
+template <int CTRL>
+__device__ __forceinline__ float pc_dpp(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+// sum over the 8 lanes 8 r .. 8 r + 7 of a row, in every one of them: lane ^ 1, lane ^ 2 (quad_perm), then lane 7 - i of the
+// half row (row_half_mirror: the other quad's sum, which is the same value in each of its lanes)
+__device__ __forceinline__ float pc_sum8(float b)
+{
+    b += pc_dpp<0xB1>(b);                                   // quad_perm [1, 0, 3, 2]
+    b += pc_dpp<0x4E>(b);                                   // quad_perm [2, 3, 0, 1]
+    b += pc_dpp<0x141>(b);                                  // row_half_mirror
+    return b;
+}
+// x[lane] + x[lane ^ 16], x[lane] + x[lane ^ 32]: v_permlane16_swap / v_permlane32_swap of a value with itself leave the row's
+// (half's) own value in one result and its partner's in the other
+__device__ __forceinline__ float pc_add_xor16(float x)
+{
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float pc_add_xor32(float x)
+{
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
 template <int N>
 __device__ __forceinline__ void pc_wait_vmem()
 {
@@ -620,6 +661,16 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
         return p.perm ? (uint32_t)__builtin_amdgcn_readfirstlane((int)p.tile_blocks[tile])
                       : (0x06543210u | ((uint32_t)(NH >> pshift) << 28));             // every block: nibble j = j, count = K / E
     };
+    // The NEXT tile's word, requested a tile ahead (consumers, gatherers): as tile_word() reads it -- a scalar load at the head of
+    // the tile, waited for on the spot -- every tile began with a dependent round trip to L2 / HBM in each role (round 6's arrival
+    // trace: the barrier intervals after a tile boundary).  A VECTOR load (the index made opaque, so that it is not scalarised: a
+    // pending scalar load would turn every LDS wait into lgkmcnt(0)), kept raw in a VGPR and made uniform where it is used.
+    int pc_zero_;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(pc_zero_));
+    auto tile_word_raw = [&](int64_t tile) -> uint32_t {
+        return p.perm ? p.tile_blocks[tile + pc_zero_] : (0x06543210u | ((uint32_t)(NH >> pshift) << 28));
+    };
+    auto tile_word_ready = [&](uint32_t raw) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)raw); };
     auto nper_of = [&](uint32_t w) { return (int)(w >> 28) << pshift; };
     auto kmap = [&](uint32_t w, int q) { return (int)(((w >> (4 * (q >> pshift))) & 15u) << pshift) | (q & ((1 << pshift) - 1)); };
 #if M2D_MLP_DIAG & 64
@@ -725,7 +776,10 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
         zread(0);
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) split(ch, bA);
+        uint32_t tw_next = tile_word_raw(blockIdx.x);
         for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const uint32_t tw_c = tile_word_ready(tw_next);
+            if (tile + gridDim.x < ntiles) tw_next = tile_word_raw(tile + gridDim.x);
             // where this lane's scores go (lanes 0-15: pairs c and 16 + c of the wave's 32): requested now, needed after layer 3
             // (-1: a padding slot)
             int32_t pi[2];
@@ -738,7 +792,7 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
             for (int nt = 0; nt < 16; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc1[nt][0][r] = acc1[nt][1][r] = sb1[16 * nt + 4 * g4 + r];
-            const int nper = nper_of(tile_word(tile));                    // even (blocks of >= 2 periods, or every block)
+            const int nper = nper_of(tw_c);                               // even (blocks of >= 2 periods, or every block)
 #pragma unroll 1
             for (int kc = 0; kc < nper / 2; ++kc) {
                 period(bA, bB);
@@ -795,8 +849,7 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o = fmaf(sw3[16 * mt + 4 * g4 + r], fmaxf(acc2[mt][ct][r], 0.f), o);
-                o += __shfl_xor(o, 16, 64);
-                o += __shfl_xor(o, 32, 64);
+                o = pc_add_xor32(pc_add_xor16(o));
                 if (g4 == 0 && pi[ct] >= 0) p.out[pi[ct]] = sbase[tpar * 128 + wave * 32 + 16 * ct + c16] + (o + p.b3);
             }
             tpar ^= 1;
@@ -965,10 +1018,13 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
         unsigned long long t_a = 0, t_b = 0, t_c = 0, t_d = 0, n_t = 0, t0_, t1_;
         MSTAMP(t0_);
 #endif
+        uint32_t tw_next = tile_word_raw(tile0);
         for (int64_t tile = tile0; tile < ntiles; tile += gridDim.x) {
 #if M2D_MLP_DIAG
             ++n_t;
 #endif
+            const uint32_t tw = tile_word_ready(tw_next);
+            if (tile + gridDim.x < ntiles) tw_next = tile_word_raw(tile + gridDim.x);
 #pragma unroll
             for (int i = 0; i < 8; ++i) base[i] = 0.f;
             // producing z of period q: build it from the rows requested two steps ago (ordinary loads: the compiler
@@ -977,37 +1033,38 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
             auto step = [&](int set, const uint32_t (&iu)[8], const uint32_t (&id)[8], int half, bool last)
                             __attribute__((always_inline)) {
                 MACC(t_d);
+                GSTAMP(0);
                 build(set);
                 MACC(t_a);
+                GSTAMP(1);
                 gather(set, iu, id, half);
                 asm volatile("" ::: "memory");
                 MACC(t_b);
+                GSTAMP(2);
                 if (last) {
                     // reference score = sum of z over the 8 lanes of a row; an id out of range makes it NaN
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        float b = base[i].x + base[i].y;
-                        b += __shfl_xor(b, 1, 64);
-                        b += __shfl_xor(b, 2, 64);
-                        b += __shfl_xor(b, 4, 64);
+                        float b = pc_sum8(base[i].x + base[i].y);
                         if ((badmask >> i) & 1) b = __builtin_nanf("");
                         if (s == 0) sbase[tpar * 128 + (2 * g + (i >> 2)) * 32 + 8 * (i & 3) + r8] = b;
                     }
                 }
+                GSTAMP(3);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 MACC(t_c);
+                GSTAMP(4);
                 pc_barrier();
                 zb ^= 1;
             };
 #if M2D_MLP_DIAG & 16
             // diag bit 4 (timing only, wrong arithmetic): rows requested ONE period ahead
 #pragma unroll 1
-            for (int q = 0; q < nper_of(tile_word(tile)) - 2; q += 2) {
+            for (int q = 0; q < nper_of(tw) - 2; q += 2) {
                 step(0, cu, cd, q + 1, false);
                 step(0, cu, cd, q + 2, false);
             }
 #else
-            const uint32_t tw = tile_word(tile);
             const int nper = nper_of(tw);
 #pragma unroll 1
             for (int q = 0; q < nper - 2; q += 2) {
@@ -1024,11 +1081,18 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
             badmask = nbadmask;
             tpar ^= 1;
             const int64_t t2 = next_of(next_of(tile));
+            GSTAMP(0);
             load_ids(t2);
+            GSTAMP(1);
+            GSTAMP(4);
             pc_barrier();
             zb ^= 1;
+            GSTAMP(0);
             pc_wait_vmem<0>();
+            GSTAMP(1);
             convert_ids(t2);
+            GSTAMP(2);
+            GSTAMP(4);
             pc_barrier();
             zb ^= 1;
         }

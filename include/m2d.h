@@ -35,6 +35,8 @@ typedef struct m2d_engine m2d_engine;
 #define M2D_ERR_UNSUPPORTED (-6)    /* shape outside what the kernels cover (message says which)     */
 #define M2D_ERR_NO_DEVICE (-7)      /* no HIP device visible: there is no CPU fallback, by design    */
 #define M2D_ERR_BAD_INGREDIENT (-8) /* extension: ingredient id outside [0, R) or a malformed CSR     */
+#define M2D_ERR_KERNEL_TIMEOUT (-9) /* m2d_topk_users: a wave gave up waiting for its workgroup (about 1 s); that call's
+                                       lists are INVALID.  Latched on the device, reported by m2d_check */
 
 #define M2D_TABLES_HOST 0   /* table pointers are host memory: copied to HBM once, engine-owned      */
 #define M2D_TABLES_DEVICE 1 /* table pointers are device memory: borrowed, caller keeps them alive   */
@@ -269,19 +271,20 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
  *                                        are within the split's rounding of the three-product kernels' but not their bits, which is why the rule looks
  *                                        at the catalogue alone (blocks of 256 users; "topk_block" = 128 is not honoured there).  3 = that form for
  *                                        any catalogue, 4 = never (both diagnostic)
- * topk_prune       1        0 ... 9      pattern-grouped retrieval: 1 = scan starts from a lower bound of the user's k-th score and steps through the
+ * topk_prune       1        0 1 2 4 5 7 9  pattern-grouped retrieval: 1 = scan starts from a lower bound of the user's k-th score and steps through the
  *                                        tiles of the mask patterns that can reach its top-k only (bounds: alpha_P[u] +- |w_P[u]| max|RE[d]|, widened by
  *                                        what the arithmetic can move a computed score by; users sorted by pattern mask; (user block, dish range) items
- *                                        longest first); 0 = every tile.  A/B forms: 2 the bound only, 3 no sort, 4 the patterns only, 5 the grid's launch
- *                                        order, 6 the bound without its probe rows, 7 a user's dish ranges keep their thresholds apart (by default they
- *                                        meet in one atomic-max word per user, E = 64), 9 the tie repair reads every pattern's dishes.  Same lists, bit for bit.
+ *                                        longest first); 0 = every tile.  A/B forms the tests compare with it: 2 the bound only, 4 the patterns only, 5 the
+ *                                        grid's launch order, 7 a user's dish ranges keep their thresholds apart (by default they meet in one atomic-max
+ *                                        word per user, E = 64), 9 the tie repair reads every pattern's dishes.  Same lists, bit for bit.
  * topk_block       0        0 128 256    users per block of a pruned pipelined launch (0 = the launcher's choice)
- * topk_probes      0        0, 8 ... 64  probe rows per user of the retrieval plan (0 = 16 / 32 / 64 by catalogue size)
- * variant          0        7 8 9 11 12 13 14, 100 + n
- *                                        7 / 8 / 9: retrieval on the dense MFMA kernel / with LDS lists / on the one-block-per-user kernel; 9 also
- *                                        forces the generic pair and head kernels; 11 / 12: the pair kernel's throughput / latency form whatever the
- *                                        batch size; 13: tie repair's one-block-per-user tier from the third listed user on; 14: the nine-launch
- *                                        training step; 100 + n: n dish-range splits in retrieval
+ * variant          0        7 9 11 12 13 14 15, 100 + n
+ *                                        7 / 9: retrieval on the dense MFMA kernel / on the one-block-per-user kernel; 9 also forces the generic pair
+ *                                        and head kernels; 11 / 12: the pair kernel's throughput / latency form whatever the batch size; 13: tie
+ *                                        repair's one-block-per-user tier from the third listed user on; 14: the nine-launch training step;
+ *                                        15: the retrieval scan's progress-word wait gives up at once (M2D_ERR_KERNEL_TIMEOUT: test hook);
+ *                                        100 + n: n dish-range splits in retrieval
+ * (round 6 removed the values no test or profile script used: topk_prune 3 / 6, topk_probes, variant 8)
  *
  * ---- read-only diagnostics of the last m2d_topk_users call (m2d_get_option; they synchronise the device) ---------------------------------
  * topk_repaired          users the tie repair re-ranked over their patterns

@@ -45,7 +45,7 @@ int main(int argc, char **argv)
     hipMalloc(&du, B * 4); hipMalloc(&di, B * 4); hipMalloc(&out, B * 4);
     hipMemcpy(du, hu.data(), B * 4, hipMemcpyHostToDevice); hipMemcpy(di, hi.data(), B * 4, hipMemcpyHostToDevice);
 #if M2D_MLP_DIAG
-    unsigned long long *dbg; hipMalloc(&dbg, 4096 * 8 * 8 + 8 * 128 * 2 * 8); hipMemset(dbg, 0, 4096 * 8 * 8 + 8 * 128 * 2 * 8); g_m2d_mlp_diag_buffer = dbg;
+    unsigned long long *dbg; hipMalloc(&dbg, 4096 * 8 * 8 + 8 * 128 * 2 * 8 + 96 * 5 * 8); hipMemset(dbg, 0, 4096 * 8 * 8 + 8 * 128 * 2 * 8 + 96 * 5 * 8); g_m2d_mlp_diag_buffer = dbg;
 #endif
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     m2d_launch_score_pairs_mlp(&h, du, di, B, out, nullptr);
@@ -103,6 +103,15 @@ int main(int argc, char **argv)
             prev = rel;
         }
         printf("\n");
+        // the first gatherer's steps: cycles from the step's start to z built / rows requested / last-step sums done / at the barrier
+        std::vector<unsigned long long> gs(96 * 5);
+        hipMemcpy(gs.data(), dbg + 4096 * 8 + 8 * 128 * 2, gs.size() * 8, hipMemcpyDeviceToHost);
+        for (int b = 0; b < 72; ++b) {
+            const unsigned long long *e = &gs[b * 5];
+            printf("  gstep %3d: build %6lld  requests %6lld  sums %6lld  lds-wait %6lld   (start -> previous step's barrier arrival: %6lld)\n", b,
+                   (long long)(e[1] - e[0]), (long long)(e[2] - e[1]), (long long)(e[3] - e[2]), (long long)(e[4] - e[3]),
+                   b ? (long long)(e[0] - gs[(b - 1) * 5 + 4]) : 0LL);
+        }
     }
 #endif
     const double fl = 2.0 * (K * 256 + 256 * 64 + 64) * (double)B;

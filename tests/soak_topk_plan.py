@@ -64,7 +64,7 @@ for it in range(n):
     s0, i0 = s0.cpu().numpy(), i0.cpu().numpy()
     kern = eng.last_kernel()
     rep0 = eng.get_option("topk_repaired")
-    forms = [(1, 0), (5, 0), (int(rng.choice([2, 3, 4, 7])), 0), (1, 100 + int(rng.integers(2, 40))), (0, 0)]      # 7: dish ranges keep their thresholds apart
+    forms = [(1, 0), (5, 0), (int(rng.choice([2, 4, 7])), 0), (1, 100 + int(rng.integers(2, 40))), (0, 0)]      # 7: dish ranges keep their thresholds apart
     for prune, var in forms:
         eng.set_option("topk_prune", prune); eng.set_option("variant", var)
         s1, i1 = eng.topk_users(du, k); eng.check()

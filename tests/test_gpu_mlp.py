@@ -31,40 +31,43 @@ _MLP_CASES = [shape + form for shape in _MLP_SHAPES for form in _MLP_FORMS[shape
 
 
 @pytest.mark.parametrize("E,C,H1,H2,kernel,x3,form", _MLP_CASES)
-@pytest.mark.parametrize("B", [1, 127, 128, 129, 255, 256, 257, 3000])
-def test_mlp_scores_match_restatement(E, C, H1, H2, kernel, B, x3, form):
+def test_mlp_scores_match_restatement(E, C, H1, H2, kernel, x3, form):
+    """One test per (shape, arithmetic, kernel form); the batch sizes -- 1, around one and two tiles of 128 pairs, 3000 -- are
+    looped inside (8 cases each, the blend coefficient varying with them)."""
     import torch
     from foodrec_amd import ScoringEngine
     from oracle import m2d_oracle as oracle
     U, I = 300, 200
-    PM, RE, CE, users, items, _ = random_case(U, I, C, E, B, seed=E + B)
-    rng = np.random.default_rng(E + H1)
-    dish_cats = rng.integers(0, 2, (I, C)).astype(np.float32)
-    dish_cats[dish_cats.sum(1) == 0, 0] = 1
-    dish_cats[3] = 0                                      # NaN dish
-    K = (C + 1) * E
-    head = _head(K, H1, H2, rng, scale=4.0)              # large enough that the head matters
-    coef = ([0.99] + COEFS)[(E // 2 + B) % 6]            # the blend coefficient enters the head through z = PM[u] * Dt[d]
-    eng = ScoringEngine(PM, RE, CE, coef=coef)
-    ut, it = torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda")
-    with pytest.raises(ValueError):
-        eng.score_pairs_mlp(ut, it)
-    eng.set_dish_categories(dish_cats)
-    eng.set_mlp_head(*head)
-    eng.set_option("mlp_bf16x3", x3)
-    eng.set_option("mlp_form", form)
-    got = eng.score_pairs_mlp(ut, it); eng.check()
-    if kernel == "padded":
-        want = "m2d_mlp_mfma_bf16x3" if x3 else "m2d_mlp_mfma"
-    else:
-        want = kernel if kernel == "m2d_mlp_generic" or not x3 else ("m2d_mlp_mfma_bf16x3" if form else "m2d_mlp_pc_bf16x3")
-    assert eng.last_kernel() == want
-    ref = oracle.inference_mlp(PM, RE, CE, dish_cats, *head, users, items, coef=coef)
-    base = oracle.inference_f64(PM, RE, CE, users, items, dish_cats[items], coef)
-    ok = ~np.isnan(ref)
-    if ok.sum() > 10:
-        assert np.abs(ref[ok] - base[ok]).mean() > 1e-2, "head too small to be tested"
-    assert_scores_close(got.cpu().numpy(), ref, what="E%d B%d" % (E, B))
+    for B in (1, 127, 128, 129, 255, 256, 257, 3000):
+        PM, RE, CE, users, items, _ = random_case(U, I, C, E, B, seed=E + B)
+        rng = np.random.default_rng(E + H1)
+        dish_cats = rng.integers(0, 2, (I, C)).astype(np.float32)
+        dish_cats[dish_cats.sum(1) == 0, 0] = 1
+        dish_cats[3] = 0                                      # NaN dish
+        K = (C + 1) * E
+        head = _head(K, H1, H2, rng, scale=4.0)              # large enough that the head matters
+        coef = ([0.99] + COEFS)[(E // 2 + B) % 6]            # the blend coefficient enters the head through z = PM[u] * Dt[d]
+        eng = ScoringEngine(PM, RE, CE, coef=coef)
+        ut, it = torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda")
+        with pytest.raises(ValueError):
+            eng.score_pairs_mlp(ut, it)
+        eng.set_dish_categories(dish_cats)
+        eng.set_mlp_head(*head)
+        eng.set_option("mlp_bf16x3", x3)
+        eng.set_option("mlp_form", form)
+        got = eng.score_pairs_mlp(ut, it); eng.check()
+        if kernel == "padded":
+            want = "m2d_mlp_mfma_bf16x3" if x3 else "m2d_mlp_mfma"
+        else:
+            want = kernel if kernel == "m2d_mlp_generic" or not x3 else ("m2d_mlp_mfma_bf16x3" if form else "m2d_mlp_pc_bf16x3")
+        assert eng.last_kernel() == want
+        ref = oracle.inference_mlp(PM, RE, CE, dish_cats, *head, users, items, coef=coef)
+        base = oracle.inference_f64(PM, RE, CE, users, items, dish_cats[items], coef)
+        ok = ~np.isnan(ref)
+        if ok.sum() > 10:
+            assert np.abs(ref[ok] - base[ok]).mean() > 1e-2, "head too small to be tested"
+        assert_scores_close(got.cpu().numpy(), ref, what="E%d B%d" % (E, B))
+        eng.close()
 
 
 @pytest.mark.parametrize("coef", [0.99] + COEFS)

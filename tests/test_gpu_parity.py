@@ -58,22 +58,25 @@ def test_golden_vectors(torch_cuda, path):
 @pytest.mark.parametrize("shape", [(11, 13, 4, 6), (257, 129, 4, 32), (1000, 500, 4, 64), (1000, 500, 4, 128),
                                    (300, 100, 4, 200), (64, 64, 4, 256), (50, 40, 4, 260), (30, 20, 4, 7),
                                    (40, 30, 3, 16), (40, 30, 9, 64), (25, 12, 1, 4)])
-@pytest.mark.parametrize("B", [1, 63, 64, 65, 4097])
-@pytest.mark.parametrize("coef", [0.99] + COEFS)
-def test_seeded_shapes(torch_cuda, shape, B, coef):
+def test_seeded_shapes(torch_cuda, shape):
     """Every pair kernel (C = 4 throughput / latency forms, C != 4, odd embedding sizes) at every blend coefficient:
     `coef * high + (1 - coef) * low` with `1 - coef` taken in float32 (Model_Recommender.py:17, :95-96) -- the reference's
-    flag default is 0.99 (Train_recommender.py:61-62); 0 and 1 switch a level off, 1.25 makes the low level's weight negative."""
+    flag default is 0.99 (Train_recommender.py:61-62); 0 and 1 switch a level off, 1.25 makes the low level's weight negative.
+    One test per shape: the batch sizes (1, around a wavefront, 4097) and the six coefficients are looped inside (30 cases)."""
     from oracle import m2d_oracle as oracle
     U, I, C, E = shape
-    PM, RE, CE, users, items, cats = random_case(U, I, C, E, B, seed=U + E + B)
-    if B > 3:
-        cats[1] = 1.0
-        cats[2] = 0.0
-        cats[3] = np.linspace(0.25, 1.75, C)
-    eng = _engine(PM, RE, CE, coef=coef)
-    got = _run(eng, torch_cuda, users, items, cats)
-    assert_scores_close(got, oracle.inference_f64(PM, RE, CE, users, items, cats, coef), what=str(shape))
+    for B in (1, 63, 64, 65, 4097):
+        PM, RE, CE, users, items, cats = random_case(U, I, C, E, B, seed=U + E + B)
+        if B > 3:
+            cats[1] = 1.0
+            cats[2] = 0.0
+            cats[3] = np.linspace(0.25, 1.75, C)
+        for coef in [0.99] + COEFS:
+            eng = _engine(PM, RE, CE, coef=coef)
+            got = _run(eng, torch_cuda, users, items, cats)
+            assert_scores_close(got, oracle.inference_f64(PM, RE, CE, users, items, cats, coef),
+                                what="%s B %d coef %g" % (shape, B, coef))
+            eng.close()
 
 
 @pytest.mark.parametrize("coef", [0.99, 0.0, 1.0, 1.25])
