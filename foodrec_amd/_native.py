@@ -22,6 +22,7 @@ M2D_ERR_NOT_CONFIGURED = -5
 M2D_ERR_UNSUPPORTED = -6
 M2D_ERR_NO_DEVICE = -7
 M2D_ERR_BAD_INGREDIENT = -8
+M2D_ERR_KERNEL_TIMEOUT = -9          # m2d_topk_users: a wave gave up waiting for its workgroup; the lists are invalid
 M2D_TABLES_HOST = 0
 M2D_TABLES_DEVICE = 1
 M2D_WRITE_PERSONAL = 1

@@ -643,7 +643,11 @@ __device__ __forceinline__ void pc_wait_vmem()
 typedef float v2f_pc __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_pc __attribute__((ext_vector_type(2)));
 
-template <int KCH>
+// OFF32: both gathered tables are under 4 GiB -- a row's offset is a 32-bit BYTE offset and the row loads take the form
+// global_load_dwordx4 v, v_off, s[base:base+1] (the period's k-block in the scalar base): no address arithmetic in the gatherers,
+// whose every vector instruction waits for an issue slot beside a consumer's MFMAs (40 of ~130 per period were address moves
+// and 64-bit shift-adds).  Larger tables (up to 64 GiB): offsets in units of 16 B, one 64-bit shift-add per load.
+template <int KCH, bool OFF32>
 __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
 {
     extern __shared__ __align__(16) unsigned char pcs[];
@@ -713,9 +717,18 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
             fh = *reinterpret_cast<const bf16x8 *>(q);
             fl = *reinterpret_cast<const bf16x8 *>(q + PC_HALF / 2);
         };
-        // chunk ch = 2 ct + part: 4 of the next period's z values -> their place in the split B operand of pair tile ct
-        auto split = [&](int ch, bf16x8 (&nb)[2][2]) __attribute__((always_inline)) {
+        // The reference score's part of the output, sum_k z[k] (= the score Model_Recommender.py:95-96 returns), is summed HERE since round 6:
+        // every z value passes through exactly one consumer lane on its way into the B operand, four adds per chunk in the MFMAs'
+        // shadow.  The gatherers used to keep it (16 packed adds per period and, at a tile's last step, eight 8-lane sums and LDS
+        // writes): a memory wave gets a vector issue slot about every 16 cycles beside its SIMD-mate's MFMAs, the last step's
+        // sums alone held every tile's barrier for 4 200 cycles (round 6's per-step stamps, profiles/r06_mlp_slack.txt).
+        float bs[2] = {0.f, 0.f};                                         // this lane's k-values of pairs c16 and 16 + c16
+        // chunk ch = 2 ct + part: 4 of the next period's z values -> their place in the split B operand of pair tile ct; `acc`
+        // (wave-uniform): they belong to a period of a tile (after a tile's last layer-1 period the z set read is a stale one)
+        auto split = [&](int ch, bf16x8 (&nb)[2][2], const bool acc) __attribute__((always_inline)) {
             const v4f zz = zraw[ch];
+            const float zs4 = (zz.x + zz.y) + (zz.z + zz.w);
+            bs[ch >> 1] += acc ? zs4 : 0.f;
             const v2f_pc z01 = {zz.x, zz.y}, z23 = {zz.z, zz.w};
             const uint32_t h01 = __builtin_bit_cast(uint32_t, __builtin_convertvector(z01, bf16x2_pc));
             const uint32_t h23 = __builtin_bit_cast(uint32_t, __builtin_convertvector(z23, bf16x2_pc));
@@ -736,7 +749,7 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
         // one layer-1 period (32 k-values = one MFMA step): 16 hidden tiles x 2 pair tiles x 3 MFMAs; fragments two tiles ahead
         // (4 register sets), the barrier after the first half's 8 tiles (hidden units 0 .. 127: that half-stage is then done with),
         // the NEXT period's operands read and split under the last tiles
-        auto period = [&](bf16x8 (&b)[2][2], bf16x8 (&nb)[2][2]) __attribute__((always_inline)) {
+        auto period = [&](bf16x8 (&b)[2][2], bf16x8 (&nb)[2][2], const bool acc_next) __attribute__((always_inline)) {
             const unsigned h0 = hb * PC_HALF, h1 = hb_add(hb, 1) * PC_HALF, h2 = hb_add(hb, 2) * PC_HALF;
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
@@ -745,7 +758,7 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
                 const int jt = it + 2;
                 frag(jt < 8 ? h0 : jt < 16 ? h1 : h2, jt & 7, ah[jt & 3], al[jt & 3]);
                 if (it == 10) zread(zb ^ 1);
-                if (it >= 12) split(it - 12, nb);
+                if (it >= 12) split(it - 12, nb, acc_next);
                 if (M2D_MLP_DIAG & 512) {                                  // diag bit 9 (timing only): LDS reads and the split, no MFMA
                     asm volatile("" ::"v"(ah[it & 3]), "v"(al[it & 3]), "v"(b[0][0]), "v"(b[0][1]), "v"(b[1][0]), "v"(b[1][1]));
                     if (M2D_MLP_DIAG & 1024) {                             // + bit 10: idle for about the six MFMAs' wall time
@@ -775,7 +788,7 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
         frag(0, 1, ah[1], al[1]);
         zread(0);
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) split(ch, bA);
+        for (int ch = 0; ch < 4; ++ch) split(ch, bA, true);
         uint32_t tw_next = tile_word_raw(blockIdx.x);
         for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
             const uint32_t tw_c = tile_word_ready(tw_next);
@@ -795,8 +808,8 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
             const int nper = nper_of(tw_c);                               // even (blocks of >= 2 periods, or every block)
 #pragma unroll 1
             for (int kc = 0; kc < nper / 2; ++kc) {
-                period(bA, bB);
-                period(bB, bA);
+                period(bA, bB, true);
+                period(bB, bA, kc + 1 < nper / 2);                        // the tile's last period: no next z of this tile
             }
             // ---- layer 2: relu(acc1) split hi / lo is the B operand -- a step's 32 hidden units are accumulator tiles 2 s and
             // 2 s + 1, rows 4 g .. 4 g + 3 of each (the W2 image holds its k-values in that order); W2 is ring stages NH, NH + 1 ----
@@ -839,9 +852,12 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
             frag(hb * PC_HALF, 0, ah[0], al[0]);
             frag(hb * PC_HALF, 1, ah[1], al[1]);
             zread(zb);
+            const float bfin[2] = {bs[0], bs[1]};                         // this tile's sums; the next tile's start below
+            bs[0] = bs[1] = 0.f;
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch) split(ch, bA);
-            // ---- layer 3 and the reference score (summed by the producer; NaN there = an id was out of range) ----
+            for (int ch = 0; ch < 4; ++ch) split(ch, bA, true);
+            // ---- layer 3 and the reference score (its sum over this lane's k-values: bfin; the gatherers' word is 0, or NaN = an
+            // id was out of range) ----
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) {
                 float o = 0.f;
@@ -849,8 +865,9 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o = fmaf(sw3[16 * mt + 4 * g4 + r], fmaxf(acc2[mt][ct][r], 0.f), o);
+                const float base = pc_add_xor32(pc_add_xor16(bfin[ct]));
                 o = pc_add_xor32(pc_add_xor16(o));
-                if (g4 == 0 && pi[ct] >= 0) p.out[pi[ct]] = sbase[tpar * 128 + wave * 32 + 16 * ct + c16] + (o + p.b3);
+                if (g4 == 0 && pi[ct] >= 0) p.out[pi[ct]] = (sbase[tpar * 128 + wave * 32 + 16 * ct + c16] + base) + (o + p.b3);
             }
             tpar ^= 1;
 #if M2D_MLP_DIAG
@@ -941,7 +958,6 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
         uint32_t cu[8], cd[8], nu[8], nd[8];                              // this tile / the next one
         unsigned badmask = 0, nbadmask = 0;
         v4f ra[2][8], rb_[2][8];
-        v2f_pc base[8];
         int32_t npi[8];                                                   // pair index of each slot of the tile being converted
         auto load_ids = [&](int64_t tile) __attribute__((always_inline)) {
 #pragma unroll
@@ -969,8 +985,8 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
                 if (valid && (did < 0 || (int64_t)did >= p.I)) { if (s == 0) latch(p.err, M2D_ERR_BAD_ITEM_ID, did, pi); nbadmask |= 1u << i; }
                 if (!valid || ul < 0 || ul >= p.U) ul = 0;
                 if (!valid || did < 0 || (int64_t)did >= p.I) dl = 0;
-                nu[i] = (uint32_t)ul * (uint32_t)(K / 4) + (uint32_t)s;
-                nd[i] = (uint32_t)dl * (uint32_t)(K / 4) + (uint32_t)s;
+                nu[i] = ((uint32_t)ul * (uint32_t)(K / 4) + (uint32_t)s) * (OFF32 ? 16u : 1u);
+                nd[i] = ((uint32_t)dl * (uint32_t)(K / 4) + (uint32_t)s) * (OFF32 ? 16u : 1u);
             }
         };
         auto gather = [&](int set, const uint32_t (&iu)[8], const uint32_t (&id)[8], int half) __attribute__((always_inline)) {
@@ -979,26 +995,22 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 uint32_t ou = iu[i], od = id[i];
-                asm volatile("" : "+v"(ou), "+v"(od));                    // keep the 64-bit products out of registers
+                if (!OFF32) asm volatile("" : "+v"(ou), "+v"(od));        // keep the 64-bit products out of registers
                 // user rows are read about once per batch: non-temporal, so they do not push the dish vectors (each
                 // read ~10 times) out of L2 / the Infinity Cache
-                ra[set][i] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(bu + (uint64_t)ou * 16));
-                rb_[set][i] = *reinterpret_cast<const v4f *>(bd + (uint64_t)od * 16);
+                ra[set][i] = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(bu + (uint64_t)ou * (OFF32 ? 1 : 16)));
+                rb_[set][i] = *reinterpret_cast<const v4f *>(bd + (uint64_t)od * (OFF32 ? 1 : 16));
                 __builtin_amdgcn_sched_barrier(0);                        // one pair of addresses live at a time
             }
         };
         unsigned zb = 0, tpar = 0;                                        // z set being written; parity of this block's tile count
-        // per 4 k-values of a pair: 2 packed multiplies, 2 packed adds into the reference score, one 16-byte store
+        // per 4 k-values of a pair: 2 packed multiplies, one 16-byte store (the reference score's sum: in the consumers)
         auto build = [&](int set) __attribute__((always_inline)) {
             if (M2D_MLP_DIAG & 2) return;                                 // diag bit 1: no z build
             unsigned char *zs = pcs + PC_Z_OFF + zb * PC_ZSET + z_w;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const v4f zz = ra[set][i] * rb_[set][i];
-                const v2f_pc z01 = {zz.x, zz.y}, z23 = {zz.z, zz.w};
-                base[i] += z01 + z23;
-                *reinterpret_cast<v4f *>(zs + (i >> 2) * 4096 + (i & 3) * 128) = zz;
-            }
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<v4f *>(zs + (i >> 2) * 4096 + (i & 3) * 128) = ra[set][i] * rb_[set][i];
         };
         // prologue: offsets of this block's first two tiles; the first two periods' rows
         const int64_t tile0 = blockIdx.x;
@@ -1025,8 +1037,6 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
 #endif
             const uint32_t tw = tile_word_ready(tw_next);
             if (tile + gridDim.x < ntiles) tw_next = tile_word_raw(tile + gridDim.x);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) base[i] = 0.f;
             // producing z of period q: build it from the rows requested two steps ago (ordinary loads: the compiler
             // places the vmcnt waits, and in this wave it sees every outstanding request), request the rows two
             // periods on, publish
@@ -1042,13 +1052,9 @@ __global__ __launch_bounds__(512) void m2d_mlp_pc(MlpArgs p)
                 MACC(t_b);
                 GSTAMP(2);
                 if (last) {
-                    // reference score = sum of z over the 8 lanes of a row; an id out of range makes it NaN
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        float b = pc_sum8(base[i].x + base[i].y);
-                        if ((badmask >> i) & 1) b = __builtin_nanf("");
-                        if (s == 0) sbase[tpar * 128 + (2 * g + (i >> 2)) * 32 + 8 * (i & 3) + r8] = b;
-                    }
+                    // the pair's word beside the consumers' sum: 0, or NaN when one of its ids was out of range.  One store per lane:
+                    // lane (r8, s) writes the word of slot i = s (a row's eight lanes hold the same badmask)
+                    sbase[tpar * 128 + (2 * g + (s >> 2)) * 32 + 8 * (s & 3) + r8] = ((badmask >> s) & 1) ? __builtin_nanf("") : 0.f;
                 }
                 GSTAMP(3);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1225,11 +1231,15 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
             a.perm = perm; a.tile_blocks = tblocks; a.ntiles_dev = ntl;
         }
         const unsigned grid = (unsigned)(tiles_max < h->num_cu ? tiles_max : h->num_cu);
+        // row offsets as 32-bit byte offsets where both gathered tables allow it (see the kernel's OFF32)
+        const bool off32 = (uint64_t)h->U * a.K * 4 <= (1ull << 32) && (uint64_t)h->I * a.K * 4 <= (1ull << 32);
 #define M2D_MLP_PC_CASE(N)                                                                                  \
-    if (kch == N) {                                                                                         \
-        M2D_HIP_TRY(h, m2d_lds_limit((const void *)m2d_mlp_pc<N>, \
-                                           PC_LDS_BYTES));                                                  \
-        hipLaunchKernelGGL((m2d_mlp_pc<N>), dim3(grid), dim3(512), PC_LDS_BYTES, stream, a);                \
+    if (kch == N && off32) {                                                                                \
+        M2D_HIP_TRY(h, m2d_lds_limit((const void *)m2d_mlp_pc<N, true>, PC_LDS_BYTES));                     \
+        hipLaunchKernelGGL((m2d_mlp_pc<N, true>), dim3(grid), dim3(512), PC_LDS_BYTES, stream, a);          \
+    } else if (kch == N) {                                                                                  \
+        M2D_HIP_TRY(h, m2d_lds_limit((const void *)m2d_mlp_pc<N, false>, PC_LDS_BYTES));                    \
+        hipLaunchKernelGGL((m2d_mlp_pc<N, false>), dim3(grid), dim3(512), PC_LDS_BYTES, stream, a);         \
     }
         M2D_MLP_PC_CASE(3) M2D_MLP_PC_CASE(5) M2D_MLP_PC_CASE(10) M2D_MLP_PC_CASE(20)
 #undef M2D_MLP_PC_CASE

@@ -156,13 +156,19 @@ def train_case(rng, what):
         assert abs(loss - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (what, loss, ref_loss)
         assert abs(norm - ref_norm) <= 2e-5 * max(1.0, ref_norm), (what, norm, ref_norm)
     # adam / rmsprop divide by sqrt(v) + 1e-8: an element whose gradient all but cancels in float32 moves by a different fraction of lr than
-    # in the float64 restatement (tests/test_gpu_train.py: 1e-3 of lr per step on its tables; these are three times larger, and seed
-    # 1791184991 case 124 came out at 1.0003e-3: 1.5e-3 here)
-    tol = 1.5e-3 * lr * steps if learner in ("adam", "rmsprop") else 1e-5
+    # in the float64 restatement.  The general bound stays tests/test_gpu_train.py's 1e-3 of lr per step; a cancelling element may reach 1.5e-3
+    # (seed 1791184991 case 124: ONE element at 1.0003e-3) -- but only a handful may: an optimiser regression moves whole rows, and a bound
+    # widened for every element would let it through (round 5's form of this check)
+    adaptive = learner in ("adam", "rmsprop")
+    tol = 1e-3 * lr * steps if adaptive else 1e-5
     for got, ref in ((eng.pm, st.PM), (eng.re, st.RE), (eng.ce, st.CE)):
         err = np.abs(got.cpu().numpy().astype(np.float64) - ref)
         bound = tol * np.maximum(1.0, np.abs(ref)) if learner in ("sgd", "adagrad") else tol
-        assert np.all(err <= bound), (what, learner, err.max())
+        if adaptive:
+            over = err > bound
+            assert np.all(err <= 1.5 * bound) and over.sum() <= max(2, err.size // 100000), (what, learner, err.max(), int(over.sum()))
+        else:
+            assert np.all(err <= bound), (what, learner, err.max())
     eng.train_end()
     return "train %s C%d E%d B%d" % (learner, C, E, B)
 

@@ -398,6 +398,29 @@ def test_both_forms_of_the_split_bf16_kernel_agree(E, k):
     _check(eng, PM, RE, CE, cats, np.arange(0, U, 7), k)                # the first form on its own against the oracle
 
 
+def test_progress_word_timeout_is_reported_and_the_engine_recovers():
+    """The E = 64 hi x hi first form's waves wait for their workgroup's progress words before they refill tiles 6 and 7 of a stage; a
+    wave that waited past the bound latches M2D_ERR_KERNEL_TIMEOUT (include/m2d.h: that call's lists are invalid) and goes on instead
+    of hanging the launch.  "variant" = 15 sets the bound to zero polls: check() must raise and name the cause, and the next call must
+    be clean and return the lists of an undisturbed engine."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    U, I, E, k = 2048, 12000, 64, 10
+    PM, RE, CE, cats = _tables(U, I, 4, E, seed=777)
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(cats)
+    users = torch.arange(U, dtype=torch.int32, device="cuda")
+    eng.set_option("topk_form", 3); eng.set_option("topk_prune", 0)
+    s0, i0 = eng.topk_users(users, k); eng.check()
+    eng.set_option("variant", 15)
+    eng.topk_users(users, k)
+    with pytest.raises(RuntimeError, match="progress words"):
+        eng.check()
+    eng.set_option("variant", 0)
+    s1, i1 = eng.topk_users(users, k); eng.check()                     # the latch is cleared, the engine works
+    assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+
+
 @pytest.mark.parametrize("E,k,low_scale,coef", [(64, 10, 1.0, 0.99), (64, 16, 1.0, 0.99), (64, 10, 6.0, 0.99), (64, 10, 0.05, 0.99), (64, 10, 1.0, 0.5),
                                                 (64, 10, 1.0, 0.0), (64, 16, 1.0, 1.25), (64, 10, 1.0, 0.9), (128, 10, 1.0, 0.99), (128, 16, 1.0, 0.99),
                                                 (128, 10, 6.0, 0.5), (128, 13, 0.05, 1.25), (128, 10, 1.0, 0.0)])
