@@ -96,7 +96,8 @@ def topk_workload_text(a, world, U, I, E, round_cfg, n_tk):
         notes += ("; any float is legal placeholder input (Model_Recommender.py:32): no pattern grouping, the dense "
                   "exact-f32 kernel contracts over (C + 1) E")
     if a.topk_with_ingredients:
-        wl += " -- WITH the build-defined ingredient table (%d rows, 1-20 per dish)" % a.ingredients
+        wl += " -- WITH the ingredient table (%d rows)" % a.ingredients
+        notes += "; build-defined ingredient table, 1-20 ingredients per dish, retrieval over [H[d] | RE[d]] rows"
     return wl, notes
 
 
@@ -288,7 +289,7 @@ def main():
             line["side_legs"] = {"status": "not finished: headline line only", "rank": rank,
                                  "leg_in_flight": in_flight["leg"], "timeout_s": a.side_timeout, "exit_status": 4}
             line.update(linelib.config_scalars(line))
-            cli.emit(line, a.out)
+            cli.emit(linelib.ordered(line), a.out)
         os._exit(4)
     watchdog = threading.Timer(a.side_timeout, give_up)
     watchdog.daemon = True
@@ -452,7 +453,7 @@ def main():
                                  "(M2D_BENCH_REHEARSE_ONE_GPU=1); its timings and rates mean nothing" % world)
         line.update(linelib.config_scalars(line))
         watchdog.cancel()
-        cli.emit(line, a.out)
+        cli.emit(linelib.ordered(line), a.out)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -61,3 +61,46 @@ def scaling_scalars(scaling):
                     "topk_path_projected_world8_speedup_upper_bound": pj["implied_speedup_upper_bound"],
                     "topk_path_projected_world8_status": pj["status"]})
     return out
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data")
+ROOFLINE_FIRST = ("bound", "achieved", "peak", "unit", "frac", "traffic", "survey_8d_frac", "survey_8d_pairs_per_s",
+                  "hbm_only_frac_of_spec", "hbm_only_masked_frac_of_spec", "stream_probe_GBps",
+                  "hbm_only_frac_of_stream_probe", "hbm_only_masked_frac_of_stream_probe", "kernel_avg_ms",
+                  "algorithmic_bytes_per_pair", "pairs_per_launch")
+# the scalars a record that keeps only the END of the line (the driver's `tail`: 2 000 characters) must still show;
+# last = most wanted
+TAIL_KEYS = ("ranks_seen", "distinct_devices", "dist_backend", "topk_path_ms", "topk_path_allgather_exposed_ms_max",
+             "topk_path_projected_world8_speedup_upper_bound", "cfg0_evaluator_users_per_s", "cfg1_pairs_per_s",
+             "cfg1_hbm_frac", "cfg1_ingredients_pairs_per_s", "cfg3_topk_e64_path_ms", "cfg3_topk_e64_mfma_frac",
+             "topk_pruned_frac", "topk_every_tile_frac", "cpu_baseline_pairs_per_s", "stream_probe_GBps",
+             "hbm_only_frac_of_spec", "hbm_only_masked_frac_of_spec", "survey_8d_pairs_per_s", "survey_8d_frac",
+             "cfg4_topk_e128_round_ms", "cfg4_topk_e128_mfma_frac", "cfg2_mlp_e128_ms",
+             "cfg2_mlp_max_rel_vs_restatement", "cfg2_mlp_mfma_frac", "cfg2_mlp_e128_pairs_per_s", "parity")
+
+
+def _short(v):
+    """Six significant digits for the tail's copies (the nested legs keep every digit)."""
+    return float("%.6g" % v) if isinstance(v, float) else v
+
+
+def ordered(line):
+    """The same line, keys in the order a truncating reader serves best: the contract's keys first; `roofline` with its
+    headline scalars ahead of the nested legs; the nested legs in the middle; every other top-level scalar at the END,
+    the per-config summary last (the driver's record keeps the last 2 000 characters of stdout verbatim)."""
+    out = {k: line[k] for k in CONTRACT_KEYS if k in line}
+    if "config" in line:
+        out["config"] = line["config"]
+    roof = line.get("roofline")
+    if isinstance(roof, dict):
+        r2 = {k: roof[k] for k in ROOFLINE_FIRST if k in roof}
+        r2.update({k: v for k, v in roof.items() if k not in r2 and not isinstance(v, (dict, list))})
+        r2.update({k: v for k, v in roof.items() if k not in r2})
+        out["roofline"] = r2
+    if "cpu_baseline" in line:
+        out["cpu_baseline"] = line["cpu_baseline"]
+    out.update({k: v for k, v in line.items() if k not in out and isinstance(v, (dict, list))})
+    out.update({k: v for k, v in line.items() if k not in out and k not in TAIL_KEYS})
+    out.update({k: _short(line[k]) for k in TAIL_KEYS if k in line})
+    return out

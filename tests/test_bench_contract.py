@@ -91,6 +91,28 @@ def test_top_level_scalars_of_the_default_line():
     assert "cfg2_mlp_e128_ms" not in linelib.config_scalars({"value": 1.0, "n_gpus": 1, "config": {}, "roofline": {}})
 
 
+def test_summary_scalars_end_the_line():
+    """benchlib.line.ordered: the driver's record keeps `parsed` (contract keys, config, roofline, cpu_baseline; other keys by NAME
+    only) and the last 2 000 characters of stdout -- so the per-config summary scalars are emitted LAST, and `roofline` leads with
+    its headline scalars, nested legs behind them."""
+    from benchlib import line as linelib
+    path = os.path.join(ROOT, "profiles", "r06_bench_default.json")
+    line = json.load(open(path))
+    text = json.dumps(linelib.ordered(line))
+    assert json.loads(text).keys() == line.keys()
+    tail = text[-2000:]
+    for key in ("cfg2_mlp_e128_pairs_per_s", "cfg2_mlp_e128_ms", "cfg2_mlp_mfma_frac", "cfg2_mlp_max_rel_vs_restatement",
+                "cfg4_topk_e128_round_ms", "cfg4_topk_e128_mfma_frac", "cfg1_ingredients_pairs_per_s", "survey_8d_pairs_per_s",
+                "survey_8d_frac", "hbm_only_frac_of_spec", "hbm_only_masked_frac_of_spec", "stream_probe_GBps",
+                "topk_every_tile_frac", "topk_path_ms", "ranks_seen", "distinct_devices", "parity"):
+        assert '"%s": ' % key in tail, key
+    roof = list(linelib.ordered(line)["roofline"])
+    assert roof[:5] == ["bound", "achieved", "peak", "unit", "frac"]
+    first_nested = min(i for i, k in enumerate(roof) if isinstance(line["roofline"][k], (dict, list)))
+    for key in ("survey_8d_frac", "hbm_only_frac_of_spec", "stream_probe_GBps"):
+        assert roof.index(key) < first_nested
+
+
 def test_bench_sources_stay_auditable():
     """bench.py and benchlib/: lines of at most 120 characters; bench.py itself under 500 lines."""
     import glob
