@@ -44,8 +44,32 @@ def _candidates(user, testRatings, testNegatives) -> List[int]:
     return [testRatings[str(user)][0]] + list(testNegatives[str(user)][50:100])
 
 
-def eval_one_rating(model: Model, user, testRatings, testNegatives, K, dish_to_category):
-    """Reference-shaped single-user path (evaluate.py:35-66): one predict call of <= 51 pairs, host ranking."""
+# evaluate.py:5-10: the reference's evaluator keeps its arguments in module globals, set by evaluate_model and read by
+# eval_one_rating(user).  Kept for the one-argument call; the six-argument form needs none of them.
+_model = None
+_testRatings = None
+_testNegatives = None
+_K = None
+_dish_to_category = None
+
+
+def eval_one_rating(*args):
+    """Reference-shaped single-user path (evaluate.py:35-66): one predict call of <= 51 pairs, host ranking.
+
+    ``eval_one_rating(user)`` -- the reference's own signature (evaluate.py:35): the model and the split are those of the
+    last ``evaluate_model`` call, as in the reference's module globals (evaluate.py:5-10, :14-25).
+    ``eval_one_rating(model, user, testRatings, testNegatives, K, dish_to_category)`` -- the same with everything passed in.
+    Returns ``(hit, ndcg)``, or ``None`` for a user without a test rating (evaluate.py:37-38)."""
+    if len(args) == 1:
+        if _model is None:
+            raise RuntimeError("eval_one_rating(user): call evaluate_model first (it sets the evaluator's model and split, "
+                               "evaluate.py:14-25), or pass (model, user, testRatings, testNegatives, K, dish_to_category)")
+        model, user = _model, args[0]
+        testRatings, testNegatives, K, dish_to_category = _testRatings, _testNegatives, _K, _dish_to_category
+    elif len(args) == 6:
+        model, user, testRatings, testNegatives, K, dish_to_category = args
+    else:
+        raise TypeError("eval_one_rating takes (user) or (model, user, testRatings, testNegatives, K, dish_to_category)")
     if str(user) not in testRatings or len(testRatings[str(user)]) == 0:
         return None
     items = _candidates(user, testRatings, testNegatives)
@@ -177,6 +201,8 @@ def evaluate_model(sess, model: Model, testRatings: Dict[str, List[int]], testNe
     makes ``dish_to_category`` the engine's resident dish mask table: a table set earlier with ``set_dish_categories`` is
     replaced.
     """
+    global _model, _testRatings, _testNegatives, _K, _dish_to_category
+    _model, _testRatings, _testNegatives, _K, _dish_to_category = model, testRatings, testNegatives, K, dish_to_category
     if not testRatings:
         return [], []
     if K > 64:

@@ -32,6 +32,8 @@ def test_evaluate_model_matches_reference(case):
     for (u, hr, nd) in zip(case["testRatings"], case["hits"], case["ndcgs"]):
         assert eval_one_rating(model, u, case["testRatings"], case["testNegatives"], case["K"],
                                case["dish_to_category"]) == (hr, nd)
+        assert eval_one_rating(u) == (hr, nd)             # the reference's own signature (evaluate.py:35): last evaluate_model's split
+    assert eval_one_rating("no such user") is None        # evaluate.py:37-38
 
 
 def test_rank_candidates_against_oracle_ranking():
