@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/traffic.json from a scripts/profile_gpu.sh run: the fabric bytes per launch of the timed pair kernel (PMC
 passes) keyed by the workload's shape, with the streaming-read probe of the SAME box beside them (bench.py publishes the
-reading only on a box whose probe is within 5 % of it).
+reading only on a box whose probe is within 10 % of it).
     python scripts/update_traffic.py gpurun_out/prof_<tag> <a default bench.py line of the same gpurun call> [profiles/traffic.json]"""
 import json
 import sys
