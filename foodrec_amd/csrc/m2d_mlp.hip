@@ -1232,7 +1232,8 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
         }
         const unsigned grid = (unsigned)(tiles_max < h->num_cu ? tiles_max : h->num_cu);
         // row offsets as 32-bit byte offsets where both gathered tables allow it (see the kernel's OFF32)
-        const bool off32 = (uint64_t)h->U * a.K * 4 <= (1ull << 32) && (uint64_t)h->I * a.K * 4 <= (1ull << 32);
+        // ("variant" 16: the 16-byte-unit offsets whatever the sizes -- the tests' way to run the large-table instantiation)
+        const bool off32 = (uint64_t)h->U * a.K * 4 <= (1ull << 32) && (uint64_t)h->I * a.K * 4 <= (1ull << 32) && h->opt_variant != 16;
 #define M2D_MLP_PC_CASE(N)                                                                                  \
     if (kch == N && off32) {                                                                                \
         M2D_HIP_TRY(h, m2d_lds_limit((const void *)m2d_mlp_pc<N, true>, PC_LDS_BYTES));                     \

@@ -278,11 +278,12 @@ int m2d_check(m2d_engine *h, void *stream, int64_t *bad_value, int64_t *bad_inde
  *                                        grid's launch order, 7 a user's dish ranges keep their thresholds apart (by default they meet in one atomic-max
  *                                        word per user, E = 64), 9 the tie repair reads every pattern's dishes.  Same lists, bit for bit.
  * topk_block       0        0 128 256    users per block of a pruned pipelined launch (0 = the launcher's choice)
- * variant          0        7 9 11 12 13 14 15, 100 + n
+ * variant          0        7 9 11 12 13 14 15 16, 100 + n
  *                                        7 / 9: retrieval on the dense MFMA kernel / on the one-block-per-user kernel; 9 also forces the generic pair
  *                                        and head kernels; 11 / 12: the pair kernel's throughput / latency form whatever the batch size; 13: tie
  *                                        repair's one-block-per-user tier from the third listed user on; 14: the nine-launch training step;
  *                                        15: the retrieval scan's progress-word wait gives up at once (M2D_ERR_KERNEL_TIMEOUT: test hook);
+ *                                        16: the MLP head's row offsets in 16-byte units (the instantiation tables of 4 GiB and more take);
  *                                        100 + n: n dish-range splits in retrieval
  * (round 6 removed the values no test or profile script used: topk_prune 3 / 6, topk_probes, variant 8)
  *

@@ -70,6 +70,34 @@ def test_mlp_scores_match_restatement(E, C, H1, H2, kernel, x3, form):
         eng.close()
 
 
+@pytest.mark.parametrize("E", [64, 128])
+def test_mlp_large_table_instantiation_gives_the_same_bits(E):
+    """m2d_mlp_pc<KCH, OFF32>: tables under 4 GiB take 32-bit byte offsets and scalar-base row loads, larger ones (up to 64 GiB)
+    offsets in units of 16 B -- the same loads, the same arithmetic.  "variant" = 16 runs the second form on small tables: the same
+    scores bit for bit, a bad id reported alike."""
+    import torch
+    from foodrec_amd import ScoringEngine
+    U, I, C, B = 3000, 500, 4, 40000
+    PM, RE, CE, users, items, _ = random_case(U, I, C, E, B, seed=E + 5)
+    rng = np.random.default_rng(E)
+    dish_cats = rng.integers(0, 2, (I, C)).astype(np.float32)
+    dish_cats[dish_cats.sum(1) == 0, 1] = 1
+    eng = ScoringEngine(PM, RE, CE)
+    eng.set_dish_categories(dish_cats)
+    eng.set_mlp_head(*_head((C + 1) * E, 256, 64, rng, scale=3.0))
+    ut, it = torch.as_tensor(users, device="cuda"), torch.as_tensor(items, device="cuda")
+    a = eng.score_pairs_mlp(ut, it); eng.check()
+    assert eng.last_kernel() == "m2d_mlp_pc_bf16x3"
+    eng.set_option("variant", 16)
+    b = eng.score_pairs_mlp(ut, it); eng.check()
+    assert eng.last_kernel() == "m2d_mlp_pc_bf16x3"
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    bad = users.copy(); bad[123] = U + 7
+    with pytest.raises(IndexError, match="user id %d at position 123" % (U + 7)):
+        eng.score_pairs_mlp(torch.as_tensor(bad, device="cuda"), it); eng.check()
+    eng.set_option("variant", 0)
+
+
 @pytest.mark.parametrize("coef", [0.99] + COEFS)
 def test_mlp_reduces_to_reference_and_reports_bad_ids(coef):
     import torch
