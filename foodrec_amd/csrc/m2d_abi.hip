@@ -124,6 +124,7 @@ void release(m2d_engine *h)
     if (h->mlp_w1pad) (void)hipFree(h->mlp_w1pad);
     if (h->mlp_w1pc) (void)hipFree(h->mlp_w1pc);
     if (h->mlp_pg) (void)hipFree(h->mlp_pg);
+    if (h->mlp_pat8) (void)hipFree(h->mlp_pat8);
     if (h->user_high) (void)hipFree(h->user_high);
     if (h->dish_high) (void)hipFree(h->dish_high);
     if (h->own_ing) {

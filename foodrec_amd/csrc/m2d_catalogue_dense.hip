@@ -454,6 +454,7 @@ int m2d_ensure_dish_vectors(m2d_engine *h, hipStream_t st)
                        h->dish_cats, h->dish_high, h->I, h->C, h->E, h->a, h->b, h->dish_vec, rows);
     M2D_HIP_TRY(h, hipGetLastError());
     h->dish_vec_valid = true;
+    ++h->dish_vec_gen;
     return M2D_OK;
 }
 

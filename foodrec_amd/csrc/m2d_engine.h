@@ -60,6 +60,9 @@ struct m2d_engine {
     float *mlp_w1pad = nullptr;         // W1 zero-padded to a multiple of 64 rows, for K = (C + 1) E that is not one (built lazily)
     void *mlp_w1pc = nullptr;           // W1 | W2 image of the producer / consumer kernel (built lazily)
     int32_t *mlp_pg = nullptr;          // per-launch pair grouping of that kernel: histogram | tile count | tile blocks | slot -> pair
+    uint8_t *mlp_pat8 = nullptr;        // [I] a dish's pattern of non-zero mask weights (all blocks for n = 0 / NaN): what the grouping reads per pair
+    uint64_t mlp_pat8_gen = 0;          // the dish-vector build it belongs to (dish_vec_gen)
+    int64_t mlp_pat8_rows = 0;
     size_t mlp_pg_cap = 0;              // ints
 
     // derived table for pair scoring: <U_high[u], CE_c> per user and category (built lazily by large m2d_score_pairs calls;
@@ -71,6 +74,7 @@ struct m2d_engine {
     float *dish_vec = nullptr;  // [I_pad, (C+1)*E]
     int64_t dish_vec_rows = 0;
     bool dish_vec_valid = false;
+    uint64_t dish_vec_gen = 0;          // counts m2d_ensure_dish_vectors' rebuilds (what hangs on the dish masks rebuilds with it)
 
     // pattern-grouped retrieval tables (0/1 masks only; built lazily by m2d_topk_users)
     float *grp_rs = nullptr;            // [grp_cap_rows, E] Recipe_Embedding rows sorted by (mask pattern, dish id)

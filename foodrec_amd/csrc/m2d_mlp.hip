@@ -507,21 +507,37 @@ __device__ __forceinline__ int pg_pattern(const float *cats, int C, int64_t I, i
     return (n == 0.f || n != n) ? (1 << C) - 1 : pat;
 }
 
-__global__ __launch_bounds__(256) void m2d_mlp_pg_hist(const int32_t *items, int64_t B, int64_t I, const float *cats, int C,
+// the per-dish pattern byte, once per mask table: what m2d_mlp_pg_hist / _scatter read per pair instead of the dish's C mask weights
+__global__ __launch_bounds__(256) void m2d_mlp_pg_pat8(const float *cats, int C, int64_t I, const int32_t *nogroup, uint8_t *pat8)
+{
+    const int32_t zero = 0;
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d < I) pat8[d] = (uint8_t)pg_pattern(cats, C, I, (int32_t)d, &zero);
+    (void)nogroup;
+}
+
+// a pair's bucket: the dish's pattern byte; every block while a table value is not finite (`group`, see pg_pattern) or for a bad id
+__device__ __forceinline__ int pg_bucket(const uint8_t *pat8, int C, int64_t I, int32_t did, int nogroup)
+{
+    return (nogroup || did < 0 || (int64_t)did >= I) ? (1 << C) - 1 : (int)pat8[did];
+}
+
+__global__ __launch_bounds__(256) void m2d_mlp_pg_hist(const int32_t *items, int64_t B, int64_t I, const uint8_t *pat8, int C,
                                                        const int32_t *group, int32_t *hist)
 {
     // lane p of a wave counts pattern p in a register (one ballot + popcount per pattern and 64 pairs: no contended
     // atomics on a dozen addresses), then one LDS add and one global add per pattern and block
     __shared__ int32_t sh[PG_MAXPAT];
     const int lane = threadIdx.x & 63, npat = 1 << C;
+    const int nogroup = *group != 0;
     if (threadIdx.x < PG_MAXPAT) sh[threadIdx.x] = 0;
     __syncthreads();
     int32_t cnt = 0;
     const int64_t step = (int64_t)gridDim.x * 256;
     for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < B; i0 += step) {   // block-uniform trip count: every ballot is full-wave
         const int64_t i = i0 + threadIdx.x;
-        const int pat = i < B ? pg_pattern(cats, C, I, items[i], group) : -1;
-        for (int q = 0; q < npat; ++q) {
+        const int pat = i < B ? pg_bucket(pat8, C, I, items[i], nogroup) : -1;
+        for (int q = 1; q < npat; ++q) {                                 // (pattern 0 does not occur: an empty mask takes every block)
             const unsigned long long b = __ballot(pat == q);
             if (lane == q) cnt += __popcll(b);
         }
@@ -558,12 +574,15 @@ __global__ __launch_bounds__(256) void m2d_mlp_pg_scan(int32_t *hist, int C, uin
     if (threadIdx.x < npat) hist[threadIdx.x] = start[threadIdx.x] * PC_PAIRS;
 }
 
-// chunks of 4096 pairs: count per pattern in LDS, reserve each pattern's range with ONE global add per chunk, place
-__global__ __launch_bounds__(256) void m2d_mlp_pg_scatter(const int32_t *items, int64_t B, int64_t I, const float *cats, int C,
+// chunks of 4096 pairs: count per pattern in LDS, reserve each pattern's range with ONE global add per chunk, place.  (Round 6
+// tried ranking by ballot instead of the per-pair LDS atomics -- a wave's lanes of one pattern behind one add of their leader:
+// 97 us against 88 for 4 M pairs, the 240 dependent ballot / add / readlane rounds per wave cost more than the contention.)
+__global__ __launch_bounds__(256) void m2d_mlp_pg_scatter(const int32_t *items, int64_t B, int64_t I, const uint8_t *pat8, int C,
                                                           const int32_t *group, int32_t *cursor, int32_t *perm)
 {
     __shared__ int32_t cnt[PG_MAXPAT], base[PG_MAXPAT];
     constexpr int CH = 4096;
+    const int nogroup = *group != 0;
     for (int64_t c0 = (int64_t)blockIdx.x * CH; c0 < B; c0 += (int64_t)gridDim.x * CH) {
         if (threadIdx.x < PG_MAXPAT) cnt[threadIdx.x] = 0;
         __syncthreads();
@@ -571,7 +590,7 @@ __global__ __launch_bounds__(256) void m2d_mlp_pg_scatter(const int32_t *items, 
 #pragma unroll
         for (int r = 0; r < CH / 256; ++r) {
             const int64_t i = c0 + r * 256 + threadIdx.x;
-            pat[r] = i < B ? pg_pattern(cats, C, I, items[i], group) : -1;
+            pat[r] = i < B ? pg_bucket(pat8, C, I, items[i], nogroup) : -1;
             if (pat[r] >= 0) atomicAdd(&cnt[pat[r]], 1);
         }
         __syncthreads();
@@ -1216,6 +1235,15 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
                 M2D_HIP_TRY(h, hipMalloc((void **)&h->mlp_pg, need * sizeof(int32_t)));
                 h->mlp_pg_cap = need;
             }
+            if (!h->mlp_pat8 || h->mlp_pat8_gen != h->dish_vec_gen || h->mlp_pat8_rows != h->I) {      // once per mask table
+                if (h->mlp_pat8 && h->mlp_pat8_rows != h->I) { M2D_HIP_TRY(h, hipFree(h->mlp_pat8)); h->mlp_pat8 = nullptr; }
+                if (!h->mlp_pat8) M2D_HIP_TRY(h, hipMalloc((void **)&h->mlp_pat8, (size_t)h->I));
+                h->mlp_pat8_rows = h->I;
+                hipLaunchKernelGGL(m2d_mlp_pg_pat8, dim3((unsigned)((h->I + 255) / 256)), dim3(256), 0, stream, h->dish_cats, h->C, h->I,
+                                   h->nonfinite_dev, h->mlp_pat8);
+                M2D_HIP_TRY(h, hipGetLastError());
+                h->mlp_pat8_gen = h->dish_vec_gen;
+            }
             int32_t *hist = h->mlp_pg, *ntl = hist + PG_MAXPAT, *perm = ntl + 4 + tiles_max;
             uint32_t *tblocks = reinterpret_cast<uint32_t *>(ntl + 4);
             M2D_HIP_TRY(h, hipMemsetAsync(hist, 0, (PG_MAXPAT + 4) * sizeof(int32_t), stream));
@@ -1223,10 +1251,10 @@ int m2d_launch_score_pairs_mlp(m2d_engine *h, const int32_t *users, const int32_
             const unsigned gcap = (unsigned)h->num_cu * 8;
             const int64_t hb = (B + 255) / 256, sb = (B + 4095) / 4096;
             hipLaunchKernelGGL(m2d_mlp_pg_hist, dim3((unsigned)(hb < gcap ? hb : gcap)), dim3(256), 0, stream, items, B, h->I,
-                               h->dish_cats, h->C, h->nonfinite_dev, hist);
+                               h->mlp_pat8, h->C, h->nonfinite_dev, hist);
             hipLaunchKernelGGL(m2d_mlp_pg_scan, dim3(1), dim3(256), 0, stream, hist, h->C, tblocks, ntl);
             hipLaunchKernelGGL(m2d_mlp_pg_scatter, dim3((unsigned)(sb < gcap ? sb : gcap)), dim3(256), 0, stream, items, B, h->I,
-                               h->dish_cats, h->C, h->nonfinite_dev, hist, perm);
+                               h->mlp_pat8, h->C, h->nonfinite_dev, hist, perm);
             M2D_HIP_TRY(h, hipGetLastError());
             a.perm = perm; a.tile_blocks = tblocks; a.ntiles_dev = ntl;
         }
