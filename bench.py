@@ -211,6 +211,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clock settle (disclosed in the line: config.settle): the part ramps its clocks over the first tens of ms of
+    # work after an idle period -- with the driver's W = 5, K = 20 the timed launches ran 6 % slower than launches
+    # 30 ... 230 of a longer run.  Untimed, before the W warmup steps, the same step on the same buffers; at most
+    # --settle-ms of wall time
+    settle = {"ms_budget": a.settle_ms, "launches": 0, "ms": 0.0}
+    if a.settle_ms > 0:
+        import time as _time
+        t_s = _time.perf_counter()
+        while (_time.perf_counter() - t_s) * 1e3 < a.settle_ms:
+            step()
+            settle["launches"] += 1
+            torch.cuda.synchronize()
+        settle["ms"] = (_time.perf_counter() - t_s) * 1e3
     for _ in range(a.warmup):
         step()
     eng.check()
@@ -267,6 +280,10 @@ def main():
                          "table_bytes": table_bytes},
             "world": ident, **cli.ident_scalars(ident),
         }
+        settle["what"] = ("untimed launches of the step BEFORE the W warmup steps, so that the timed steps run at the "
+                          "clocks the part holds under this load (not counted in `steps` / `warmup`; "
+                          "--settle-ms 0: off)")
+        line["config"]["settle"] = settle
         if survey is not None:
             line["roofline"].update(survey)
         if skip:

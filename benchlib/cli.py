@@ -57,6 +57,10 @@ def parse(argv=None):
     p.add_argument("--sweep", action="store_true", help="also time the kernel knobs (stderr only)")
     p.add_argument("--opt", action="append", default=[], help="engine option name=value")
     p.add_argument("--out", default=None, help="also write the JSON line to this file (rank 0)")
+    p.add_argument("--settle-ms", type=float, default=150.0,
+                   help="before the W warmup steps: run the step untimed for this long so that the part's clocks have "
+                        "ramped (the first ~25 launches after an idle period run 5-7 %% slow); not counted as steps, "
+                        "reported in the line as config.settle; 0 = off")
     p.add_argument("--side-timeout", type=float, default=420.0,
                    help="seconds the legs after the timed region may take before rank 0 prints the headline line "
                         "without them and every rank exits")
