@@ -82,6 +82,17 @@ def time_steps(torch, eng, users, items, cats, out, steps, step=None):
     return wall, per
 
 
+def settle(torch, step, ms=100.0):
+    """Untimed launches of `step` for `ms` of wall time: a leg that follows host work (an idle GPU) would otherwise be
+    timed while the part ramps its clocks (bench.py's config.settle does the same in front of the headline's warmup)."""
+    t0, n = time.perf_counter(), 0
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        step()
+        n += 1
+        torch.cuda.synchronize()
+    return n
+
+
 def usable_cores():
     """Host cores this process may actually run on: the affinity mask capped by the cgroup CPU quota.  (A GPU box
     hands one GPU's job a share of a 256-thread host; 256 threads on that share run slower than 16.)"""
