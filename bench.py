@@ -437,8 +437,8 @@ def main():
             if world > 1 and wl == "pairs" and "error" not in scaling:
                 # a SCALE record headlines `value`, which is the collective-free pair path in weak scaling (about N x
                 # by construction): say first where the path north_star scales is
-                prefix = ("[strong-scaling top-k path: topk_path_ms = %.1f, see topk_path_*; `value` = weak-scaling "
-                          "pair path] " % (scaling.get("wall_ms") or float("nan")))
+                prefix = ("[topk_path_ms = %.1f is the strong-scaling path; `value` scales weakly] "
+                          % (scaling.get("wall_ms") or float("nan")))
                 line["config"]["workload"] = prefix + line["config"]["workload"]
             line["scaling_path"] = scaling                  # ("scaling" itself is the contract's "weak" / "strong")
             line.update(linelib.scaling_scalars(scaling))
